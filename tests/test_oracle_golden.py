@@ -1,0 +1,112 @@
+"""Pins the CPU oracle (oracle/) to outputs of the reference itself (tests/golden/*.npz,
+produced by tests/golden/make_golden.py which imports /root/reference unmodified)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vq_oracle as O
+from oracle import transformer_oracle as TO
+
+TINY = dict(ddconfig=dict(z_channels=32, in_channels=3, out_channels=3, channels=[32, 32, 64, 64],
+                          num_res_blocks=1, resolution=32, attn_resolutions=[8], dropout=0.0),
+            n_embed=64, embed_dim=32)
+IMG_DD = dict(z_channels=256, in_channels=3, out_channels=3, channels=[128, 128, 128, 256, 512, 512],
+              num_res_blocks=2, resolution=512, attn_resolutions=[32], dropout=0.0)
+
+
+def _close(a, b, rtol=1e-4, atol=1e-5):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def _run_train(cfg, x, seed, grad_keys):
+    sd = O.synth_state_dict(cfg["ddconfig"], cfg["n_embed"], cfg["embed_dim"], seed=seed)
+    for k, v in sd.items():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    dec, q_loss, idx, z = O.vqbase_forward(sd, x, cfg["ddconfig"], training=True)
+    loss = O.recon_vq_loss(x, dec, q_loss)
+    loss.backward()
+    return sd, dec, q_loss, idx, z, loss
+
+
+def test_tiny_train_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "vq_tiny.npz"))
+    x = O.synth_image_batch(2, 3, 32, seed=0)
+    sd, dec, q_loss, idx, z, loss = _run_train(TINY, x, 0, None)
+    assert np.array_equal(idx.numpy(), g["train:idx"])          # indices bit-exact
+    _close(z, g["train:z"]); _close(dec, g["train:rec"]); _close(q_loss, g["train:q_loss"])
+    _close(loss, g["train:loss"])
+    for k in g.files:
+        if k.startswith("train:grad:"):
+            _close(sd[k[len("train:grad:"):]].grad, g[k], rtol=2e-3, atol=1e-6)
+    tot = np.sqrt(sum(float((v.grad.double() ** 2).sum()) for v in sd.values() if v.grad is not None))
+    assert abs(tot - float(g["train:gradnorm_total"])) < 1e-4 * tot
+
+
+def test_tiny_eval_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "vq_tiny.npz"))
+    x = O.synth_image_batch(2, 3, 32, seed=0)
+    sd = O.synth_state_dict(TINY["ddconfig"], TINY["n_embed"], TINY["embed_dim"], seed=0)
+    with torch.no_grad():
+        dec, q_loss, idx, z = O.vqbase_forward(sd, x, TINY["ddconfig"], training=False)
+    assert np.array_equal(idx.numpy(), g["eval:idx"])
+    _close(dec, g["eval:rec"]); _close(z, g["eval:z"])
+
+
+def test_seg_tiny_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "vq_seg_tiny.npz"))
+    cfg = dict(TINY, ddconfig=dict(TINY["ddconfig"], in_channels=159, out_channels=159))
+    x = O.synth_image_batch(2, 159, 16, seed=3)
+    sd, dec, q_loss, idx, z, loss = _run_train(cfg, x, 3, None)
+    assert np.array_equal(idx.numpy(), g["train:idx"])
+    _close(dec, g["train:rec"]); _close(loss, g["train:loss"])
+    _close(sd["encoder.model.0.weight"].grad, g["train:grad:encoder.model.0.weight"], rtol=2e-3, atol=1e-6)
+
+
+def test_img256_matches_reference(golden_dir):
+    """Full VQ-IMG config (conf/img_config.yaml model block), B=1, fwd+bwd."""
+    g = np.load(os.path.join(golden_dir, "vq_img256.npz"))
+    cfg = dict(ddconfig=IMG_DD, n_embed=8192, embed_dim=256)
+    x = O.synth_image_batch(1, 3, 256, seed=1)
+    sd, dec, q_loss, idx, z, loss = _run_train(cfg, x, 1, None)
+    assert np.array_equal(idx.numpy(), g["idx"])
+    _close(dec[:, :, ::8, ::8], g["rec_sub"], rtol=1e-3, atol=1e-4)
+    _close(z[:, ::8], g["z_sub"], rtol=1e-3, atol=1e-4)
+    _close(loss, g["loss"])
+    _close(sd["decoder.model.28.weight"].grad, g["grad:decoder.model.28.weight"], rtol=5e-3, atol=1e-6)
+    tot = np.sqrt(sum(float((v.grad.double() ** 2).sum()) for v in sd.values() if v.grad is not None))
+    assert abs(tot - float(g["gradnorm_total"])) < 1e-3 * tot
+
+
+@pytest.mark.parametrize("tag", ["scaled", "default"])
+def test_codebook_matches_reference(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"codebook_{tag}.npz"))
+    rs = np.random.RandomState(7)
+    z = torch.from_numpy(rs.randn(4, 256, 16, 16).astype(np.float32))
+    scaled = rs.randn(8192, 256).astype(np.float32)
+    default = rs.uniform(-1 / 8192, 1 / 8192, size=(8192, 256)).astype(np.float32)
+    cb = torch.from_numpy(scaled if tag == "scaled" else default)
+    zq, loss, idx = O.codebook_forward(cb, z)
+    assert np.array_equal(idx.numpy(), g["idx"])
+    _close(loss, g["loss"]); _close(zq[:, ::16], g["zq_sub"])
+
+
+def test_transformer_tiny_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "transformer_tiny.npz"))
+    cfg = dict(num_layers=2, hidden_dim=64, num_attn_heads=4, image_vocab_size=96, seg_vocab_size=40,
+               text_vocab_size=58, image_tokens_per_dim=4, seg_tokens_per_dim=2, text_length=8)
+    sd = TO.synth_transformer_state_dict(cfg, seed=5)
+    for v in sd.values():
+        v.requires_grad_(True)
+    text, seg, img = TO.synth_tokens(cfg, batch=2, seed=5)
+    logits = TO.make_a_scene_forward(sd, cfg, text, seg, img)
+    loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), img.reshape(-1))
+    loss.backward()
+    _close(logits, g["logits"], rtol=1e-4, atol=1e-5)
+    _close(loss, g["loss"])
+    for k in g.files:
+        if k.startswith("grad:"):
+            _close(sd[k[5:]].grad, g[k], rtol=2e-3, atol=1e-6)
