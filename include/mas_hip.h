@@ -1,0 +1,133 @@
+/*
+ * mas_hip.h -- C ABI of libmas_hip.so, the MI355X (gfx950) kernels behind the
+ * Make-A-Scene hot path (VQ-IMG / VQ-SEG conv stack, vector quantiser, attention).
+ *
+ * The reference (CasualGANPapers/Make-A-Scene) has no FFI layer: its arithmetic is
+ * reached through torch.nn call sites.  Each entry point below names the reference
+ * call site(s) it replaces.  The Python host (make-a-scene_amd/mas_hip/) binds these
+ * with ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless noted.
+ *   - the caller owns every buffer (incl. workspaces); the library never allocates or
+ *     frees device memory and keeps no pointer after return.
+ *   - asynchronous on the caller's hipStream_t (passed as void*); no hidden syncs.
+ *   - return 0 on success, a negative MAS_E* code otherwise; mas_last_error() gives a
+ *     thread-local message.  No C++ exception crosses the ABI.
+ *   - activations are NHWC ("channels last"), element type MAS_BF16 or MAS_F32,
+ *     accumulation is always fp32.
+ */
+#ifndef MAS_HIP_H
+#define MAS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAS_ABI_VERSION 1
+
+enum { MAS_OK = 0, MAS_EINVAL = -1, MAS_EUNSUPPORTED = -2, MAS_ELAUNCH = -3, MAS_EWORKSPACE = -4 };
+enum { MAS_F32 = 0, MAS_BF16 = 1 };
+/* input prologue fused into the conv / wgrad loaders */
+enum { MAS_ACT_NONE = 0,      /* a = x                                   */
+       MAS_ACT_AFFINE = 1,    /* a = x*scale[n,c] + shift[n,c]  (GroupNorm apply, modules.py:40-41) */
+       MAS_ACT_AFFINE_SILU = 2 /* a = silu(x*scale + shift)     (+ swish, modules.py:35-37)         */ };
+
+typedef struct MasConvDesc {
+    int32_t N, H, W, Cin;       /* input  [N,H,W,Cin]  (the tensor in memory; before any upsample fold) */
+    int32_t Ho, Wo, Cout;       /* output [N,Ho,Wo,Cout] */
+    int32_t ks;                 /* 1 or 3 (square)  */
+    int32_t stride;             /* 1 or 2           */
+    int32_t pad_top, pad_left;  /* input row = ho*stride + kh - pad_top ; rows/cols outside [0,H)x[0,W) read 0
+                                   (covers padding=1, and the right/bottom-only pad of Downsample, modules.py:76-78) */
+    int32_t in_dtype;           /* MAS_F32 | MAS_BF16 : x, residual, (dy for wgrad) */
+    int32_t out_dtype;          /* MAS_F32 | MAS_BF16 : y */
+    int32_t act;                /* MAS_ACT_* prologue applied to x on load (padding stays exactly 0) */
+    int32_t upsample;           /* 1: logical input is nearest-x2 of x (F.interpolate, modules.py:56): pixel (h,w) reads x[h>>1][w>>1];
+                                   H,W above are then the PHYSICAL (pre-upsample) size */
+} MasConvDesc;
+
+int         mas_abi_version(void);
+const char* mas_last_error(void);
+
+/* ---- weight packing (host-visible layout contract) -------------------------------
+ * Packs an OIHW fp32 parameter (nn.Conv2d.weight, e.g. modules.py:93-104) into the
+ * kernel layout [ks*ks][Cout_pad][Cin_pad] (dtype `dtype`, zero padded; Cout_pad =
+ * roundup(Cout,32), Cin_pad = roundup(Cin,16)).
+ *   transpose=0 : forward operand            Wp[t][o][i] = W[o][i][kh][kw], t = kh*ks+kw
+ *   transpose=1 : data-gradient operand      Wp[t][i][o] = W[o][i][ks-1-kh][ks-1-kw]
+ *                 (conv of dY with the flipped, in/out-swapped filter; then "Cout"=Cin)
+ */
+size_t mas_packed_weight_elems(int Cout, int Cin, int ks);
+int    mas_pack_conv_weight(const float* w_oihw, void* packed, int Cout, int Cin, int ks,
+                            int transpose, int dtype, void* stream);
+
+/* ---- GroupNorm statistics (replaces the reduction half of torch.nn.GroupNorm,
+ * modules.py:40-41).  x: [N,HW,C] NHWC.  Outputs:
+ *   mean_rstd [N][G][2] fp32, scale_shift [N][C][2] fp32 with
+ *   scale = rstd*gamma, shift = beta - mean*rstd*gamma  (consumed by the conv prologue).
+ * workspace: mas_gn_stats_workspace(N,C) bytes.                                      */
+size_t mas_gn_stats_workspace(int N, int C);
+int    mas_gn_stats(const void* x, int dtype, int N, int HW, int C, int G, float eps,
+                    const float* gamma, const float* beta, float* mean_rstd, float* scale_shift,
+                    void* workspace, size_t ws_bytes, void* stream);
+
+/* ---- GroupNorm(+SiLU) backward.  Given da = dL/d act(gn(x)) computes
+ *   dx [N,HW,C] (+ dres if non-NULL, the residual-branch gradient), dgamma[C], dbeta[C].
+ * act is MAS_ACT_AFFINE or MAS_ACT_AFFINE_SILU.                                       */
+size_t mas_gn_bwd_workspace(int N, int C);
+int    mas_gn_bwd(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G,
+                  int act, const float* gamma, const float* mean_rstd, const float* scale_shift,
+                  void* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, void* stream);
+
+/* ---- convolution forward  (replaces F.conv2d at modules.py:49,68,93,100,113,145-160,
+ * 219,236,345,364 and vqvae.py:15,18, with the GroupNorm-apply/SiLU of modules.py:121-128
+ * fused into the input loader and bias / residual add (modules.py:136,191) into the epilogue).
+ *   x         [N,H,W,Cin]     in_dtype
+ *   scale_shift [N][Cin][2]   fp32, required iff act != NONE
+ *   w_packed  from mas_pack_conv_weight (same dtype as x)
+ *   bias      [Cout] fp32 or NULL
+ *   residual  [N,Ho,Wo,Cout]  in_dtype or NULL (added in fp32 before the store)
+ *   y         [N,Ho,Wo,Cout]  out_dtype
+ * The data gradient of a stride-1 conv is this same entry point called on dy with the
+ * transpose=1 packing and pad = ks-1-pad.                                             */
+int mas_conv_fwd(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed,
+                 const float* bias, const void* residual, void* y, void* stream);
+
+/* ---- convolution weight gradient  (autograd of the F.conv2d sites above)
+ *   dw [Cout][ks][ks][Cin] fp32 (caller zero-fills; accumulated with fp32 atomics),
+ *   dbias [Cout] fp32 or NULL (same).  x / scale_shift / act as in mas_conv_fwd
+ *   (the activated input is recomputed in the loader, never stored).                   */
+int mas_conv_wgrad(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy,
+                   float* dw, float* dbias, void* stream);
+
+/* ---- vector quantiser  (replaces Codebook.forward's distance / argmin / gather / loss,
+ * modules.py:501-509; never materialises d[M,K]).
+ *   z [M][D] fp32 (NHWC latent rows), codebook [K][D] fp32.
+ *   idx [M] int64 : argmin_k ( (|z|^2+|e_k|^2) - 2 z.e_k ), first minimum on ties
+ *   zq  [M][D] fp32 = codebook[idx]
+ *   sqerr [1] fp32 = sum (zq - z)^2      (loss = (1+beta) * sqerr / (M*D), modules.py:509)
+ * workspace: mas_vq_workspace(M,K) bytes.                                             */
+size_t mas_vq_workspace(int M, int K);
+int    mas_vq_argmin_fwd(const float* z, const float* codebook, int M, int K, int D,
+                         int64_t* idx, float* zq, float* sqerr, void* workspace, size_t ws_bytes, void* stream);
+/* backward of (z_q straight-through, loss):  dz = g_zq + g_loss*2/(M*D)*(z-e[idx]);
+ * dcodebook[idx] += g_loss*beta*2/(M*D)*(e[idx]-z)   (dcodebook zero-filled by caller).
+ * g_loss is a device scalar.                                                          */
+int    mas_vq_bwd(const float* z, const float* codebook, const int64_t* idx, const float* g_zq,
+                  const float* g_loss, float beta, int M, int K, int D, float* dz, float* dcodebook, void* stream);
+
+/* ---- small NHWC helpers on the path -------------------------------------------------
+ * nearest x2 upsample (F.interpolate, modules.py:56) and its adjoint (2x2 sum);
+ * zero-stuffing used by the stride-2 data gradient (adjoint of modules.py:76-78).      */
+int mas_upsample2x(const void* x, void* y, int dtype, int N, int H, int W, int C, void* stream);
+int mas_sumpool2x(const void* x, void* y, int dtype, int N, int Ho, int Wo, int C, void* stream);
+int mas_zero_stuff2x(const void* x, void* y, int dtype, int N, int H, int W, int C, int Hout, int Wout, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAS_HIP_H */

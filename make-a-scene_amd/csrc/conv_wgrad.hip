@@ -1,0 +1,278 @@
+// Convolution weight gradient for gfx950 (autograd of the F.conv2d sites listed in conv_fwd.hip;
+// reference models/modules.py:93-117,145-164,219,236,345,364, models/vqvae.py:15,18).
+//
+// GEMM view (per tap):  dW[tap][co][ci] = sum_pixels dY[pixel][co] * A[pixel (+) tap][ci]
+//   M = co (MFMA A operand = dY^T), N = ci (MFMA B operand = activated input), K = pixels.
+// Both operands need the contraction index (pixels) contiguous per lane, which NHWC does not give,
+// so both are transposed while being staged into LDS ([channel][pixel] images).  The input halo
+// patch is staged ONCE per pixel tile (prologue = GroupNorm apply + SiLU recomputed here, the
+// activated tensor is never stored) and every tap reads a column-shifted fragment of it: an aligned
+// 5-dword read + v_alignbit for the odd shift, plain register renaming for the even one.
+// One work-group (8 waves) owns a 128(co) x 64(ci) x all-taps accumulator block in registers and
+// walks a strided subset of the pixel tiles (split-K); partial sums are committed with fp32 atomics.
+#include "mas_common.h"
+
+namespace {
+
+struct WgradParams {
+    const void* x; const float* ss; const void* dy; float* dw; float* dbias;
+    int N, H, W, Cin, Ho, Wo, Cout;
+    int Hl, Wl, pad_top, pad_left, act, upsample;
+    int tiles_h, tiles_w, n_pt, n_co_t, n_ci_t, nsplit;
+};
+
+constexpr int NTW = 512, TWW = 16, BCO = 128, BCI = 64;
+
+template <typename T, int KS, int STRIDE, int THW>
+struct WGeo {
+    static constexpr int EPU = 16 / (int)sizeof(T);
+    static constexpr int NPIX = THW * TWW;
+    static constexpr int DS = NPIX + EPU;                       // dY^T row stride (elements)
+    static constexpr int PH = (THW - 1) * STRIDE + KS, PW = (TWW - 1) * STRIDE + KS;
+    static constexpr int PWA = 24;                              // padded plane width (>= 8*1+10)
+    static constexpr int PLANES = STRIDE;                       // stride 2: even / odd input columns
+    static constexpr int CS = PH * PLANES * PWA + EPU;          // per-channel stride (elements)
+    static constexpr size_t LDS_BYTES = (size_t)(BCO * DS + BCI * CS) * sizeof(T);
+};
+
+// 8 consecutive elements starting `shift` (0..2) elements after the 16-byte aligned pointer p
+__device__ __forceinline__ bf16x8 shifted8(const bf16_t* p, int shift) {
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(p);
+    const unsigned hi = *reinterpret_cast<const unsigned*>(p + 8);
+    u32x4 r;
+    if (shift == 0) r = lo;
+    else if (shift == 1) {
+        r[0] = __builtin_amdgcn_alignbit(lo[1], lo[0], 16); r[1] = __builtin_amdgcn_alignbit(lo[2], lo[1], 16);
+        r[2] = __builtin_amdgcn_alignbit(lo[3], lo[2], 16); r[3] = __builtin_amdgcn_alignbit(hi, lo[3], 16);
+    } else { r[0] = lo[1]; r[1] = lo[2]; r[2] = lo[3]; r[3] = hi; }
+    return *reinterpret_cast<bf16x8*>(&r);
+}
+__device__ __forceinline__ f32x8 shifted8(const float* p, int shift) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    const float c0 = p[8], c1 = p[9];
+    const float v[10] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c0, c1};
+    f32x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = v[j + shift];
+    return r;
+}
+
+template <typename T, int KS, int STRIDE, int THW>
+__global__ __launch_bounds__(NTW) void conv_wgrad_kernel(WgradParams p) {
+    using G = WGeo<T, KS, STRIDE, THW>;
+    using V8 = typename Vec8<T>::type;
+    constexpr int EPU = G::EPU, DS = G::DS, CS = G::CS, PW = G::PW, PH = G::PH, PWA = G::PWA;
+    constexpr int NTAP = KS * KS;
+    constexpr int DY_UPP = BCO / EPU;            // 16-byte units per pixel of the dY tile
+    constexpr int DY_UNITS = G::NPIX * DY_UPP;
+    constexpr int A_UPP = BCI / EPU;
+    constexpr int A_UNITS = PH * PW * A_UPP;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* dyt = reinterpret_cast<T*>(smem);         // [BCO][DS]
+    T* at = dyt + BCO * DS;                      // [BCI][CS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 5, l31 = lane & 31;
+    const int wco = (wave & 3) * 32, wci = (wave >> 2) * 32;
+
+    int bid = blockIdx.x;
+    const int split = bid % p.nsplit; bid /= p.nsplit;
+    const int ci_t = bid % p.n_ci_t; const int co_t = bid / p.n_ci_t;
+    const int co0 = co_t * BCO, ci0 = ci_t * BCI;
+
+    const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
+
+    f32x16 acc[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    const bool vec_dy = (p.Cout % EPU) == 0, vec_x = (p.Cin % EPU) == 0;
+    const int dy_cu = tid % DY_UPP, a_cu = tid % A_UPP;
+    float bsum[EPU];
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) bsum[e] = 0.0f;
+    const bool do_bias = (p.dbias != nullptr) && (ci_t == 0);
+
+    const T* a_frag_base = dyt + (wco + l31) * DS + g * 8;
+    const T* b_frag_base = at + (wci + l31) * CS + g * 8;
+
+    for (int pt = split; pt < p.n_pt; pt += p.nsplit) {
+        int t = pt;
+        const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+        const int th_i = t % p.tiles_h; const int n = t / p.tiles_h;
+        const int h0 = th_i * THW, w0 = tw_i * TWW;
+        __syncthreads();                         // previous tile's fragment reads are done
+        // ---- stage dY^T ------------------------------------------------------------
+        for (int u = tid; u < DY_UNITS; u += NTW) {
+            const int pix = u / DY_UPP;
+            const int ho = h0 + (pix >> 4), wo = w0 + (pix & 15);
+            const int cb = co0 + dy_cu * EPU;
+            float v[EPU];
+#pragma unroll
+            for (int e = 0; e < EPU; ++e) v[e] = 0.0f;
+            if (ho < p.Ho && wo < p.Wo && cb < p.Cout) {
+                const T* src = DY + ((size_t)(n * p.Ho + ho) * p.Wo + wo) * p.Cout + cb;
+                if (vec_dy) {
+                    u32x4 raw = *reinterpret_cast<const u32x4*>(src);
+                    const T* rv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+                    for (int e = 0; e < EPU; ++e) v[e] = (float)rv[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPU; ++e) if (cb + e < p.Cout) v[e] = (float)src[e];
+                }
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int e = 0; e < EPU; ++e) bsum[e] += v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < EPU; ++e) dyt[(dy_cu * EPU + e) * DS + pix] = (T)v[e];
+        }
+        // ---- stage A^T (activated input patch) ---------------------------------------
+        {
+            const int cb = ci0 + a_cu * EPU;
+            float sc[EPU], sh[EPU];
+            if (p.act != MAS_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < EPU; ++e) {
+                    const int c = cb + e;
+                    sc[e] = (c < p.Cin) ? p.ss[((size_t)n * p.Cin + c) * 2 + 0] : 0.0f;
+                    sh[e] = (c < p.Cin) ? p.ss[((size_t)n * p.Cin + c) * 2 + 1] : 0.0f;
+                }
+            }
+            for (int u = tid; u < A_UNITS; u += NTW) {
+                const int pp = u / A_UPP;
+                const int pr = pp / PW, pc = pp - pr * PW;
+                int ih = h0 * STRIDE + pr - p.pad_top, iw = w0 * STRIDE + pc - p.pad_left;
+                const bool inb = (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl);
+                if (p.upsample) { ih >>= 1; iw >>= 1; }
+                float v[EPU];
+#pragma unroll
+                for (int e = 0; e < EPU; ++e) v[e] = 0.0f;
+                if (inb && cb < p.Cin) {
+                    const T* src = X + ((size_t)(n * p.H + ih) * p.W + iw) * p.Cin + cb;
+                    if (vec_x) {
+                        u32x4 raw = *reinterpret_cast<const u32x4*>(src);
+                        const T* rv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+                        for (int e = 0; e < EPU; ++e) v[e] = (float)rv[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < EPU; ++e) if (cb + e < p.Cin) v[e] = (float)src[e];
+                    }
+                    if (p.act != MAS_ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < EPU; ++e) {
+                            float a = v[e] * sc[e] + sh[e];
+                            if (p.act == MAS_ACT_AFFINE_SILU) a = silu_f(a);
+                            v[e] = (cb + e < p.Cin) ? a : 0.0f;
+                        }
+                    }
+                }
+                const int off = (STRIDE == 1) ? (pr * PWA + pc) : (pr * 2 * PWA + (pc & 1) * PWA + (pc >> 1));
+#pragma unroll
+                for (int e = 0; e < EPU; ++e) at[(a_cu * EPU + e) * CS + off] = (T)v[e];
+            }
+        }
+        __syncthreads();
+        // ---- MFMA: for every patch row, every tap that touches it -------------------
+#pragma unroll
+        for (int pr = 0; pr < PH; ++pr) {
+            V8 bf[KS];
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+                const int plane = (STRIDE == 1) ? 0 : (kw & 1);
+                const int shift = (STRIDE == 1) ? kw : (kw >> 1);
+                bf[kw] = shifted8(b_frag_base + (pr * G::PLANES + plane) * PWA, shift);
+            }
+#pragma unroll
+            for (int kh = 0; kh < KS; ++kh) {
+                const int rr = pr - kh;
+                if (rr < 0 || (rr % STRIDE) != 0 || (rr / STRIDE) >= THW) continue;
+                const V8 af = ld8<T>(a_frag_base + (rr / STRIDE) * 16);
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw) mma16(acc[kh * KS + kw], af, bf[kw]);
+            }
+        }
+    }
+
+    // ---- commit: fp32 atomics into dW[co][kh][kw][ci] --------------------------------
+    const int ci = ci0 + wci + l31;
+    if (ci < p.Cin) {
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco + acc_row(lane, r);
+                if (co < p.Cout) atomicAdd(p.dw + ((size_t)co * NTAP + t) * p.Cin + ci, acc[t][r]);
+            }
+    }
+    if (do_bias) {
+        // reduce the per-thread column sums over threads that share a channel group (through LDS)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);       // [BCO]
+        for (int i = tid; i < BCO; i += NTW) red[i] = 0.0f;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) atomicAdd(&red[dy_cu * EPU + e], bsum[e]);
+        __syncthreads();
+        for (int i = tid; i < BCO; i += NTW)
+            if (co0 + i < p.Cout) atomicAdd(p.dbias + co0 + i, red[i]);
+    }
+}
+
+template <typename T, int KS, int STRIDE, int THW>
+int launch(WgradParams p, hipStream_t s) {
+    using G = WGeo<T, KS, STRIDE, THW>;
+    auto kern = conv_wgrad_kernel<T, KS, STRIDE, THW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess)
+            MAS_FAIL(MAS_ELAUNCH, "conv_wgrad: cannot set dynamic LDS size %zu", (size_t)G::LDS_BYTES);
+        attr_done = true;
+    }
+    p.tiles_h = mas_cdiv(p.Ho, THW); p.tiles_w = mas_cdiv(p.Wo, TWW);
+    p.n_pt = p.N * p.tiles_h * p.tiles_w;
+    p.n_co_t = mas_cdiv(p.Cout, BCO); p.n_ci_t = mas_cdiv(p.Cin, BCI);
+    const int out_tiles = p.n_co_t * p.n_ci_t;
+    int nsplit = mas_cdiv(512, out_tiles);
+    if (nsplit > p.n_pt) nsplit = p.n_pt;
+    if (nsplit < 1) nsplit = 1;
+    p.nsplit = nsplit;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(out_tiles * nsplit)), dim3(NTW), G::LDS_BYTES, s, p);
+    MAS_CHECK_LAUNCH("conv_wgrad");
+    return MAS_OK;
+}
+
+template <typename T>
+int launch_t(const WgradParams& p, int ks, int stride, hipStream_t s) {
+    if (ks == 1 && stride == 1) return launch<T, 1, 1, 8>(p, s);
+    if (ks == 3 && stride == 1) return launch<T, 3, 1, 8>(p, s);
+    if (ks == 3 && stride == 2) return launch<T, 3, 2, 4>(p, s);
+    MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad: unsupported ks=%d stride=%d", ks, stride);
+}
+
+}  // namespace
+
+extern "C" int mas_conv_wgrad(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy,
+                              float* dw, float* dbias, void* stream) {
+    if (!d || !x || !dy || !dw) MAS_FAIL(MAS_EINVAL, "conv_wgrad: null argument");
+    if (d->act != MAS_ACT_NONE && !scale_shift) MAS_FAIL(MAS_EINVAL, "conv_wgrad: act prologue needs scale_shift");
+    if (d->upsample && d->stride != 1) MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad: upsample fold needs stride 1");
+    WgradParams p;
+    p.x = x; p.ss = scale_shift; p.dy = dy; p.dw = dw; p.dbias = dbias;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+    p.Hl = d->upsample ? 2 * d->H : d->H; p.Wl = d->upsample ? 2 * d->W : d->W;
+    p.pad_top = d->pad_top; p.pad_left = d->pad_left; p.act = d->act; p.upsample = d->upsample;
+    p.tiles_h = p.tiles_w = p.n_pt = p.n_co_t = p.n_ci_t = p.nsplit = 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (d->in_dtype == MAS_BF16) return launch_t<bf16_t>(p, d->ks, d->stride, s);
+    if (d->in_dtype == MAS_F32) return launch_t<float>(p, d->ks, d->stride, s);
+    MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad: unsupported dtype %d", d->in_dtype);
+}

@@ -1,0 +1,341 @@
+// GroupNorm statistics and GroupNorm(+SiLU) backward for NHWC tensors on gfx950.
+// Replaces the reduction half of torch.nn.GroupNorm(32, C, eps=1e-6) (reference
+// models/modules.py:40-41) -- the normalise/affine/SiLU half is fused into the conv loaders --
+// and the autograd of GroupNorm + swish (modules.py:35-37,121-128).
+//
+// All kernels are HBM-bound streaming passes: 16-byte NHWC loads, a thread owns a fixed
+// 16-byte channel unit and walks pixels, so per-channel partial sums live in registers.
+// Reductions are two-stage and deterministic (per-block partials -> finalize kernel).
+#include "mas_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAX_SPLIT = 64;
+
+// ---------------------------------------------------------------------------------------
+// stage 1: per (n, split) block: sum and sum of squares per channel over a slab of pixels
+// partial layout: [N][split][C][2]
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_stats_partial(const T* __restrict__ x, int HW, int C, int nsplit,
+                                                       float* __restrict__ partial) {
+    constexpr int EPU = 16 / (int)sizeof(T);
+    const int n = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+    const int upp = C / EPU;                        // 16-byte units per pixel
+    const int tid = threadIdx.x;
+    extern __shared__ float red[];                  // [C][2]
+    for (int i = tid; i < 2 * C; i += NT) red[i] = 0.0f;
+    __syncthreads();
+    const int rows_per = (HW + nsplit - 1) / nsplit;
+    const int r0 = sp * rows_per, r1 = min(HW, r0 + rows_per);
+    // thread t handles unit (t % upp) when NT % upp == 0; otherwise units are walked linearly
+    const size_t base = (size_t)n * HW * C;
+    if (NT % upp == 0) {
+        const int cu = tid % upp, rstep = NT / upp;
+        float s[EPU], q[EPU];
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) { s[e] = 0.0f; q[e] = 0.0f; }
+        for (int r = r0 + tid / upp; r < r1; r += rstep) {
+            u32x4 raw = *reinterpret_cast<const u32x4*>(x + base + (size_t)r * C + cu * EPU);
+            const T* rv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+            for (int e = 0; e < EPU; ++e) { const float v = (float)rv[e]; s[e] += v; q[e] += v * v; }
+        }
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) {
+            atomicAdd(&red[(cu * EPU + e) * 2 + 0], s[e]);
+            atomicAdd(&red[(cu * EPU + e) * 2 + 1], q[e]);
+        }
+    } else {
+        const long long total = (long long)(r1 - r0) * upp;
+        for (long long u = tid; u < total; u += NT) {
+            const int r = r0 + (int)(u / upp), cu = (int)(u % upp);
+            u32x4 raw = *reinterpret_cast<const u32x4*>(x + base + (size_t)r * C + cu * EPU);
+            const T* rv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+            for (int e = 0; e < EPU; ++e) {
+                const float v = (float)rv[e];
+                atomicAdd(&red[(cu * EPU + e) * 2 + 0], v);
+                atomicAdd(&red[(cu * EPU + e) * 2 + 1], v * v);
+            }
+        }
+    }
+    __syncthreads();
+    float* out = partial + ((size_t)(n * nsplit + sp) * C) * 2;
+    for (int i = tid; i < 2 * C; i += NT) out[i] = red[i];
+}
+
+// stage 2: one block per n: combine splits (fp64), emit mean/rstd per group and scale/shift per channel
+__global__ __launch_bounds__(NT) void gn_stats_finalize(const float* __restrict__ partial, int HW, int C, int G,
+                                                        int nsplit, float eps, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ mean_rstd,
+                                                        float* __restrict__ ss) {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int cpg = C / G;
+    extern __shared__ double dred[];                // [C][2] then [G][2] floats
+    double* csum = dred;
+    float* gstat = reinterpret_cast<float*>(dred + 2 * C);
+    for (int c = tid; c < C; c += NT) {
+        double s = 0.0, q = 0.0;
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float* p = partial + ((size_t)(n * nsplit + sp) * C + c) * 2;
+            s += (double)p[0]; q += (double)p[1];
+        }
+        csum[2 * c] = s; csum[2 * c + 1] = q;
+    }
+    __syncthreads();
+    for (int g = tid; g < G; g += NT) {
+        double s = 0.0, q = 0.0;
+        for (int j = 0; j < cpg; ++j) { s += csum[2 * (g * cpg + j)]; q += csum[2 * (g * cpg + j) + 1]; }
+        const double m = (double)cpg * (double)HW;
+        const double mean = s / m;
+        double var = q / m - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        gstat[2 * g] = (float)mean; gstat[2 * g + 1] = rstd;
+        mean_rstd[((size_t)n * G + g) * 2 + 0] = (float)mean;
+        mean_rstd[((size_t)n * G + g) * 2 + 1] = rstd;
+    }
+    __syncthreads();
+    if (ss) {
+        for (int c = tid; c < C; c += NT) {
+            const float mean = gstat[2 * (c / cpg)], rstd = gstat[2 * (c / cpg) + 1];
+            const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+            const float sc = rstd * ga;
+            ss[((size_t)n * C + c) * 2 + 0] = sc;
+            ss[((size_t)n * C + c) * 2 + 1] = be - mean * sc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward stage 1: per (n, split): S1[c] = sum du, S2[c] = sum du*xhat, with
+//   u = x*sc+sh, du = da*silu'(u) (or da), xhat = (x-mean)*rstd
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_bwd_partial(const T* __restrict__ x, const T* __restrict__ da, int HW, int C,
+                                                     int G, int nsplit, int act, const float* __restrict__ mean_rstd,
+                                                     const float* __restrict__ ss, float* __restrict__ partial) {
+    constexpr int EPU = 16 / (int)sizeof(T);
+    const int n = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+    const int upp = C / EPU, cpg = C / G;
+    const int tid = threadIdx.x;
+    extern __shared__ float red[];
+    for (int i = tid; i < 2 * C; i += NT) red[i] = 0.0f;
+    __syncthreads();
+    const int rows_per = (HW + nsplit - 1) / nsplit;
+    const int r0 = sp * rows_per, r1 = min(HW, r0 + rows_per);
+    const size_t base = (size_t)n * HW * C;
+    const long long total = (long long)(r1 - r0) * upp;
+    const bool fixed = (NT % upp) == 0;
+    // generic walk; when `fixed`, cu is loop invariant and the per-channel constants stay in registers
+    int cu_prev = -1;
+    float sc[EPU], sh[EPU], mu[EPU], rs[EPU], s1[EPU], s2[EPU];
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) { s1[e] = 0.0f; s2[e] = 0.0f; sc[e] = sh[e] = mu[e] = rs[e] = 0.0f; }
+    for (long long u = tid; u < total; u += NT) {
+        const int r = r0 + (int)(u / upp), cu = (int)(u % upp);
+        if (cu != cu_prev) {
+            if (cu_prev >= 0 && !fixed) {
+#pragma unroll
+                for (int e = 0; e < EPU; ++e) {
+                    atomicAdd(&red[(cu_prev * EPU + e) * 2 + 0], s1[e]); atomicAdd(&red[(cu_prev * EPU + e) * 2 + 1], s2[e]);
+                    s1[e] = 0.0f; s2[e] = 0.0f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPU; ++e) {
+                const int c = cu * EPU + e;
+                sc[e] = ss[((size_t)n * C + c) * 2 + 0]; sh[e] = ss[((size_t)n * C + c) * 2 + 1];
+                mu[e] = mean_rstd[((size_t)n * G + c / cpg) * 2 + 0]; rs[e] = mean_rstd[((size_t)n * G + c / cpg) * 2 + 1];
+            }
+            cu_prev = cu;
+        }
+        const size_t off = base + (size_t)r * C + cu * EPU;
+        u32x4 rx = *reinterpret_cast<const u32x4*>(x + off);
+        u32x4 rd = *reinterpret_cast<const u32x4*>(da + off);
+        const T* xv = reinterpret_cast<const T*>(&rx);
+        const T* dv = reinterpret_cast<const T*>(&rd);
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) {
+            const float xe = (float)xv[e];
+            float du = (float)dv[e];
+            if (act == MAS_ACT_AFFINE_SILU) du *= dsilu_f(xe * sc[e] + sh[e]);
+            s1[e] += du; s2[e] += du * (xe - mu[e]) * rs[e];
+        }
+    }
+    if (cu_prev >= 0) {
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) {
+            atomicAdd(&red[(cu_prev * EPU + e) * 2 + 0], s1[e]); atomicAdd(&red[(cu_prev * EPU + e) * 2 + 1], s2[e]);
+        }
+    }
+    __syncthreads();
+    float* out = partial + ((size_t)(n * nsplit + sp) * C) * 2;
+    for (int i = tid; i < 2 * C; i += NT) out[i] = red[i];
+}
+
+// backward stage 2: one block per n: coefficient table coef[n][c][4] = {c1, k2, k3, 0} with
+//   dx = c1*du + k2*x + k3 ; c1 = rstd*gamma_c ; k2 = -rstd^2*B/m ; k3 = rstd*(mean*rstd*B - A)/m
+//   A = sum_{c in g} gamma_c S1_c ; B = sum_{c in g} gamma_c S2_c ; m = cpg*HW
+// and per-sample contributions to dgamma/dbeta: nsum[n][c][2] = {S2, S1}
+__global__ __launch_bounds__(NT) void gn_bwd_finalize(const float* __restrict__ partial, int HW, int C, int G, int nsplit,
+                                                      const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                      float* __restrict__ coef, float* __restrict__ nsum) {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int cpg = C / G;
+    extern __shared__ double dred[];
+    double* cs = dred;                               // [C][2]
+    for (int c = tid; c < C; c += NT) {
+        double a = 0.0, b = 0.0;
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float* p = partial + ((size_t)(n * nsplit + sp) * C + c) * 2;
+            a += (double)p[0]; b += (double)p[1];
+        }
+        cs[2 * c] = a; cs[2 * c + 1] = b;
+        nsum[((size_t)n * C + c) * 2 + 0] = (float)b;   // -> dgamma
+        nsum[((size_t)n * C + c) * 2 + 1] = (float)a;   // -> dbeta
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += NT) {
+        const int g = c / cpg;
+        double A = 0.0, B = 0.0;
+        for (int j = 0; j < cpg; ++j) {
+            const double ga = gamma ? (double)gamma[g * cpg + j] : 1.0;
+            A += ga * cs[2 * (g * cpg + j)]; B += ga * cs[2 * (g * cpg + j) + 1];
+        }
+        const double mean = mean_rstd[((size_t)n * G + g) * 2 + 0], rstd = mean_rstd[((size_t)n * G + g) * 2 + 1];
+        const double m = (double)cpg * (double)HW;
+        float* o = coef + ((size_t)n * C + c) * 4;
+        o[0] = (float)(rstd * (gamma ? (double)gamma[c] : 1.0));
+        o[1] = (float)(-rstd * rstd * B / m);
+        o[2] = (float)(rstd * (mean * rstd * B - A) / m);
+        o[3] = 0.0f;
+    }
+}
+
+// sum nsum over n -> dgamma, dbeta
+__global__ __launch_bounds__(NT) void gn_bwd_param_reduce(const float* __restrict__ nsum, int N, int C,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int n = 0; n < N; ++n) { a += (double)nsum[((size_t)n * C + c) * 2 + 0]; b += (double)nsum[((size_t)n * C + c) * 2 + 1]; }
+    if (dgamma) dgamma[c] = (float)a;
+    if (dbeta) dbeta[c] = (float)b;
+}
+
+// backward stage 3: elementwise dx = c1*du + k2*x + k3 (+ dres)
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_bwd_apply(const T* __restrict__ x, const T* __restrict__ da, const T* __restrict__ dres,
+                                                   T* __restrict__ dx, int HW, int C, int act, const float* __restrict__ ss,
+                                                   const float* __restrict__ coef, long long units_per_n) {
+    constexpr int EPU = 16 / (int)sizeof(T);
+    const int upp = C / EPU;
+    const int n = blockIdx.y;
+    const size_t base = (size_t)n * HW * C;
+    for (long long u = (long long)blockIdx.x * NT + threadIdx.x; u < units_per_n; u += (long long)gridDim.x * NT) {
+        const int cu = (int)(u % upp);
+        const size_t off = base + (size_t)u * EPU;
+        u32x4 rx = *reinterpret_cast<const u32x4*>(x + off);
+        u32x4 rd = *reinterpret_cast<const u32x4*>(da + off);
+        u32x4 rr = {0u, 0u, 0u, 0u};
+        if (dres) rr = *reinterpret_cast<const u32x4*>(dres + off);
+        const T* xv = reinterpret_cast<const T*>(&rx);
+        const T* dv = reinterpret_cast<const T*>(&rd);
+        const T* rv = reinterpret_cast<const T*>(&rr);
+        u32x4 ov;
+        T* o = reinterpret_cast<T*>(&ov);
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) {
+            const int c = cu * EPU + e;
+            const float xe = (float)xv[e];
+            float du = (float)dv[e];
+            if (act == MAS_ACT_AFFINE_SILU) du *= dsilu_f(xe * ss[((size_t)n * C + c) * 2] + ss[((size_t)n * C + c) * 2 + 1]);
+            const float* k = coef + ((size_t)n * C + c) * 4;
+            float v = k[0] * du + k[1] * xe + k[2];
+            if (dres) v += (float)rv[e];
+            o[e] = (T)v;
+        }
+        *reinterpret_cast<u32x4*>(dx + off) = ov;
+    }
+}
+
+int pick_split(int N, int HW) {
+    // enough blocks to fill 256 CUs a few times over, but >= 64 pixels per block
+    int s = mas_cdiv(1024, N);
+    if (s > MAX_SPLIT) s = MAX_SPLIT;
+    const int cap = HW / 64 > 0 ? HW / 64 : 1;
+    if (s > cap) s = cap;
+    return s < 1 ? 1 : s;
+}
+
+}  // namespace
+
+extern "C" size_t mas_gn_stats_workspace(int N, int C) { return (size_t)N * MAX_SPLIT * C * 2 * sizeof(float); }
+
+extern "C" int mas_gn_stats(const void* x, int dtype, int N, int HW, int C, int G, float eps, const float* gamma,
+                            const float* beta, float* mean_rstd, float* scale_shift, void* workspace, size_t ws_bytes,
+                            void* stream) {
+    if (!x || !mean_rstd || !workspace) MAS_FAIL(MAS_EINVAL, "gn_stats: null argument");
+    if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G) MAS_FAIL(MAS_EINVAL, "gn_stats: bad shape N=%d HW=%d C=%d G=%d", N, HW, C, G);
+    const int epu = dtype == MAS_BF16 ? 8 : 4;
+    if (C % epu) MAS_FAIL(MAS_EUNSUPPORTED, "gn_stats: C=%d must be a multiple of %d", C, epu);
+    if (ws_bytes < mas_gn_stats_workspace(N, C)) MAS_FAIL(MAS_EWORKSPACE, "gn_stats: workspace too small");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nsplit = pick_split(N, HW);
+    float* partial = reinterpret_cast<float*>(workspace);
+    const size_t lds1 = (size_t)2 * C * sizeof(float);
+    if (dtype == MAS_BF16)
+        hipLaunchKernelGGL(gn_stats_partial<bf16_t>, dim3(N * nsplit), dim3(NT), lds1, s, (const bf16_t*)x, HW, C, nsplit, partial);
+    else
+        hipLaunchKernelGGL(gn_stats_partial<float>, dim3(N * nsplit), dim3(NT), lds1, s, (const float*)x, HW, C, nsplit, partial);
+    MAS_CHECK_LAUNCH("gn_stats_partial");
+    const size_t lds2 = (size_t)2 * C * sizeof(double) + (size_t)2 * G * sizeof(float);
+    hipLaunchKernelGGL(gn_stats_finalize, dim3(N), dim3(NT), lds2, s, partial, HW, C, G, nsplit, eps, gamma, beta, mean_rstd, scale_shift);
+    MAS_CHECK_LAUNCH("gn_stats_finalize");
+    return MAS_OK;
+}
+
+// workspace: partial [N][MAX_SPLIT][C][2] + coef [N][C][4] + nsum [N][C][2]
+extern "C" size_t mas_gn_bwd_workspace(int N, int C) {
+    return ((size_t)N * MAX_SPLIT * C * 2 + (size_t)N * C * 4 + (size_t)N * C * 2) * sizeof(float);
+}
+
+extern "C" int mas_gn_bwd(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G, int act,
+                          const float* gamma, const float* mean_rstd, const float* scale_shift, void* dx, float* dgamma,
+                          float* dbeta, void* workspace, size_t ws_bytes, void* stream) {
+    if (!x || !da || !dx || !mean_rstd || !scale_shift || !workspace) MAS_FAIL(MAS_EINVAL, "gn_bwd: null argument");
+    if (act != MAS_ACT_AFFINE && act != MAS_ACT_AFFINE_SILU) MAS_FAIL(MAS_EINVAL, "gn_bwd: bad act %d", act);
+    if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G) MAS_FAIL(MAS_EINVAL, "gn_bwd: bad shape");
+    const int epu = dtype == MAS_BF16 ? 8 : 4;
+    if (C % epu) MAS_FAIL(MAS_EUNSUPPORTED, "gn_bwd: C=%d must be a multiple of %d", C, epu);
+    if (ws_bytes < mas_gn_bwd_workspace(N, C)) MAS_FAIL(MAS_EWORKSPACE, "gn_bwd: workspace too small");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nsplit = pick_split(N, HW);
+    float* partial = reinterpret_cast<float*>(workspace);
+    float* coef = partial + (size_t)N * MAX_SPLIT * C * 2;
+    float* nsum = coef + (size_t)N * C * 4;
+    const size_t lds1 = (size_t)2 * C * sizeof(float);
+    if (dtype == MAS_BF16)
+        hipLaunchKernelGGL(gn_bwd_partial<bf16_t>, dim3(N * nsplit), dim3(NT), lds1, s, (const bf16_t*)x, (const bf16_t*)da, HW, C, G, nsplit, act, mean_rstd, scale_shift, partial);
+    else
+        hipLaunchKernelGGL(gn_bwd_partial<float>, dim3(N * nsplit), dim3(NT), lds1, s, (const float*)x, (const float*)da, HW, C, G, nsplit, act, mean_rstd, scale_shift, partial);
+    MAS_CHECK_LAUNCH("gn_bwd_partial");
+    hipLaunchKernelGGL(gn_bwd_finalize, dim3(N), dim3(NT), (size_t)2 * C * sizeof(double), s, partial, HW, C, G, nsplit, gamma, mean_rstd, coef, nsum);
+    MAS_CHECK_LAUNCH("gn_bwd_finalize");
+    if (dgamma || dbeta) {
+        hipLaunchKernelGGL(gn_bwd_param_reduce, dim3(mas_cdiv(C, NT)), dim3(NT), 0, s, nsum, N, C, dgamma, dbeta);
+        MAS_CHECK_LAUNCH("gn_bwd_param_reduce");
+    }
+    const long long units_per_n = (long long)HW * C / epu;
+    int gx = (int)((units_per_n + NT - 1) / NT);
+    const int cap = mas_cdiv(2048, N) > 0 ? mas_cdiv(2048, N) : 1;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    if (dtype == MAS_BF16)
+        hipLaunchKernelGGL(gn_bwd_apply<bf16_t>, dim3(gx, N), dim3(NT), 0, s, (const bf16_t*)x, (const bf16_t*)da, (const bf16_t*)dres, (bf16_t*)dx, HW, C, act, scale_shift, coef, units_per_n);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply<float>, dim3(gx, N), dim3(NT), 0, s, (const float*)x, (const float*)da, (const float*)dres, (float*)dx, HW, C, act, scale_shift, coef, units_per_n);
+    MAS_CHECK_LAUNCH("gn_bwd_apply");
+    return MAS_OK;
+}

@@ -1,0 +1,82 @@
+// Shared device/host helpers for libmas_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/mas_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// ---- error plumbing (host) -------------------------------------------------------
+void mas_set_error(const char* fmt, ...);
+#define MAS_FAIL(code, ...) do { mas_set_error(__VA_ARGS__); return (code); } while (0)
+#define MAS_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) MAS_FAIL(MAS_ELAUNCH, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)
+
+static inline int mas_roundup(int a, int b) { return (a + b - 1) / b * b; }
+static inline int mas_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t mas_esize(int dtype) { return dtype == MAS_BF16 ? 2 : 4; }
+
+// ---- bf16 <-> f32 (round-to-nearest-even, same as torch's .to(bfloat16)) ---------
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)f; }
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int DT = MAS_F32;
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int DT = MAS_BF16;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return (float)*p; }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = (bf16_t)v; }
+};
+
+// 8 consecutive elements as a register vector
+template <typename T> struct Vec8;
+template <> struct Vec8<float> { typedef f32x8 type; };
+template <> struct Vec8<bf16_t> { typedef bf16x8 type; };
+
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type ld8(const T* p) {   // p 16B (bf16) / 32B (f32) aligned
+    return *reinterpret_cast<const typename Vec8<T>::type*>(p);
+}
+template <typename T>
+__device__ __forceinline__ void st8(T* p, typename Vec8<T>::type v) {
+    *reinterpret_cast<typename Vec8<T>::type*>(p) = v;
+}
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type zero8() {
+    typename Vec8<T>::type v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (T)0.0f;
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float u) { return u / (1.0f + __expf(-u)); }
+// d silu(u)/du = s*(1+u*(1-s)),  s = sigmoid(u)
+__device__ __forceinline__ float dsilu_f(float u) { float s = 1.0f / (1.0f + __expf(-u)); return s * (1.0f + u * (1.0f - s)); }
+
+// ---- MFMA: one 32x32 tile, K-chunk of 16 (8 elements per lane: k = 8*(lane>>5)+j) ---
+// D[row=(r&3)+8*(r>>2)+4*(lane>>5)][col=lane&31] += sum_k A[row][k]*B[k][col]
+// bf16: one v_mfma_f32_32x32x16_bf16.  f32: eight v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain);
+// MFMA j pairs lane-group g's element j of A with the same of B, so any (g,j)->k map is valid
+// as long as A and B are loaded with the same one.
+__device__ __forceinline__ void mma16(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x16& acc, const f32x8& a, const f32x8& b) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+}
+// accumulator row owned by (lane, reg)
+__device__ __forceinline__ int acc_row(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }

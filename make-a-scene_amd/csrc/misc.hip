@@ -1,0 +1,158 @@
+// Error plumbing, weight packing and the small NHWC helpers of libmas_hip.so.
+#include "mas_common.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+void mas_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* mas_last_error(void) { return g_err; }
+extern "C" int mas_abi_version(void) { return MAS_ABI_VERSION; }
+
+namespace {
+constexpr int NT = 256;
+
+// packed[t][o][i] (padded) from OIHW fp32; see mas_hip.h for the two modes
+template <typename T>
+__global__ __launch_bounds__(NT) void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin,
+                                                         int ks, int transpose, int rows_pad, int cols_pad) {
+    const long long total = (long long)ks * ks * rows_pad * cols_pad;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+        const int col = (int)(i % cols_pad);
+        const int row = (int)((i / cols_pad) % rows_pad);
+        const int t = (int)(i / ((long long)cols_pad * rows_pad));
+        const int kh = t / ks, kw = t % ks;
+        float v = 0.0f;
+        if (!transpose) {
+            if (row < Cout && col < Cin) v = w[(((size_t)row * Cin + col) * ks + kh) * ks + kw];
+        } else {
+            // rows = input channels (the dgrad's "Cout"), cols = output channels (its "Cin"), taps flipped
+            if (row < Cin && col < Cout) v = w[(((size_t)col * Cin + row) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)];
+        }
+        out[i] = (T)v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void upsample2x_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C) {
+    // one thread per 16-byte unit of the OUTPUT
+    constexpr int EPU = 16 / (int)sizeof(T);
+    const int upp = C / EPU;
+    const long long total = (long long)N * 2 * H * 2 * W * upp;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+        const int cu = (int)(i % upp); long long r = i / upp;
+        const int wo = (int)(r % (2 * W)); r /= 2 * W;
+        const int ho = (int)(r % (2 * H)); const int n = (int)(r / (2 * H));
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + (((size_t)n * H + (ho >> 1)) * W + (wo >> 1)) * C + cu * EPU);
+        *reinterpret_cast<u32x4*>(y + (size_t)i * EPU) = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void sumpool2x_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int Ho, int Wo, int C) {
+    constexpr int EPU = 16 / (int)sizeof(T);
+    const int upp = C / EPU;
+    const long long total = (long long)N * Ho * Wo * upp;
+    const int Hi = 2 * Ho, Wi = 2 * Wo;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+        const int cu = (int)(i % upp); long long r = i / upp;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho); const int n = (int)(r / Ho);
+        float acc[EPU];
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 2; ++dw) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(x + (((size_t)n * Hi + 2 * ho + dh) * Wi + 2 * wo + dw) * C + cu * EPU);
+                const T* ev = reinterpret_cast<const T*>(&v);
+#pragma unroll
+                for (int e = 0; e < EPU; ++e) acc[e] += (float)ev[e];
+            }
+        u32x4 ov; T* o = reinterpret_cast<T*>(&ov);
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) o[e] = (T)acc[e];
+        *reinterpret_cast<u32x4*>(y + (size_t)i * EPU) = ov;
+    }
+}
+
+// y[n][2h][2w] = x[n][h][w], everything else 0; y is [N,Hout,Wout,C]
+template <typename T>
+__global__ __launch_bounds__(NT) void zero_stuff2x_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C,
+                                                          int Hout, int Wout) {
+    constexpr int EPU = 16 / (int)sizeof(T);
+    const int upp = C / EPU;
+    const long long total = (long long)N * Hout * Wout * upp;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+        const int cu = (int)(i % upp); long long r = i / upp;
+        const int wo = (int)(r % Wout); r /= Wout;
+        const int ho = (int)(r % Hout); const int n = (int)(r / Hout);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (!(ho & 1) && !(wo & 1) && (ho >> 1) < H && (wo >> 1) < W)
+            v = *reinterpret_cast<const u32x4*>(x + (((size_t)n * H + (ho >> 1)) * W + (wo >> 1)) * C + cu * EPU);
+        *reinterpret_cast<u32x4*>(y + (size_t)i * EPU) = v;
+    }
+}
+
+int grid_for(long long total) {
+    long long b = (total + NT - 1) / NT;
+    if (b > 8192) b = 8192;
+    return b < 1 ? 1 : (int)b;
+}
+}  // namespace
+
+extern "C" size_t mas_packed_weight_elems(int Cout, int Cin, int ks) {
+    // large enough for either packing mode
+    const size_t a = (size_t)mas_roundup(Cout, 32) * mas_roundup(Cin, 16);
+    const size_t b = (size_t)mas_roundup(Cin, 32) * mas_roundup(Cout, 16);
+    return (size_t)ks * ks * (a > b ? a : b);
+}
+
+extern "C" int mas_pack_conv_weight(const float* w_oihw, void* packed, int Cout, int Cin, int ks, int transpose, int dtype,
+                                    void* stream) {
+    if (!w_oihw || !packed) MAS_FAIL(MAS_EINVAL, "pack_conv_weight: null argument");
+    if (Cout <= 0 || Cin <= 0 || (ks != 1 && ks != 3)) MAS_FAIL(MAS_EINVAL, "pack_conv_weight: bad shape");
+    const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
+    const int rows_pad = mas_roundup(rows, 32), cols_pad = mas_roundup(cols, 16);
+    const long long total = (long long)ks * ks * rows_pad * cols_pad;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MAS_BF16)
+        hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, s, w_oihw, (bf16_t*)packed, Cout, Cin, ks, transpose, rows_pad, cols_pad);
+    else if (dtype == MAS_F32)
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, s, w_oihw, (float*)packed, Cout, Cin, ks, transpose, rows_pad, cols_pad);
+    else MAS_FAIL(MAS_EUNSUPPORTED, "pack_conv_weight: dtype %d", dtype);
+    MAS_CHECK_LAUNCH("pack_conv_weight");
+    return MAS_OK;
+}
+
+#define MAS_DISPATCH_NHWC(NAME, KERN, TOTAL, ...)                                                                   \
+    do {                                                                                                            \
+        const int epu_ = dtype == MAS_BF16 ? 8 : 4;                                                                 \
+        if (C % epu_) MAS_FAIL(MAS_EUNSUPPORTED, NAME ": C=%d must be a multiple of %d", C, epu_);                  \
+        hipStream_t s_ = reinterpret_cast<hipStream_t>(stream);                                                     \
+        const long long total_ = (TOTAL) / epu_;                                                                    \
+        if (dtype == MAS_BF16) hipLaunchKernelGGL(KERN<bf16_t>, dim3(grid_for(total_)), dim3(NT), 0, s_, (const bf16_t*)x, (bf16_t*)y, __VA_ARGS__); \
+        else if (dtype == MAS_F32) hipLaunchKernelGGL(KERN<float>, dim3(grid_for(total_)), dim3(NT), 0, s_, (const float*)x, (float*)y, __VA_ARGS__); \
+        else MAS_FAIL(MAS_EUNSUPPORTED, NAME ": dtype %d", dtype);                                                  \
+        MAS_CHECK_LAUNCH(NAME);                                                                                     \
+        return MAS_OK;                                                                                              \
+    } while (0)
+
+extern "C" int mas_upsample2x(const void* x, void* y, int dtype, int N, int H, int W, int C, void* stream) {
+    if (!x || !y) MAS_FAIL(MAS_EINVAL, "upsample2x: null argument");
+    MAS_DISPATCH_NHWC("upsample2x", upsample2x_kernel, (long long)N * 4 * H * W * C, N, H, W, C);
+}
+extern "C" int mas_sumpool2x(const void* x, void* y, int dtype, int N, int Ho, int Wo, int C, void* stream) {
+    if (!x || !y) MAS_FAIL(MAS_EINVAL, "sumpool2x: null argument");
+    MAS_DISPATCH_NHWC("sumpool2x", sumpool2x_kernel, (long long)N * Ho * Wo * C, N, Ho, Wo, C);
+}
+extern "C" int mas_zero_stuff2x(const void* x, void* y, int dtype, int N, int H, int W, int C, int Hout, int Wout, void* stream) {
+    if (!x || !y) MAS_FAIL(MAS_EINVAL, "zero_stuff2x: null argument");
+    MAS_DISPATCH_NHWC("zero_stuff2x", zero_stuff2x_kernel, (long long)N * Hout * Wout * C, N, H, W, C, Hout, Wout);
+}

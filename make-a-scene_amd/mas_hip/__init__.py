@@ -1,0 +1,78 @@
+"""ctypes binding of libmas_hip.so (the C ABI declared in include/mas_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a kernel call
+fails, a RuntimeError is raised.  PyTorch is used only for device memory, streams and
+torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmas_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_AFFINE, ACT_AFFINE_SILU = 0, 1, 2
+ABI_VERSION = 1
+
+
+class ConvDesc(C.Structure):
+    """Mirror of ``MasConvDesc`` (include/mas_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "ks", "stride", "pad_top", "pad_left",
+        "in_dtype", "out_dtype", "act", "upsample")]
+
+
+_p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_SIGNATURES = {
+    "mas_abi_version": (C.c_int, []),
+    "mas_last_error": (C.c_char_p, []),
+    "mas_packed_weight_elems": (_sz, [_i, _i, _i]),
+    "mas_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "mas_gn_stats_workspace": (_sz, [_i, _i]),
+    "mas_gn_stats": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _sz, _p]),
+    "mas_gn_bwd_workspace": (_sz, [_i, _i]),
+    "mas_gn_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "mas_conv_fwd": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p]),
+    "mas_conv_wgrad": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
+    "mas_vq_workspace": (_sz, [_i, _i]),
+    "mas_vq_argmin_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    "mas_vq_bwd": (_i, [_p, _p, _p, _p, _p, _f, _i, _i, _i, _p, _p, _p]),
+    "mas_upsample2x": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "mas_sumpool2x": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "mas_zero_stuff2x": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Loads libmas_hip.so once; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                        "(hipcc --offload-arch=gfx950); there is no PyTorch/CPU fallback for this path")
+                L = C.CDLL(LIB_PATH)
+                for name, (res, args) in _SIGNATURES.items():
+                    fn = getattr(L, name, None)
+                    if fn is None:
+                        continue          # optional symbol of a later ABI revision; callers check
+                    fn.restype, fn.argtypes = res, args
+                if L.mas_abi_version() != ABI_VERSION:
+                    raise RuntimeError(f"libmas_hip.so ABI {L.mas_abi_version()} != binding {ABI_VERSION}")
+                _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().mas_last_error()
+        raise RuntimeError(f"libmas_hip {what} failed (code {rc}): {msg.decode() if msg else ''}")

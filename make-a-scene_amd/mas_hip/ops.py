@@ -1,0 +1,306 @@
+"""torch.autograd.Function wrappers over the C ABI (include/mas_hip.h).
+
+Activations are torch tensors of LOGICAL shape [N,C,H,W] in ``channels_last`` memory
+format (== the NHWC buffers the kernels expect), dtype bf16 or fp32.  Parameters stay
+ordinary fp32 OIHW ``nn.Parameter``s (state_dict compatible with the reference); the
+bf16 / NHWC-packed copies are a cache keyed on ``Parameter._version``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import weakref
+from typing import Optional
+
+import torch
+
+from . import ACT_AFFINE, ACT_AFFINE_SILU, ACT_NONE, BF16, F32, ConvDesc, check, lib
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_state = {"compute_dtype": torch.bfloat16 if os.environ.get("MAS_COMPUTE_DTYPE", "bf16") == "bf16" else torch.float32}
+
+
+def compute_dtype() -> torch.dtype:
+    return _state["compute_dtype"]
+
+
+def set_compute_dtype(dt: torch.dtype) -> None:
+    """bf16 (default; MFMA bf16, fp32 accumulate) or fp32 (exact-fp32 MFMA; parity mode)."""
+    if dt not in _DT:
+        raise ValueError("compute dtype must be torch.bfloat16 or torch.float32")
+    _state["compute_dtype"] = dt
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: the MI355X path needs a GPU tensor (no CPU fallback); got device {t.device}")
+
+
+def nhwc(x: torch.Tensor, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """[N,C,H,W]-logical tensor in channels_last memory, optionally cast."""
+    if dtype is not None and x.dtype != dtype:
+        return x.to(dtype=dtype, memory_format=torch.channels_last)
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def _empty_nhwc(n, c, h, w, dtype, device):
+    return torch.empty((n, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last)
+
+
+# --------------------------------------------------------------------------- #
+# packed-weight cache
+# --------------------------------------------------------------------------- #
+class _PackCache:
+    """bf16/NHWC-packed copies of conv parameters, valid while ``Parameter._version`` is unchanged
+    (the optimizer's in-place update bumps it).  Only ``nn.Parameter`` objects are cached (held by
+    weak reference); temporaries (e.g. the concatenated q|k|v weight) are packed on every call."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, w: torch.Tensor, transpose: bool, dtype: torch.dtype) -> torch.Tensor:
+        if not isinstance(w, torch.nn.Parameter):
+            return pack_conv_weight(w.detach(), transpose, dtype)
+        key = (id(w), transpose, dtype)
+        ver = (w._version, w.data_ptr())
+        hit = self.store.get(key)
+        if hit is not None and hit[0]() is w and hit[1] == ver:
+            return hit[2]
+        packed = pack_conv_weight(w.detach(), transpose, dtype)
+        self.store[key] = (weakref.ref(w, lambda _r, k=key: self.store.pop(k, None)), ver, packed)
+        return packed
+
+
+_pack_cache = _PackCache()
+
+
+def pack_conv_weight(w: torch.Tensor, transpose: bool, dtype: torch.dtype) -> torch.Tensor:
+    _require_cuda(w, "pack_conv_weight")
+    cout, cin, ks, ks2 = w.shape
+    assert ks == ks2
+    w = w.contiguous().float()
+    n = lib().mas_packed_weight_elems(cout, cin, ks)
+    out = torch.empty(n, dtype=dtype, device=w.device)
+    check(lib().mas_pack_conv_weight(_ptr(w), _ptr(out), cout, cin, ks, int(transpose), _DT[dtype], _stream()), "pack_conv_weight")
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# raw kernel calls
+# --------------------------------------------------------------------------- #
+def gn_stats(x: torch.Tensor, gamma, beta, groups: int, eps: float):
+    """x channels_last [N,C,H,W] -> (mean_rstd [N,G,2], scale_shift [N,C,2]) fp32."""
+    n, c, h, w = x.shape
+    mr = torch.empty((n, groups, 2), dtype=torch.float32, device=x.device)
+    ss = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+    wsb = lib().mas_gn_stats_workspace(n, c)
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
+    check(lib().mas_gn_stats(_ptr(x), _DT[x.dtype], n, h * w, c, groups, float(eps), _ptr(gamma), _ptr(beta), _ptr(mr), _ptr(ss),
+                             _ptr(ws), wsb, _stream()), "gn_stats")
+    return mr, ss
+
+
+def gn_bwd(x, da, dres, groups, act, gamma, mr, ss):
+    n, c, h, w = x.shape
+    dx = torch.empty_like(x, memory_format=torch.channels_last)
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    wsb = lib().mas_gn_bwd_workspace(n, c)
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
+    check(lib().mas_gn_bwd(_ptr(x), _ptr(da), _ptr(dres), _DT[x.dtype], n, h * w, c, groups, act, _ptr(gamma), _ptr(mr), _ptr(ss),
+                           _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), wsb, _stream()), "gn_bwd")
+    return dx, dgamma, dbeta
+
+
+def _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, in_dt, out_dt, act, upsample):
+    return ConvDesc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, _DT[in_dt], _DT[out_dt], act, int(upsample))
+
+
+def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, upsample, out_dtype):
+    y = _empty_nhwc(n, cout, ho, wo, out_dtype, x.device)
+    d = _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, x.dtype, out_dtype, act, upsample)
+    check(lib().mas_conv_fwd(C.byref(d), _ptr(x), _ptr(ss), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), _stream()), "conv_fwd")
+    return y
+
+
+def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, upsample, want_bias):
+    dw = torch.zeros((cout, ks, ks, cin), dtype=torch.float32, device=x.device)
+    db = torch.zeros(cout, dtype=torch.float32, device=x.device) if want_bias else None
+    d = _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, x.dtype, x.dtype, act, upsample)
+    check(lib().mas_conv_wgrad(C.byref(d), _ptr(x), _ptr(ss), _ptr(dy), _ptr(dw), _ptr(db), _stream()), "conv_wgrad")
+    return dw.permute(0, 3, 1, 2).contiguous(), db
+
+
+def upsample2x(x):
+    n, c, h, w = x.shape
+    y = _empty_nhwc(n, c, 2 * h, 2 * w, x.dtype, x.device)
+    check(lib().mas_upsample2x(_ptr(x), _ptr(y), _DT[x.dtype], n, h, w, c, _stream()), "upsample2x")
+    return y
+
+
+def sumpool2x(x):
+    n, c, h2, w2 = x.shape
+    y = _empty_nhwc(n, c, h2 // 2, w2 // 2, x.dtype, x.device)
+    check(lib().mas_sumpool2x(_ptr(x), _ptr(y), _DT[x.dtype], n, h2 // 2, w2 // 2, c, _stream()), "sumpool2x")
+    return y
+
+
+def zero_stuff2x(x, hout, wout):
+    n, c, h, w = x.shape
+    y = _empty_nhwc(n, c, hout, wout, x.dtype, x.device)
+    check(lib().mas_zero_stuff2x(_ptr(x), _ptr(y), _DT[x.dtype], n, h, w, c, hout, wout, _stream()), "zero_stuff2x")
+    return y
+
+
+# --------------------------------------------------------------------------- #
+# fused [GroupNorm (+SiLU)] -> conv (+bias, +residual)
+# --------------------------------------------------------------------------- #
+class _NormActConv(torch.autograd.Function):
+    """y = conv(act(gn(x)), W) + b (+ residual).   act in {none, affine, affine+silu}.
+
+    Forward: gn statistics kernel (if act) -> conv kernel with the normalise/affine/SiLU fused
+    into its loader.  Backward: wgrad kernel (recomputes the activated input in its loader),
+    data gradient = the forward kernel on dy with flipped/transposed weights, then the
+    GroupNorm(+SiLU) backward kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gn_w, gn_b, residual, cfg):
+        _require_cuda(x, "conv")
+        cd = cfg["in_dtype"]
+        x = nhwc(x, cd)
+        n, cin, h, w = x.shape
+        cout, cin_w, ks, _ = weight.shape
+        if cin_w != cin:
+            raise RuntimeError(f"conv: input has {cin} channels, weight expects {cin_w}")
+        stride, pt, pl, pb, pr_, ups = cfg["stride"], cfg["pad_top"], cfg["pad_left"], cfg["pad_bottom"], cfg["pad_right"], cfg["upsample"]
+        hl, wl = (2 * h, 2 * w) if ups else (h, w)
+        ho = (hl + pt + pb - ks) // stride + 1
+        wo = (wl + pl + pr_ - ks) // stride + 1
+        act = cfg["act"]
+        mr = ss = None
+        if act != ACT_NONE:
+            mr, ss = gn_stats(x, gn_w.detach().float(), gn_b.detach().float(), cfg["groups"], cfg["eps"])
+        wp = _pack_cache.get(weight, False, cd)
+        b32 = bias.detach().float() if bias is not None else None
+        res = nhwc(residual, cd) if residual is not None else None
+        y = conv_fwd_raw(x, ss, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, cfg["out_dtype"])
+        ctx.cfg = cfg
+        ctx.dims = (n, h, w, cin, ho, wo, cout, ks)
+        ctx.has_res = residual is not None
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, gn_w, mr, ss)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, gn_w, mr, ss = ctx.saved_tensors
+        cfg = ctx.cfg
+        n, h, w, cin, ho, wo, cout, ks = ctx.dims
+        cd = cfg["in_dtype"]
+        stride, pt, pl, ups, act = cfg["stride"], cfg["pad_top"], cfg["pad_left"], cfg["upsample"], cfg["act"]
+        dy = nhwc(dy, cd)
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        need_gn = act != ACT_NONE and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        dx = dw = db = dgw = dgb = None
+        if need_w or need_b:
+            dw, db = conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, need_b)
+            dw = dw.to(weight.dtype) if need_w else None
+        if need_x or need_gn:
+            wt = _pack_cache.get(weight, True, cd)
+            hl, wl = (2 * h, 2 * w) if ups else (h, w)
+            if stride == 1:
+                d_in, hd, wd = dy, ho, wo
+            else:  # adjoint of the strided read: zero-stuff dy, then a stride-1 conv
+                hd, wd = (ho - 1) * stride + 1, (wo - 1) * stride + 1
+                d_in = zero_stuff2x(dy, hd, wd)
+            da = conv_fwd_raw(d_in, None, wt, None, None, n, hd, wd, cout, hl, wl, cin, ks, 1, ks - 1 - pt, ks - 1 - pl, ACT_NONE, False, cd)
+            if ups:
+                da = sumpool2x(da)
+            if act != ACT_NONE:
+                dx, dgw, dgb = gn_bwd(x, da, None, cfg["groups"], act, gn_w.detach().float(), mr, ss)
+                dgw, dgb = dgw.to(gn_w.dtype), dgb.to(gn_w.dtype)
+            else:
+                dx = da
+        dres = dy if ctx.has_res and ctx.needs_input_grad[5] else None
+        return dx, dw, (db.to(weight.dtype) if db is not None else None), dgw, dgb, dres, None
+
+
+def norm_act_conv(x, weight, bias, gn_w=None, gn_b=None, residual=None, *, stride=1, padding=(1, 1, 1, 1), act=ACT_NONE,
+                  upsample=False, groups=32, eps=1e-6, in_dtype=None, out_dtype=None):
+    """padding = (top, bottom, left, right)."""
+    cd = in_dtype or compute_dtype()
+    cfg = dict(stride=stride, pad_top=padding[0], pad_bottom=padding[1], pad_left=padding[2], pad_right=padding[3], act=act,
+               upsample=bool(upsample), groups=groups, eps=eps, in_dtype=cd, out_dtype=out_dtype or cd)
+    if cfg["in_dtype"] == torch.float32 and cfg["out_dtype"] != torch.float32:
+        raise RuntimeError("conv: fp32 input requires fp32 output")
+    return _NormActConv.apply(x, weight, bias, gn_w, gn_b, residual, cfg)
+
+
+# --------------------------------------------------------------------------- #
+# vector quantiser
+# --------------------------------------------------------------------------- #
+class _VQ(torch.autograd.Function):
+    """(z_q straight-through, loss, idx) = VQ(z, codebook)  -- Codebook.forward's arithmetic
+    (reference models/modules.py:501-517)."""
+
+    @staticmethod
+    def forward(ctx, z, codebook, beta):
+        _require_cuda(z, "vq")
+        z = nhwc(z, torch.float32)
+        n, d, h, w = z.shape
+        k = codebook.shape[0]
+        m = n * h * w
+        cb = codebook.detach().contiguous().float()
+        idx = torch.empty(m, dtype=torch.int64, device=z.device)
+        zq = torch.empty((n, d, h, w), dtype=torch.float32, device=z.device, memory_format=torch.channels_last)
+        sq = torch.empty(1, dtype=torch.float32, device=z.device)
+        wsb = lib().mas_vq_workspace(m, k)
+        ws = torch.empty(wsb // 4 + 1, dtype=torch.float32, device=z.device)
+        check(lib().mas_vq_argmin_fwd(_ptr(z), _ptr(cb), m, k, d, _ptr(idx), _ptr(zq), _ptr(sq), _ptr(ws), wsb, _stream()), "vq_argmin_fwd")
+        loss = (sq[0] * ((1.0 + beta) / (m * d)))
+        ctx.beta = beta
+        ctx.save_for_backward(z, cb, idx)
+        ctx.mark_non_differentiable(idx)
+        return zq, loss, idx
+
+    @staticmethod
+    def backward(ctx, g_zq, g_loss, _g_idx):
+        z, cb, idx = ctx.saved_tensors
+        n, d, h, w = z.shape
+        m, k = n * h * w, cb.shape[0]
+        need_z, need_cb = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_zq = nhwc(g_zq, torch.float32) if g_zq is not None else None
+        g_loss = g_loss.reshape(1).float().contiguous() if g_loss is not None else None
+        dz = torch.empty_like(z, memory_format=torch.channels_last) if need_z else None
+        dcb = torch.zeros_like(cb) if need_cb else None
+        check(lib().mas_vq_bwd(_ptr(z), _ptr(cb), _ptr(idx), _ptr(g_zq), _ptr(g_loss), float(ctx.beta), m, k, d, _ptr(dz), _ptr(dcb),
+                               _stream()), "vq_bwd")
+        return dz, dcb, None
+
+
+def vq_lookup(z, codebook, beta):
+    return _VQ.apply(z, codebook, beta)
+
+
+# --------------------------------------------------------------------------- #
+# single-head spatial attention core (AttnBlock, reference models/modules.py:174-187)
+# --------------------------------------------------------------------------- #
+def spatial_attention(qkv: torch.Tensor, c: int) -> torch.Tensor:
+    """qkv: [N,3C,H,W] channels_last (q|k|v stacked on channels).  softmax over keys of
+    q.k^T * C^-1/2, then . v.  0.2 % of the model's FLOPs: two plain batched
+    GEMMs on views of the NHWC buffer (library GEMM via torch.bmm) + a row softmax."""
+    n, c3, h, w = qkv.shape
+    t = qkv.permute(0, 2, 3, 1).reshape(n, h * w, c3)          # a view of the NHWC buffer
+    q, k, v = t[..., :c], t[..., c:2 * c], t[..., 2 * c:]
+    s = torch.bmm(q, k.transpose(1, 2)) * (int(c) ** (-0.5))
+    p = torch.softmax(s, dim=2)
+    o = torch.bmm(p, v)
+    return o.reshape(n, h, w, c).permute(0, 3, 1, 2)            # [N,C,H,W] logical, NHWC memory
