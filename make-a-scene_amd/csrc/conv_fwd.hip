@@ -291,6 +291,7 @@ int launch_ks(const ConvParams& p, int ks, int stride, hipStream_t s) {
 
 extern "C" int mas_conv_fwd(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed,
                             const float* bias, const void* residual, void* y, void* stream) {
+    MAS_ENTER();
     if (!d || !x || !w_packed || !y) MAS_FAIL(MAS_EINVAL, "conv_fwd: null argument");
     if (d->act != MAS_ACT_NONE && !scale_shift) MAS_FAIL(MAS_EINVAL, "conv_fwd: act prologue needs scale_shift");
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0)

@@ -262,6 +262,7 @@ int launch_t(const WgradParams& p, int ks, int stride, hipStream_t s) {
 
 extern "C" int mas_conv_wgrad(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy,
                               float* dw, float* dbias, void* stream) {
+    MAS_ENTER();
     if (!d || !x || !dy || !dw) MAS_FAIL(MAS_EINVAL, "conv_wgrad: null argument");
     if (d->act != MAS_ACT_NONE && !scale_shift) MAS_FAIL(MAS_EINVAL, "conv_wgrad: act prologue needs scale_shift");
     if (d->upsample && d->stride != 1) MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad: upsample fold needs stride 1");

@@ -5,7 +5,8 @@
 //
 // All kernels are HBM-bound streaming passes: 16-byte NHWC loads, a thread owns a fixed
 // 16-byte channel unit and walks pixels, so per-channel partial sums live in registers.
-// Reductions are two-stage and deterministic (per-block partials -> finalize kernel).
+// Reductions are two-stage with a fixed summation order (per-thread registers -> LDS slots ->
+// per-block partials -> fp64 finalize kernel): bitwise reproducible run to run, no global atomics.
 #include "mas_common.h"
 
 namespace {
@@ -41,10 +42,19 @@ __global__ __launch_bounds__(NT) void gn_stats_partial(const T* __restrict__ x, 
 #pragma unroll
             for (int e = 0; e < EPU; ++e) { const float v = (float)rv[e]; s[e] += v; q[e] += v * v; }
         }
+        // fixed-order (deterministic) reduction over the NT/upp pixel-row groups
+        float* slots = red + 2 * C;                 // [NT/upp][C][2]
+        const int rg = tid / upp;
 #pragma unroll
         for (int e = 0; e < EPU; ++e) {
-            atomicAdd(&red[(cu * EPU + e) * 2 + 0], s[e]);
-            atomicAdd(&red[(cu * EPU + e) * 2 + 1], q[e]);
+            slots[((size_t)rg * C + cu * EPU + e) * 2 + 0] = s[e];
+            slots[((size_t)rg * C + cu * EPU + e) * 2 + 1] = q[e];
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * C; i += NT) {
+            float a = 0.0f;
+            for (int k = 0; k < rstep; ++k) a += slots[(size_t)k * 2 * C + i];
+            red[i] = a;
         }
     } else {
         const long long total = (long long)(r1 - r0) * upp;
@@ -163,7 +173,21 @@ __global__ __launch_bounds__(NT) void gn_bwd_partial(const T* __restrict__ x, co
             s1[e] += du; s2[e] += du * (xe - mu[e]) * rs[e];
         }
     }
-    if (cu_prev >= 0) {
+    if (fixed) {
+        float* slots = red + 2 * C;                 // [NT/upp][C][2]
+        const int cu = tid % upp, rg = tid / upp, rstep = NT / upp;
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) {
+            slots[((size_t)rg * C + cu * EPU + e) * 2 + 0] = s1[e];
+            slots[((size_t)rg * C + cu * EPU + e) * 2 + 1] = s2[e];
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * C; i += NT) {
+            float a = 0.0f;
+            for (int k = 0; k < rstep; ++k) a += slots[(size_t)k * 2 * C + i];
+            red[i] = a;
+        }
+    } else if (cu_prev >= 0) {
 #pragma unroll
         for (int e = 0; e < EPU; ++e) {
             atomicAdd(&red[(cu_prev * EPU + e) * 2 + 0], s1[e]); atomicAdd(&red[(cu_prev * EPU + e) * 2 + 1], s2[e]);
@@ -276,6 +300,7 @@ extern "C" size_t mas_gn_stats_workspace(int N, int C) { return (size_t)N * MAX_
 extern "C" int mas_gn_stats(const void* x, int dtype, int N, int HW, int C, int G, float eps, const float* gamma,
                             const float* beta, float* mean_rstd, float* scale_shift, void* workspace, size_t ws_bytes,
                             void* stream) {
+    MAS_ENTER();
     if (!x || !mean_rstd || !workspace) MAS_FAIL(MAS_EINVAL, "gn_stats: null argument");
     if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G) MAS_FAIL(MAS_EINVAL, "gn_stats: bad shape N=%d HW=%d C=%d G=%d", N, HW, C, G);
     const int epu = dtype == MAS_BF16 ? 8 : 4;
@@ -284,7 +309,7 @@ extern "C" int mas_gn_stats(const void* x, int dtype, int N, int HW, int C, int 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nsplit = pick_split(N, HW);
     float* partial = reinterpret_cast<float*>(workspace);
-    const size_t lds1 = (size_t)2 * C * sizeof(float);
+    const size_t lds1 = ((size_t)2 * C + (size_t)NT * epu * 2) * sizeof(float);
     if (dtype == MAS_BF16)
         hipLaunchKernelGGL(gn_stats_partial<bf16_t>, dim3(N * nsplit), dim3(NT), lds1, s, (const bf16_t*)x, HW, C, nsplit, partial);
     else
@@ -304,6 +329,7 @@ extern "C" size_t mas_gn_bwd_workspace(int N, int C) {
 extern "C" int mas_gn_bwd(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G, int act,
                           const float* gamma, const float* mean_rstd, const float* scale_shift, void* dx, float* dgamma,
                           float* dbeta, void* workspace, size_t ws_bytes, void* stream) {
+    MAS_ENTER();
     if (!x || !da || !dx || !mean_rstd || !scale_shift || !workspace) MAS_FAIL(MAS_EINVAL, "gn_bwd: null argument");
     if (act != MAS_ACT_AFFINE && act != MAS_ACT_AFFINE_SILU) MAS_FAIL(MAS_EINVAL, "gn_bwd: bad act %d", act);
     if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G) MAS_FAIL(MAS_EINVAL, "gn_bwd: bad shape");
@@ -315,7 +341,7 @@ extern "C" int mas_gn_bwd(const void* x, const void* da, const void* dres, int d
     float* partial = reinterpret_cast<float*>(workspace);
     float* coef = partial + (size_t)N * MAX_SPLIT * C * 2;
     float* nsum = coef + (size_t)N * C * 4;
-    const size_t lds1 = (size_t)2 * C * sizeof(float);
+    const size_t lds1 = ((size_t)2 * C + (size_t)NT * epu * 2) * sizeof(float);
     if (dtype == MAS_BF16)
         hipLaunchKernelGGL(gn_bwd_partial<bf16_t>, dim3(N * nsplit), dim3(NT), lds1, s, (const bf16_t*)x, (const bf16_t*)da, HW, C, G, nsplit, act, mean_rstd, scale_shift, partial);
     else

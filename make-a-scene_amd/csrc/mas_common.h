@@ -21,6 +21,9 @@ void mas_set_error(const char* fmt, ...);
 #define MAS_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
     if (e_ != hipSuccess) MAS_FAIL(MAS_ELAUNCH, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)
 
+// a stale error left in this thread by another library must not be blamed on our launch
+#define MAS_ENTER() do { (void)hipGetLastError(); } while (0)
+
 static inline int mas_roundup(int a, int b) { return (a + b - 1) / b * b; }
 static inline int mas_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t mas_esize(int dtype) { return dtype == MAS_BF16 ? 2 : 4; }

@@ -12,7 +12,8 @@ void mas_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mas_last_error(void) { return g_err; }
-extern "C" int mas_abi_version(void) { return MAS_ABI_VERSION; }
+extern "C" int mas_abi_version(void) {
+    MAS_ENTER(); return MAS_ABI_VERSION; }
 
 namespace {
 constexpr int NT = 256;
@@ -116,6 +117,7 @@ extern "C" size_t mas_packed_weight_elems(int Cout, int Cin, int ks) {
 
 extern "C" int mas_pack_conv_weight(const float* w_oihw, void* packed, int Cout, int Cin, int ks, int transpose, int dtype,
                                     void* stream) {
+    MAS_ENTER();
     if (!w_oihw || !packed) MAS_FAIL(MAS_EINVAL, "pack_conv_weight: null argument");
     if (Cout <= 0 || Cin <= 0 || (ks != 1 && ks != 3)) MAS_FAIL(MAS_EINVAL, "pack_conv_weight: bad shape");
     const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
@@ -145,14 +147,17 @@ extern "C" int mas_pack_conv_weight(const float* w_oihw, void* packed, int Cout,
     } while (0)
 
 extern "C" int mas_upsample2x(const void* x, void* y, int dtype, int N, int H, int W, int C, void* stream) {
+    MAS_ENTER();
     if (!x || !y) MAS_FAIL(MAS_EINVAL, "upsample2x: null argument");
     MAS_DISPATCH_NHWC("upsample2x", upsample2x_kernel, (long long)N * 4 * H * W * C, N, H, W, C);
 }
 extern "C" int mas_sumpool2x(const void* x, void* y, int dtype, int N, int Ho, int Wo, int C, void* stream) {
+    MAS_ENTER();
     if (!x || !y) MAS_FAIL(MAS_EINVAL, "sumpool2x: null argument");
     MAS_DISPATCH_NHWC("sumpool2x", sumpool2x_kernel, (long long)N * Ho * Wo * C, N, Ho, Wo, C);
 }
 extern "C" int mas_zero_stuff2x(const void* x, void* y, int dtype, int N, int H, int W, int C, int Hout, int Wout, void* stream) {
+    MAS_ENTER();
     if (!x || !y) MAS_FAIL(MAS_EINVAL, "zero_stuff2x: null argument");
     MAS_DISPATCH_NHWC("zero_stuff2x", zero_stuff2x_kernel, (long long)N * Hout * Wout * C, N, H, W, C, Hout, Wout);
 }

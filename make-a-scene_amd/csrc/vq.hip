@@ -171,6 +171,7 @@ extern "C" size_t mas_vq_workspace(int M, int K) {
 
 extern "C" int mas_vq_argmin_fwd(const float* z, const float* codebook, int M, int K, int D, int64_t* idx, float* zq,
                                  float* sqerr, void* workspace, size_t ws_bytes, void* stream) {
+    MAS_ENTER();
     if (!z || !codebook || !idx || !zq || !sqerr || !workspace) MAS_FAIL(MAS_EINVAL, "vq_argmin_fwd: null argument");
     if (M <= 0 || K <= 0) MAS_FAIL(MAS_EINVAL, "vq_argmin_fwd: bad shape M=%d K=%d", M, K);
     if (ws_bytes < mas_vq_workspace(M, K)) MAS_FAIL(MAS_EWORKSPACE, "vq_argmin_fwd: workspace too small");
@@ -202,6 +203,7 @@ extern "C" int mas_vq_argmin_fwd(const float* z, const float* codebook, int M, i
 
 extern "C" int mas_vq_bwd(const float* z, const float* codebook, const int64_t* idx, const float* g_zq, const float* g_loss,
                           float beta, int M, int K, int D, float* dz, float* dcodebook, void* stream) {
+    MAS_ENTER();
     if (!z || !codebook || !idx) MAS_FAIL(MAS_EINVAL, "vq_bwd: null argument");
     (void)K;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

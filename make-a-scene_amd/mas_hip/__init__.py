@@ -10,6 +10,8 @@ import ctypes as C
 import os
 import threading
 
+import torch  # noqa: F401  -- must come first: PyTorch-ROCm bundles its own libamdhip64; loading ours before it leaves torch without GPUs
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmas_hip.so")
 
