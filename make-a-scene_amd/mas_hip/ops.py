@@ -31,6 +31,16 @@ def set_compute_dtype(dt: torch.dtype) -> None:
     _state["compute_dtype"] = dt
 
 
+_launch_hook = None
+
+
+def set_launch_hook(fn) -> None:
+    """fn(kind, shape, launch) wraps every conv launch (bench.py times the dominant kernel with HIP events
+    recorded on the launch stream); None disables it."""
+    global _launch_hook
+    _launch_hook = fn
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -127,7 +137,14 @@ def _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, in_dt, out_dt, act, up
 def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, upsample, out_dtype):
     y = _empty_nhwc(n, cout, ho, wo, out_dtype, x.device)
     d = _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, x.dtype, out_dtype, act, upsample)
-    check(lib().mas_conv_fwd(C.byref(d), _ptr(x), _ptr(ss), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), _stream()), "conv_fwd")
+
+    def launch():
+        check(lib().mas_conv_fwd(C.byref(d), _ptr(x), _ptr(ss), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), _stream()), "conv_fwd")
+
+    if _launch_hook is not None:
+        _launch_hook("conv_fwd", (n, h, w, cin, ho, wo, cout, ks, stride), launch)
+    else:
+        launch()
     return y
 
 
@@ -135,7 +152,14 @@ def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ac
     dw = torch.zeros((cout, ks, ks, cin), dtype=torch.float32, device=x.device)
     db = torch.zeros(cout, dtype=torch.float32, device=x.device) if want_bias else None
     d = _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, x.dtype, x.dtype, act, upsample)
-    check(lib().mas_conv_wgrad(C.byref(d), _ptr(x), _ptr(ss), _ptr(dy), _ptr(dw), _ptr(db), _stream()), "conv_wgrad")
+
+    def launch():
+        check(lib().mas_conv_wgrad(C.byref(d), _ptr(x), _ptr(ss), _ptr(dy), _ptr(dw), _ptr(db), _stream()), "conv_wgrad")
+
+    if _launch_hook is not None:
+        _launch_hook("conv_wgrad", (n, h, w, cin, ho, wo, cout, ks, stride), launch)
+    else:
+        launch()
     return dw.permute(0, 3, 1, 2).contiguous(), db
 
 
