@@ -56,7 +56,7 @@ const char* mas_last_error(void);
 /* ---- weight packing (host-visible layout contract) -------------------------------
  * Packs an OIHW fp32 parameter (nn.Conv2d.weight, e.g. modules.py:93-104) into the
  * kernel layout [ks*ks][Cout_pad][Cin_pad] (dtype `dtype`, zero padded; Cout_pad =
- * roundup(Cout,32), Cin_pad = roundup(Cin,16)).
+ * roundup(Cout,128), Cin_pad = roundup(Cin,64), so the kernels load tiles without bounds checks).
  *   transpose=0 : forward operand            Wp[t][o][i] = W[o][i][kh][kw], t = kh*ks+kw
  *   transpose=1 : data-gradient operand      Wp[t][i][o] = W[o][i][ks-1-kh][ks-1-kw]
  *                 (conv of dY with the flipped, in/out-swapped filter; then "Cout"=Cin)

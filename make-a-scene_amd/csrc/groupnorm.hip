@@ -257,8 +257,19 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply(const T* __restrict__ x, cons
     const int upp = C / EPU;
     const int n = blockIdx.y;
     const size_t base = (size_t)n * HW * C;
-    for (long long u = (long long)blockIdx.x * NT + threadIdx.x; u < units_per_n; u += (long long)gridDim.x * NT) {
-        const int cu = (int)(u % upp);
+    // NT % upp == 0 (checked by the host): the channel unit of a thread is loop invariant, so the five
+    // per-channel coefficients live in registers and the loop is a pure 3-stream pass
+    const long long u0 = (long long)blockIdx.x * NT + threadIdx.x;
+    const int cu = (int)(u0 % upp);
+    float sc[EPU], sh[EPU], k0[EPU], k1[EPU], k2[EPU];
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) {
+        const int c = cu * EPU + e;
+        sc[e] = ss[((size_t)n * C + c) * 2]; sh[e] = ss[((size_t)n * C + c) * 2 + 1];
+        const float* k = coef + ((size_t)n * C + c) * 4;
+        k0[e] = k[0]; k1[e] = k[1]; k2[e] = k[2];
+    }
+    for (long long u = u0; u < units_per_n; u += (long long)gridDim.x * NT) {
         const size_t off = base + (size_t)u * EPU;
         u32x4 rx = *reinterpret_cast<const u32x4*>(x + off);
         u32x4 rd = *reinterpret_cast<const u32x4*>(da + off);
@@ -271,12 +282,10 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply(const T* __restrict__ x, cons
         T* o = reinterpret_cast<T*>(&ov);
 #pragma unroll
         for (int e = 0; e < EPU; ++e) {
-            const int c = cu * EPU + e;
             const float xe = (float)xv[e];
             float du = (float)dv[e];
-            if (act == MAS_ACT_AFFINE_SILU) du *= dsilu_f(xe * ss[((size_t)n * C + c) * 2] + ss[((size_t)n * C + c) * 2 + 1]);
-            const float* k = coef + ((size_t)n * C + c) * 4;
-            float v = k[0] * du + k[1] * xe + k[2];
+            if (act == MAS_ACT_AFFINE_SILU) du *= dsilu_f(xe * sc[e] + sh[e]);
+            float v = k0[e] * du + k1[e] * xe + k2[e];
             if (dres) v += (float)rv[e];
             o[e] = (T)v;
         }
@@ -334,7 +343,7 @@ extern "C" int mas_gn_bwd(const void* x, const void* da, const void* dres, int d
     if (act != MAS_ACT_AFFINE && act != MAS_ACT_AFFINE_SILU) MAS_FAIL(MAS_EINVAL, "gn_bwd: bad act %d", act);
     if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G) MAS_FAIL(MAS_EINVAL, "gn_bwd: bad shape");
     const int epu = dtype == MAS_BF16 ? 8 : 4;
-    if (C % epu) MAS_FAIL(MAS_EUNSUPPORTED, "gn_bwd: C=%d must be a multiple of %d", C, epu);
+    if (C % epu || NT % (C / epu)) MAS_FAIL(MAS_EUNSUPPORTED, "gn_bwd: C=%d: C/%d must divide %d", C, epu, NT);
     if (ws_bytes < mas_gn_bwd_workspace(N, C)) MAS_FAIL(MAS_EWORKSPACE, "gn_bwd: workspace too small");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nsplit = pick_split(N, HW);

@@ -18,22 +18,28 @@ extern "C" int mas_abi_version(void) {
 namespace {
 constexpr int NT = 256;
 
-// packed[t][o][i] (padded) from OIHW fp32; see mas_hip.h for the two modes
+// OIHW fp32 -> the LDS image the conv kernels copy linearly: [tap][chunk][row][128 B], where a 128-byte row
+// holds CK = 128/sizeof(T) consecutive K elements as eight 16-byte slots and slot position sp stores logical
+// slot sp ^ ((row>>1)&7) (the bank-conflict swizzle of conv_fwd.hip).  See mas_hip.h for the two modes.
 template <typename T>
 __global__ __launch_bounds__(NT) void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin,
-                                                         int ks, int transpose, int rows_pad, int cols_pad) {
-    const long long total = (long long)ks * ks * rows_pad * cols_pad;
+                                                         int ks, int transpose, int rows_pad, int n_chunks) {
+    constexpr int EPU = 16 / (int)sizeof(T), CK = 128 / (int)sizeof(T);
+    const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
+    const long long total = (long long)ks * ks * n_chunks * rows_pad * CK;
     for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
-        const int col = (int)(i % cols_pad);
-        const int row = (int)((i / cols_pad) % rows_pad);
-        const int t = (int)(i / ((long long)cols_pad * rows_pad));
+        const int pos = (int)(i % CK);
+        const int row = (int)((i / CK) % rows_pad);
+        const int ch = (int)((i / ((long long)CK * rows_pad)) % n_chunks);
+        const int t = (int)(i / ((long long)CK * rows_pad * n_chunks));
+        const int sp = pos / EPU, e = pos % EPU;
+        const int col = ch * CK + ((sp ^ ((row >> 1) & 7)) * EPU) + e;
         const int kh = t / ks, kw = t % ks;
         float v = 0.0f;
-        if (!transpose) {
-            if (row < Cout && col < Cin) v = w[(((size_t)row * Cin + col) * ks + kh) * ks + kw];
-        } else {
+        if (row < rows && col < cols) {
+            if (!transpose) v = w[(((size_t)row * Cin + col) * ks + kh) * ks + kw];
             // rows = input channels (the dgrad's "Cout"), cols = output channels (its "Cin"), taps flipped
-            if (row < Cin && col < Cout) v = w[(((size_t)col * Cin + row) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)];
+            else v = w[(((size_t)col * Cin + row) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)];
         }
         out[i] = (T)v;
     }
@@ -109,9 +115,9 @@ int grid_for(long long total) {
 }  // namespace
 
 extern "C" size_t mas_packed_weight_elems(int Cout, int Cin, int ks) {
-    // large enough for either packing mode
-    const size_t a = (size_t)mas_roundup(Cout, 32) * mas_roundup(Cin, 16);
-    const size_t b = (size_t)mas_roundup(Cin, 32) * mas_roundup(Cout, 16);
+    // large enough for either packing mode and either dtype (fp32 chunks are 32 channels, bf16 64)
+    const size_t a = (size_t)mas_roundup(Cout, 128) * mas_roundup(Cin, 64);
+    const size_t b = (size_t)mas_roundup(Cin, 128) * mas_roundup(Cout, 64);
     return (size_t)ks * ks * (a > b ? a : b);
 }
 
@@ -121,13 +127,15 @@ extern "C" int mas_pack_conv_weight(const float* w_oihw, void* packed, int Cout,
     if (!w_oihw || !packed) MAS_FAIL(MAS_EINVAL, "pack_conv_weight: null argument");
     if (Cout <= 0 || Cin <= 0 || (ks != 1 && ks != 3)) MAS_FAIL(MAS_EINVAL, "pack_conv_weight: bad shape");
     const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
-    const int rows_pad = mas_roundup(rows, 32), cols_pad = mas_roundup(cols, 16);
-    const long long total = (long long)ks * ks * rows_pad * cols_pad;
+    const int rows_pad = mas_roundup(rows, 128);
+    const int ck = dtype == MAS_BF16 ? 64 : 32;
+    const int n_chunks = mas_cdiv(cols, ck);
+    const long long total = (long long)ks * ks * n_chunks * rows_pad * ck;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MAS_BF16)
-        hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, s, w_oihw, (bf16_t*)packed, Cout, Cin, ks, transpose, rows_pad, cols_pad);
+        hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, s, w_oihw, (bf16_t*)packed, Cout, Cin, ks, transpose, rows_pad, n_chunks);
     else if (dtype == MAS_F32)
-        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, s, w_oihw, (float*)packed, Cout, Cin, ks, transpose, rows_pad, cols_pad);
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, s, w_oihw, (float*)packed, Cout, Cin, ks, transpose, rows_pad, n_chunks);
     else MAS_FAIL(MAS_EUNSUPPORTED, "pack_conv_weight: dtype %d", dtype);
     MAS_CHECK_LAUNCH("pack_conv_weight");
     return MAS_OK;

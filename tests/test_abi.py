@@ -40,7 +40,7 @@ def test_argument_validation_without_gpu():
     with pytest.raises(RuntimeError):
         mas_hip.check(-1, "probe")
     assert L.mas_packed_weight_elems(128, 128, 3) == 9 * 128 * 128
-    assert L.mas_packed_weight_elems(3, 128, 3) == 9 * 32 * 128     # Cout padded to 32
+    assert L.mas_packed_weight_elems(3, 128, 3) == 9 * 128 * 128    # Cout padded to the 128-row tile
 
 
 def test_surface_matches_reference_contract():

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of single libmas_hip kernels on synthetic shapes (HIP-event timed).
+    python tools/kbench.py conv_fwd|dgrad|wgrad|gn_stats|gn_bwd|vq [--n 32 --c 128 --hw 256 --act 2 --iters 20]
+Prints achieved TFLOP/s / GB/s per launch; run under rocprofv3 for counters."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "make-a-scene_amd"))
+import torch  # noqa: E402
+from mas_hip import ops  # noqa: E402
+
+
+def timeit(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("kind")
+    ap.add_argument("--n", type=int, default=32)
+    ap.add_argument("--c", type=int, default=128)
+    ap.add_argument("--co", type=int, default=0)
+    ap.add_argument("--hw", type=int, default=256)
+    ap.add_argument("--ks", type=int, default=3)
+    ap.add_argument("--act", type=int, default=0)
+    ap.add_argument("--res", type=int, default=0)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16")
+    a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dev = torch.device("cuda:0")
+    co = a.co or a.c
+    n, c, h = a.n, a.c, a.hw
+    x = torch.randn(n, c, h, h, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
+    esz = x.element_size()
+    if a.kind in ("conv_fwd", "dgrad", "wgrad"):
+        w = (torch.randn(co, c, a.ks, a.ks, device=dev) / (c * a.ks * a.ks) ** 0.5)
+        b = torch.randn(co, device=dev) * 0.1
+        ss = torch.randn(n, c, 2, device=dev) if a.act else None
+        p = a.ks // 2
+        flops = 2.0 * a.ks * a.ks * c * co * n * h * h
+        if a.kind == "wgrad":
+            dy = torch.randn(n, co, h, h, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
+            fn = lambda: ops.conv_wgrad_raw(x, ss, dy, n, h, h, c, h, h, co, a.ks, 1, p, p, a.act, False, True)
+            byt = (x.numel() + dy.numel()) * esz
+        else:
+            wp = ops.pack_conv_weight(w, a.kind == "dgrad", dt)
+            res = torch.randn(n, co, h, h, device=dev).to(dt).contiguous(memory_format=torch.channels_last) if a.res else None
+            fn = lambda: ops.conv_fwd_raw(x, ss, wp, b, res, n, h, h, c, h, h, co, a.ks, 1, p, p, a.act, False, dt)
+            byt = (x.numel() + n * co * h * h * (2 if a.res else 1)) * esz
+        ms = timeit(fn, a.iters)
+        print(f"{a.kind} n={n} c={c}->{co} hw={h} ks={a.ks} act={a.act} {a.dtype}: {ms:.4f} ms  {flops/ms/1e9:.1f} TFLOP/s  {byt/ms/1e6:.1f} GB/s(alg)")
+    elif a.kind == "gn_stats":
+        g, bta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+        ms = timeit(lambda: ops.gn_stats(x, g, bta, 32, 1e-6), a.iters)
+        print(f"gn_stats n={n} c={c} hw={h}: {ms:.4f} ms  {x.numel()*esz/ms/1e6:.1f} GB/s")
+    elif a.kind == "gn_bwd":
+        g, bta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+        mr, ss = ops.gn_stats(x, g, bta, 32, 1e-6)
+        da = torch.randn_like(x)
+        ms = timeit(lambda: ops.gn_bwd(x, da, None, 32, a.act or 2, g, mr, ss), a.iters)
+        print(f"gn_bwd n={n} c={c} hw={h}: {ms:.4f} ms  {5*x.numel()*esz/ms/1e6:.1f} GB/s (2 reads x2 + 1 write)")
+    elif a.kind == "vq":
+        z = torch.randn(n, 256, 16, 16, device=dev).contiguous(memory_format=torch.channels_last)
+        cb = torch.randn(8192, 256, device=dev)
+        ms = timeit(lambda: ops.vq_lookup(z, cb, 0.25), a.iters)
+        print(f"vq M={n*256} K=8192 D=256: {ms:.4f} ms  {2.0*n*256*8192*256/ms/1e9:.1f} TFLOP/s(fp32)")
+
+
+if __name__ == "__main__":
+    main()
