@@ -21,10 +21,12 @@
 // hipcc's counted s_waitcnt vmcnt(N) keeps the patch prefetch (issued one slot per tap, after that
 // tap's weight loads) in flight across two taps and barriers.
 #include "mas_common.h"
+#include <stdlib.h>
 
 namespace {
 
 struct ConvParams {
+    unsigned long long* dbg;
     const void* x; const float* ss; const void* w; const float* bias; const void* res; void* y;
     int N, H, W, Cin, Ho, Wo, Cout;
     int Hl, Wl;            // logical input size (2H,2W when upsample)
@@ -33,10 +35,12 @@ struct ConvParams {
     int tiles_h, tiles_w, n_ct;
 };
 
-constexpr int TH = 8, TW = 16, NT = 256;
+constexpr int TW = 16;
+// BIG = 512 threads / 16x16-pixel tile (weights fetched once per 256 pixels); otherwise 256 threads / 8x16
 
-template <typename T, int KS, int STRIDE>
+template <typename T, int KS, int STRIDE, bool BIG>
 struct Geo {
+    static constexpr int TH = BIG ? 16 : 8, NT = BIG ? 512 : 256;
     static constexpr int EPU = 16 / (int)sizeof(T);          // elements per 16-byte slot
     static constexpr int CK = 128 / (int)sizeof(T);          // channels per chunk (one 128-byte pixel row)
     static constexpr int PH = (TH - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
@@ -63,19 +67,25 @@ __device__ __forceinline__ f32x8 ld_frag<float>(const unsigned char* row, int h,
     return r;
 }
 
-template <typename T, typename TO, int KS, int STRIDE, int BC, int WC>
-__global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvParams p) {
-    using G = Geo<T, KS, STRIDE>;
+template <typename T, typename TO, int KS, int STRIDE, int BC, int WC, bool VEC, bool BIG>
+__global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_fwd_kernel(ConvParams p) {
+    using G = Geo<T, KS, STRIDE, BIG>;
+    constexpr int TH = G::TH, NT = G::NT, NWAVE = NT / 64;
     using V8 = typename Vec8<T>::type;
     constexpr int EPU = G::EPU, CK = G::CK, PW = G::PW, PWL = G::PWL, NPU = G::NPU, PB = G::PB;
-    constexpr int WP = 4 / WC;                 // waves along pixels
+    constexpr int WP = NWAVE / WC;             // waves along pixels
     constexpr int MI = BC / WC / 32;           // 32-cout tiles per wave
     constexpr int NI = (TH * TW) / WP / 32;    // 32-pixel tiles per wave
     constexpr int WT_BYTES = BC * 128;         // one weight tile (BC rows x 128 B)
     constexpr int W_PER_T = BC * 8 / NT;       // 16-byte slots of a weight tile per thread
     constexpr int NTAP = KS * KS;
-    constexpr bool PREFETCH = (NPU <= PB);     // whole chunk fits one register batch -> issue early / write late
-    constexpr int PPT = (NPU + NTAP - 1) / NTAP;   // prefetch slots issued per tap
+    // weight stage = TPS consecutive taps staged (and barrier-synchronised) together: the measured cost of a
+    // work-group barrier is ~650 cycles of wave skew, so the big tile amortises it over 48 MFMAs instead of 16
+    constexpr int TPS = (BIG && KS == 3) ? 3 : 1;
+    constexpr int NSTAGE = NTAP / TPS;
+    constexpr bool PREFETCH = VEC && (NPU <= PB);   // whole chunk fits one register batch -> issue early / write late
+    constexpr int PPT = (NPU + NSTAGE - 1) / NSTAGE;   // prefetch slots issued per stage
+    constexpr bool vec_in = VEC;               // Cin % EPU == 0: 16-byte aligned channel slots
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* patch = smem;
@@ -84,64 +94,69 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_c = wave % WC, wave_p = wave / WC;
     const int g = lane >> 5, l31 = lane & 31;
+    const int sl = tid & 7;                    // this thread's 16-byte channel slot inside a 128-byte pixel row
 
-    int bid = blockIdx.x;
-    const int ct = bid % p.n_ct; bid /= p.n_ct;
-    const int tw_i = bid % p.tiles_w; bid /= p.tiles_w;
-    const int th_i = bid % p.tiles_h; const int n = bid / p.tiles_h;
-    const int c0 = ct * BC, h0 = th_i * TH, w0 = tw_i * TW;
-
-    const T* __restrict__ X = reinterpret_cast<const T*>(p.x) + (size_t)n * p.H * p.W * p.Cin;
+    const T* __restrict__ Xall = reinterpret_cast<const T*>(p.x);
     const unsigned char* __restrict__ Wimg = reinterpret_cast<const unsigned char*>(p.w);
+    const size_t img_elems = (size_t)p.H * p.W * p.Cin;
 
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    // ---- per-thread staging plan: slot s = tid&7 of patch pixel q = (tid>>3) + 32*i ---------------
-    const int sl = tid & 7;
-    int srcoff[NPU];                          // element offset of the pixel in this image, -1 = zero
-    int dstoff[NPU];                          // byte offset in the LDS patch (swizzled), -1 = skip
+    // ---- tile bookkeeping: the work-group is PERSISTENT and walks tiles t = blockIdx.x + k*gridDim.x -----
+    // (so the patch loads of tile k+1 and the output stores of tile k-1 overlap the MFMAs of tile k instead of
+    //  every work-group on the chip loading, computing and storing in lock-step)
+    const int total_tiles = p.N * p.tiles_h * p.tiles_w * p.n_ct;
+    struct Tile { int n, h0, w0, c0; };
+    auto decode = [&](int t) {
+        Tile tc;
+        const int ct = t % p.n_ct; t /= p.n_ct;
+        const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+        const int th_i = t % p.tiles_h; tc.n = t / p.tiles_h;
+        tc.c0 = ct * BC; tc.h0 = th_i * TH; tc.w0 = tw_i * TW;
+        return tc;
+    };
+    // staging plan: thread owns slot `sl` of patch pixels q = (tid>>3) + 32*i
+    int dstoff[NPU];                           // byte offset in the LDS patch (swizzled), -1 = skip (tile independent)
 #pragma unroll
     for (int i = 0; i < NPU; ++i) {
         const int q = (tid >> 3) + i * (NT / 8);
         const int pr = q / PWL, pc = q - pr * PWL;
-        int ih = h0 * STRIDE + pr - p.pad_top, iw = w0 * STRIDE + pc - p.pad_left;
         const bool live = (q < G::PH * PWL) && (pc < PW);
-        const bool inb = live && (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl);
-        if (p.upsample) { ih >>= 1; iw >>= 1; }
-        srcoff[i] = inb ? (ih * p.W + iw) * p.Cin : -1;
         dstoff[i] = live ? q * 128 + ((sl ^ ((pc >> 1) & 7)) << 4) : -1;
     }
-    const bool vec_in = (p.Cin % EPU) == 0;
+    auto make_plan = [&](const Tile& tc, int (&so)[NPU]) {   // element offset of each pixel in its image, -1 = zero padding
+#pragma unroll
+        for (int i = 0; i < NPU; ++i) {
+            const int q = (tid >> 3) + i * (NT / 8);
+            const int pr = q / PWL, pc = q - pr * PWL;
+            int ih = tc.h0 * STRIDE + pr - p.pad_top, iw = tc.w0 * STRIDE + pc - p.pad_left;
+            const bool inb = (dstoff[i] >= 0) && (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl);
+            if (p.upsample) { ih >>= 1; iw >>= 1; }
+            so[i] = inb ? (ih * p.W + iw) * p.Cin : -1;
+        }
+    };
 
     u32x4 preg[PB];
-    auto p_issue_one = [&](int ci0, int b0, int k) {   // global -> register k of the batch starting at slot b0
+    auto p_issue_one = [&](const T* X, const int (&so)[NPU], int ci0, int b0, int k) {   // global -> register k
         const int cb = ci0 + sl * EPU;
         const int i = b0 + k;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (vec_in) {
+        if constexpr (vec_in) {
             // unconditional load (clamped address; commit discards it for padding) keeps the per-wave
             // VMEM instruction count static, which hipcc's counted waits rely on
-            const int so = (i < NPU && srcoff[i] >= 0 && cb < p.Cin) ? srcoff[i] + cb : 0;
-            v = *reinterpret_cast<const u32x4*>(X + so);
-        } else if (i < NPU && srcoff[i] >= 0 && cb < p.Cin) {
-            const T* src = X + srcoff[i] + cb;
+            const int o = (i < NPU && so[i < NPU ? i : 0] >= 0 && cb < p.Cin) ? so[i < NPU ? i : 0] + cb : 0;
+            v = *reinterpret_cast<const u32x4*>(X + o);
+        } else if (i < NPU && so[i < NPU ? i : 0] >= 0 && cb < p.Cin) {
+            const T* src = X + so[i] + cb;
             T* tv = reinterpret_cast<T*>(&v);
 #pragma unroll
             for (int e = 0; e < EPU; ++e) if (cb + e < p.Cin) tv[e] = src[e];
         }
         preg[k] = v;
     };
-    auto p_issue = [&](int ci0, int b0) {
+    auto p_issue = [&](const T* X, const int (&so)[NPU], int ci0, int b0) {
 #pragma unroll
-        for (int k = 0; k < PB; ++k) p_issue_one(ci0, b0, k);
+        for (int k = 0; k < PB; ++k) p_issue_one(X, so, ci0, b0, k);
     };
-    auto p_commit = [&](int ci0, int b0) {    // registers -> (prologue) -> LDS
+    auto p_commit = [&](const int (&so)[NPU], int n, int ci0, int b0) {    // registers -> (prologue) -> LDS
         const int cb = ci0 + sl * EPU;
         float sc[EPU], sh[EPU];
         if (p.act != MAS_ACT_NONE) {
@@ -155,10 +170,10 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvParams p) {
 #pragma unroll
         for (int k = 0; k < PB; ++k) {
             const int i = b0 + k;
-            if (i >= NPU || dstoff[i] < 0) continue;
+            if (i >= NPU || dstoff[i < NPU ? i : 0] < 0) continue;
             u32x4 v = preg[k];
-            if (srcoff[i] < 0 || cb >= p.Cin) v = u32x4{0u, 0u, 0u, 0u};   // zero padding / channels past Cin
-            if (p.act != MAS_ACT_NONE && srcoff[i] >= 0) {     // padding stays exactly zero
+            if (so[i] < 0 || cb >= p.Cin) v = u32x4{0u, 0u, 0u, 0u};   // zero padding / channels past Cin
+            if (p.act != MAS_ACT_NONE && so[i] >= 0) {          // padding stays exactly zero
                 T* tv = reinterpret_cast<T*>(&v);
 #pragma unroll
                 for (int e = 0; e < EPU; ++e) {
@@ -170,17 +185,20 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvParams p) {
             *reinterpret_cast<u32x4*>(patch + dstoff[i]) = v;
         }
     };
-    // weight tile (tap, chunk): a linear 16-byte-per-thread copy of its pre-swizzled image
-    u32x4 wreg[W_PER_T];
-    auto w_issue = [&](int tap, int ch) {
-        const unsigned char* src = Wimg + ((size_t)(tap * p.n_chunks + ch) * p.Cout_pad + c0) * 128 + tid * 16;
+    // weight tile (tap, chunk, cout tile): a linear 16-byte-per-thread copy of its pre-swizzled image
+    u32x4 wreg[TPS * W_PER_T];
+    auto w_issue = [&](int stage, int ch, int c0) {
 #pragma unroll
-        for (int k = 0; k < W_PER_T; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(src + k * NT * 16);
+        for (int tt = 0; tt < TPS; ++tt) {
+            const unsigned char* src = Wimg + ((size_t)((stage * TPS + tt) * p.n_chunks + ch) * p.Cout_pad + c0) * 128 + tid * 16;
+#pragma unroll
+            for (int k = 0; k < W_PER_T; ++k) wreg[tt * W_PER_T + k] = *reinterpret_cast<const u32x4*>(src + k * NT * 16);
+        }
     };
     auto w_commit = [&](int buf) {
-        unsigned char* dst = wbuf + buf * WT_BYTES + tid * 16;
+        unsigned char* dst = wbuf + buf * (TPS * WT_BYTES) + tid * 16;
 #pragma unroll
-        for (int k = 0; k < W_PER_T; ++k) *reinterpret_cast<u32x4*>(dst + k * NT * 16) = wreg[k];
+        for (int k = 0; k < TPS * W_PER_T; ++k) *reinterpret_cast<u32x4*>(dst + k * NT * 16) = wreg[k];
     };
 
     // ---- per-lane fragment addressing ------------------------------------------------------------
@@ -195,50 +213,175 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) arow[i] = (wave_c * MI + i) * 32 + l31;
 
-    w_issue(0, 0);
-    if (PREFETCH) p_issue(0, 0);
+#ifdef MAS_TIMELINE
+    int tl_iter = 0;
+#define TS(id) do { if (lane == 0 && blockIdx.x == 100 && tl_iter < 2 && p.dbg) p.dbg[(tl_iter * NWAVE + wave) * 64 + (id)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TS(id) do {} while (0)
+#endif
+    int tile = blockIdx.x;                     // grid <= total_tiles
+    Tile cur = decode(tile);
+    int so_cur[NPU], so_nxt[NPU];
+    make_plan(cur, so_cur);
+#pragma unroll
+    for (int i = 0; i < NPU; ++i) so_nxt[i] = so_cur[i];
+    const T* Xcur = Xall + (size_t)cur.n * img_elems;
+    w_issue(0, 0, cur.c0);
+    if (PREFETCH) p_issue(Xcur, so_cur, 0, 0);
     int wsel = 0;
-    for (int ch = 0; ch < p.n_chunks; ++ch) {
-        const int ci0 = ch * CK;
-        if (ch > 0) __syncthreads();           // every wave is done reading the previous chunk's patch
-        if (PREFETCH) p_commit(ci0, 0);
-        else for (int b0 = 0; b0 < NPU; b0 += PB) { p_issue(ci0, b0); p_commit(ci0, b0); }
-        const bool more = ch + 1 < p.n_chunks;
-#pragma unroll
-        for (int tap = 0; tap < NTAP; ++tap) {
-            w_commit(wsel);
-            __syncthreads();                   // weight tile `tap` (and, at tap 0, the patch) visible
-            {
-                int ntap = tap + 1, nch = ch;
-                if (ntap == NTAP) { ntap = 0; nch = ch + 1; }
-                if (nch < p.n_chunks) w_issue(ntap, nch);
-            }
-            if (PREFETCH && more) {            // next chunk's patch: PPT slots per tap, newer than this tap's weight loads
-#pragma unroll
-                for (int k = tap * PPT; k < (tap + 1) * PPT && k < NPU; ++k) p_issue_one(ci0 + CK, 0, k);
-            }
-            const int kh = tap / KS, kw = tap - kh * KS;
-            const int hb = ((bcol + kw) >> 1) & 7;
-            const unsigned char* wb = wbuf + wsel * WT_BYTES;
-#pragma unroll
-            for (int kk = 0; kk < CK / 16; ++kk) {   // channels past Cin are zero in both operands
-                V8 bf[NI], af[MI];
-#pragma unroll
-                for (int j = 0; j < NI; ++j) bf[j] = ld_frag<T>(patch + (bq[j] + kh * PWL + kw) * 128, hb, kk, g);
-#pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = ld_frag<T>(wb + arow[i] * 128, (arow[i] >> 1) & 7, kk, g);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) mma16(acc[i][j], af[i], bf[j]);
-            }
-            wsel ^= 1;
-        }
-    }
+    bool first = true;
+    for (;;) {
+        const int next_tile = tile + (int)gridDim.x;
+        const bool has_next = next_tile < total_tiles;
+        const Tile nxt = has_next ? decode(next_tile) : cur;
+        const T* Xnxt = Xall + (size_t)nxt.n * img_elems;
 
+        f32x16 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+        TS(0);
+        for (int ch = 0; ch < p.n_chunks; ++ch) {
+            const int ci0 = ch * CK;
+            if (!first) __syncthreads();       // every wave is done reading the previous patch
+            first = false;
+            if (ch == 0) TS(1);
+            if (PREFETCH) p_commit(so_cur, cur.n, ci0, 0);
+            else for (int b0 = 0; b0 < NPU; b0 += PB) { p_issue(Xcur, so_cur, ci0, b0); p_commit(so_cur, cur.n, ci0, b0); }
+            // what the taps of this chunk prefetch: the next chunk of this tile, or chunk 0 of the next tile
+            const bool more = ch + 1 < p.n_chunks;
+            if (!more && has_next) make_plan(nxt, so_nxt);
+            const T* Xpf = more ? Xcur : Xnxt;
+            const int pci = more ? ci0 + CK : 0;
+#pragma unroll
+            for (int stage = 0; stage < NSTAGE; ++stage) {
+                TS(2 + ch * 28 + stage * 3);
+                w_commit(wsel);
+                TS(3 + ch * 28 + stage * 3);
+                __syncthreads();               // weight stage (and, at stage 0, the patch) visible
+                TS(4 + ch * 28 + stage * 3);
+                {
+                    int nst = stage + 1, nch = ch, nc0 = cur.c0;
+                    if (nst == NSTAGE) { nst = 0; nch = ch + 1; }
+                    if (nch >= p.n_chunks) { nch = 0; nc0 = nxt.c0; }   // next tile (or, at the very end, a harmless re-read)
+#ifndef MAS_ABL_NOWLOAD
+                    w_issue(nst, nch, nc0);
+#endif
+                }
+                if (PREFETCH) {                // PPT slots per stage, issued after (= newer than) this stage's weight loads,
+                                               // unconditionally: a branch-free VMEM stream lets hipcc keep them in flight
+#pragma unroll
+                    for (int k = stage * PPT; k < (stage + 1) * PPT && k < NPU; ++k) {
+                        if (more) p_issue_one(Xpf, so_cur, pci, 0, k);
+                        else p_issue_one(Xpf, so_nxt, pci, 0, k);
+                    }
+                }
+                if constexpr (sizeof(T) == 2) __builtin_amdgcn_sched_group_barrier(0x020, TPS * W_PER_T + (PREFETCH ? PPT : 0), 0);   // VMEM reads first
+#pragma unroll
+              for (int tt = 0; tt < TPS; ++tt) {
+                const int tap = stage * TPS + tt;
+                const int kh = tap / KS, kw = tap - kh * KS;
+                const int hb = ((bcol + kw) >> 1) & 7;
+                const unsigned char* wb = wbuf + wsel * (TPS * WT_BYTES) + tt * WT_BYTES;
+                // software-pipelined fragment loads: the ds_reads of k-step kk+1 are issued BEFORE the MFMAs of kk
+                constexpr int NKK = CK / 16;   // channels past Cin are zero in both operands
+                V8 bfr[2][NI], afr[2][MI];
+                auto ld_k = [&](int kk, int b) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) bfr[b][j] = ld_frag<T>(patch + (bq[j] + kh * PWL + kw) * 128, hb, kk, g);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) afr[b][i] = ld_frag<T>(wb + arow[i] * 128, (arow[i] >> 1) & 7, kk, g);
+                };
+                ld_k(0, 0);
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    if (kk + 1 < NKK) ld_k(kk + 1, (kk + 1) & 1);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) mma16(acc[i][j], afr[kk & 1][i], bfr[kk & 1][j]);
+                }
+                if constexpr (sizeof(T) == 2) {    // pin the interleave (masks: 0x100 DS read, 0x008 MFMA)
+                    __builtin_amdgcn_sched_group_barrier(0x100, NI + MI, 0);
+#pragma unroll
+                    for (int kk = 0; kk + 1 < NKK; ++kk) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, NI + MI, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
+                }
+              }
+                wsel ^= 1;
+            }
+        }
+
+        TS(60);
+        {
+            const int n = cur.n, h0 = cur.h0, w0 = cur.w0, c0 = cur.c0;
+            [&]() {
     // ---- epilogue: bias + residual, NHWC store ------------------------------------------------------
     TO* __restrict__ Y = reinterpret_cast<TO*>(p.y);
     const T* __restrict__ R = reinterpret_cast<const T*>(p.res);
+    if constexpr (sizeof(TO) == 2 && sizeof(T) == 2) {
+        if ((p.Cout & 7) == 0) {
+            // bf16 fast path.  A lane owns 4 consecutive couts per accumulator quad and its partner lane (+32) the
+            // next 4 of the same pixel: one v_permlane32_swap per dword turns two 8-byte pieces into one 16-byte
+            // store per lane (half the store instructions; the tail is store-issue bound).
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int pix = (wave_p * NI + j) * 32 + l31;
+                const int ho = h0 + (pix >> 4), wo = w0 + (pix & 15);
+                const bool pix_ok = (ho < p.Ho) && (wo < p.Wo);
+                const size_t obase = ((size_t)(n * p.Ho + ho) * p.Wo + wo) * p.Cout;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                    for (int qp = 0; qp < 2; ++qp) {
+                        unsigned pk[2][2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int q = qp * 2 + h;
+                            const int co = c0 + (wave_c * MI + i) * 32 + 8 * q + 4 * g;
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+                            if (pix_ok && co < p.Cout) {
+                                if (p.bias) {
+                                    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] += b[e];
+                                }
+                                if (R) {
+                                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + obase + co);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                                }
+                            }
+                            bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                            const u32x2 od = *reinterpret_cast<const u32x2*>(&o);
+                            pk[h][0] = od[0]; pk[h][1] = od[1];
+                        }
+                        // after the swaps: lanes 0-31 hold couts 8q..8q+7 of quad q=2qp, lanes 32-63 those of quad 2qp+1
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            const auto r = __builtin_amdgcn_permlane32_swap(pk[0][d], pk[1][d], false, false);
+                            pk[0][d] = r[0]; pk[1][d] = r[1];
+                        }
+                        const int co8 = c0 + (wave_c * MI + i) * 32 + 8 * (qp * 2 + g);
+                        if (pix_ok && co8 < p.Cout) {
+                            const u32x4 o = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+                            *reinterpret_cast<u32x4*>(Y + obase + co8) = o;
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
     const bool vec_out = (p.Cout & 3) == 0;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -292,13 +435,28 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvParams p) {
             }
         }
     }
+            }();
+        }
+        TS(61);
+#ifdef MAS_TIMELINE
+        ++tl_iter;
+#endif
+        if (!has_next) break;
+        tile = next_tile; cur = nxt; Xcur = Xnxt;
+#pragma unroll
+        for (int i = 0; i < NPU; ++i) so_cur[i] = so_nxt[i];
+    }
 }
 
-template <typename T, typename TO, int KS, int STRIDE, int BC, int WC>
-int launch(const ConvParams& p, hipStream_t s) {
-    using G = Geo<T, KS, STRIDE>;
-    const size_t lds = (size_t)G::PATCH_BYTES + 2 * BC * 128;
-    auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, BC, WC>;
+template <typename T, typename TO, int KS, int STRIDE, int BC, int WC, bool VEC, bool BIG>
+int launch_v(const ConvParams& p0, hipStream_t s) {
+    using G = Geo<T, KS, STRIDE, BIG>;
+    constexpr int NT = G::NT;
+    ConvParams p = p0;
+    p.tiles_h = mas_cdiv(p.Ho, G::TH); p.tiles_w = mas_cdiv(p.Wo, TW);
+    constexpr int TPS = (BIG && KS == 3) ? 3 : 1;
+    const size_t lds = (size_t)G::PATCH_BYTES + 2 * TPS * BC * 128;
+    auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, BC, WC, VEC, BIG>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -307,11 +465,26 @@ int launch(const ConvParams& p, hipStream_t s) {
     }
     ConvParams q = p;
     q.n_ct = mas_cdiv(p.Cout, BC);
-    const long long blocks = (long long)p.N * p.tiles_h * p.tiles_w * q.n_ct;
-    if (blocks <= 0 || blocks > 0x7fffffffLL) MAS_FAIL(MAS_EINVAL, "conv_fwd: bad grid %lld", blocks);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, s, q);
+    const long long tiles = (long long)p.N * p.tiles_h * p.tiles_w * q.n_ct;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) MAS_FAIL(MAS_EINVAL, "conv_fwd: bad tile count %lld", tiles);
+    const long long resident = (BIG ? 1LL : 2LL) * mas_num_cus();   // work-groups per CU allowed by the LDS / VGPR budget
+    const unsigned blocks = (unsigned)(tiles < resident ? tiles : resident);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, s, q);
     MAS_CHECK_LAUNCH("conv_fwd");
     return MAS_OK;
+}
+
+template <typename T, typename TO, int KS, int STRIDE, int BC, int WC>
+int launch(const ConvParams& p, hipStream_t s) {
+    if (p.Cin % (16 / (int)sizeof(T)) == 0) {
+        if constexpr (KS == 3 && STRIDE == 1 && BC == 128 && sizeof(T) == 2) {
+            // 16x16 tiles when they still fill the chip at one (8-wave) work-group per CU
+            const long long big_tiles = (long long)p.N * mas_cdiv(p.Ho, 16) * mas_cdiv(p.Wo, TW) * mas_cdiv(p.Cout, BC);
+            if (big_tiles >= 2LL * mas_num_cus() && !getenv("MAS_CONV_SMALL_TILE")) return launch_v<T, TO, KS, STRIDE, BC, WC, true, true>(p, s);
+        }
+        return launch_v<T, TO, KS, STRIDE, BC, WC, true, false>(p, s);
+    }
+    return launch_v<T, TO, KS, STRIDE, BC, WC, false, false>(p, s);
 }
 
 template <typename T, typename TO, int KS, int STRIDE>
@@ -341,13 +514,15 @@ extern "C" int mas_conv_fwd(const MasConvDesc* d, const void* x, const float* sc
     if (d->upsample && d->stride != 1) MAS_FAIL(MAS_EUNSUPPORTED, "conv_fwd: upsample fold needs stride 1");
     if ((long long)d->H * d->W * d->Cin > 0x7fffffffLL) MAS_FAIL(MAS_EUNSUPPORTED, "conv_fwd: one image exceeds 2^31 elements");
     ConvParams p;
+    p.dbg = nullptr;
+    if (const char* e = getenv("MAS_DBG_PTR")) p.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
     p.x = x; p.ss = scale_shift; p.w = w_packed; p.bias = bias; p.res = residual; p.y = y;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
     p.Hl = d->upsample ? 2 * d->H : d->H; p.Wl = d->upsample ? 2 * d->W : d->W;
     p.pad_top = d->pad_top; p.pad_left = d->pad_left; p.act = d->act; p.upsample = d->upsample;
     const int ck = d->in_dtype == MAS_BF16 ? 64 : 32;
     p.n_chunks = mas_cdiv(d->Cin, ck); p.Cout_pad = mas_roundup(d->Cout, 128);
-    p.tiles_h = mas_cdiv(d->Ho, TH); p.tiles_w = mas_cdiv(d->Wo, TW); p.n_ct = 1;
+    p.tiles_h = p.tiles_w = 0; p.n_ct = 1;   // set per tile geometry at launch
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d->in_dtype == MAS_BF16 && d->out_dtype == MAS_BF16) return launch_ks<bf16_t, bf16_t>(p, d->ks, d->stride, s);
     if (d->in_dtype == MAS_BF16 && d->out_dtype == MAS_F32) return launch_ks<bf16_t, float>(p, d->ks, d->stride, s);

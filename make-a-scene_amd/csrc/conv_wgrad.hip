@@ -21,7 +21,12 @@ struct WgradParams {
     int tiles_h, tiles_w, n_pt, n_co_t, n_ci_t, nsplit;
 };
 
-constexpr int NTW = 512, TWW = 16, BCO = 128, BCI = 64;
+#ifndef MAS_WGRAD_BCI
+#define MAS_WGRAD_BCI 64
+#endif
+// work-group = 128 co x BCI ci x all taps; 4 waves per 32 ci, so BCI = 32 -> 256 threads and two independent
+// work-groups per CU (one stages while the other runs MFMAs), BCI = 64 -> 512 threads, one per CU
+constexpr int BCI = MAS_WGRAD_BCI, NTW = 64 * 4 * (BCI / 32), TWW = 16, BCO = 128;
 
 template <typename T, int KS, int STRIDE, int THW>
 struct WGeo {
@@ -59,7 +64,7 @@ __device__ __forceinline__ f32x8 shifted8(const float* p, int shift) {
 }
 
 template <typename T, int KS, int STRIDE, int THW>
-__global__ __launch_bounds__(NTW) void conv_wgrad_kernel(WgradParams p) {
+__global__ __launch_bounds__(NTW, 2) void conv_wgrad_kernel(WgradParams p) {
     using G = WGeo<T, KS, STRIDE, THW>;
     using V8 = typename Vec8<T>::type;
     constexpr int EPU = G::EPU, DS = G::DS, CS = G::CS, PW = G::PW, PH = G::PH, PWA = G::PWA;

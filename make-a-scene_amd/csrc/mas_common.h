@@ -24,6 +24,7 @@ void mas_set_error(const char* fmt, ...);
 // a stale error left in this thread by another library must not be blamed on our launch
 #define MAS_ENTER() do { (void)hipGetLastError(); } while (0)
 
+int mas_num_cus();   // compute units of the current device (cached)
 static inline int mas_roundup(int a, int b) { return (a + b - 1) / b * b; }
 static inline int mas_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t mas_esize(int dtype) { return dtype == MAS_BF16 ? 2 : 4; }

@@ -11,6 +11,16 @@ void mas_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int mas_num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;   // MI355X
+    }
+    return cus;
+}
+
 extern "C" const char* mas_last_error(void) { return g_err; }
 extern "C" int mas_abi_version(void) {
     MAS_ENTER(); return MAS_ABI_VERSION; }

@@ -13,7 +13,7 @@ import threading
 import torch  # noqa: F401  -- must come first: PyTorch-ROCm bundles its own libamdhip64; loading ours before it leaves torch without GPUs
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmas_hip.so")
+LIB_PATH = os.environ.get("MAS_HIP_LIB") or os.path.join(_HERE, "libmas_hip.so")   # env override: A/B kernel experiments
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_AFFINE, ACT_AFFINE_SILU = 0, 1, 2
