@@ -1,0 +1,114 @@
+"""N>1 path on CPU: 2 gloo ranks, each running the oracle's fwd+bwd on its own half of the batch with the
+SyncBatchNorm exchange (reference models/vqvae.py:16; all-gather of per-rank sum / sum-of-squares / count)
+and DDP's gradient averaging (reference train.py:32), must reproduce the single-process full-batch result.
+This is the scheme bench.py uses for --gpus N (DistributedDataParallel + nn.SyncBatchNorm over RCCL)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TINY = dict(z_channels=32, in_channels=3, out_channels=3, channels=[32, 32, 64], num_res_blocks=1, resolution=16,
+            attn_resolutions=[8], dropout=0.0)
+
+
+class _SyncBNStats(torch.autograd.Function):
+    """global batch statistics from per-rank sums (what SyncBatchNorm's all_gather computes), differentiable"""
+
+    @staticmethod
+    def forward(ctx, x):
+        c = x.shape[1]
+        local = torch.cat([x.sum((0, 2, 3)), (x * x).sum((0, 2, 3)), x.new_tensor([x.numel() / c])])
+        g = [torch.zeros_like(local) for _ in range(dist.get_world_size())]
+        dist.all_gather(g, local)
+        tot = torch.stack(g).sum(0)
+        cnt = tot[-1]
+        mean = tot[:c] / cnt
+        var = tot[c:2 * c] / cnt - mean * mean
+        ctx.save_for_backward(x, mean)
+        ctx.cnt = float(cnt)
+        return mean, var
+
+    @staticmethod
+    def backward(ctx, gm, gv):
+        x, mean = ctx.saved_tensors
+        gm, gv = gm.clone(), gv.clone()
+        dist.all_reduce(gm); dist.all_reduce(gv)            # every rank's loss depends on the shared statistics
+        n = ctx.cnt
+        return (gm / n)[None, :, None, None] + gv[None, :, None, None] * 2.0 * (x - mean[None, :, None, None]) / n
+
+
+def _forward(sd, x, distributed):
+    sys.path.insert(0, ROOT)
+    from oracle import vq_oracle as O
+    import torch.nn.functional as F
+    h = O.run_plan(sd, "encoder", O.encoder_plan(TINY["channels"], TINY["attn_resolutions"], TINY["resolution"], 1), x)
+    h = O.conv(sd, "quant_conv.0", h)
+    if distributed:
+        mean, var = _SyncBNStats.apply(h)
+    else:
+        mean, var = h.mean((0, 2, 3)), h.var((0, 2, 3), unbiased=False)
+    z = (h - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + 1e-5)
+    z = z * sd["quant_conv.1.weight"][None, :, None, None] + sd["quant_conv.1.bias"][None, :, None, None]
+    z_q, q_loss, idx = O.codebook_forward(sd["quantize.embedding.weight"], z)
+    d = O.conv(sd, "post_quant_conv", z_q)
+    dec = O.run_plan(sd, "decoder", O.decoder_plan(TINY["channels"], TINY["attn_resolutions"], TINY["resolution"], 1), d)
+    return dec, q_loss, idx
+
+
+def _make(seed=0):
+    sys.path.insert(0, ROOT)
+    from oracle import vq_oracle as O
+    sd = O.synth_state_dict(TINY, 32, 32, seed=seed)
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    return sd, O.synth_image_batch(4, 3, 16, seed=seed)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    sd, x = _make()
+    xs = x[rank * 2:(rank + 1) * 2]                                   # this rank's shard: independent images, no data-path collective
+    dec, q_loss, idx = _forward(sd, xs, True)
+    ((xs - dec).abs().mean() + q_loss).backward()
+    grads = {}
+    for k, v in sd.items():
+        if v.grad is not None:
+            g = v.grad.clone()
+            dist.all_reduce(g)                                        # DDP: sum then divide by world size
+            grads[k] = (g / world).numpy()
+    if rank == 0:
+        np.savez(out, idx=idx.numpy(), **grads)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_equals_full_batch(tmp_path):
+    if not dist.is_gloo_available():
+        pytest.skip("gloo unavailable")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "dp.npz")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    sd, x = _make()
+    dec, q_loss, idx = _forward(sd, x, False)
+    # per-rank losses are means over the shard: the average of shard losses == the full-batch loss
+    ((x - dec).abs().mean() + q_loss).backward()
+    assert np.array_equal(got["idx"], idx.numpy()[: len(got["idx"])])
+    checked = 0
+    for k, v in sd.items():
+        if v.grad is not None and k in got.files:
+            ref = v.grad.numpy()
+            assert np.abs(got[k] - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-6, k   # conv biases in front of a GroupNorm have analytically zero gradient
+            checked += 1
+    assert checked > 40
