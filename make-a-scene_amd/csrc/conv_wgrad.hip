@@ -11,10 +11,13 @@
 // One work-group (8 waves) owns a 128(co) x 64(ci) x all-taps accumulator block in registers and
 // walks a strided subset of the pixel tiles (split-K); partial sums are committed with fp32 atomics.
 #include "mas_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
 struct WgradParams {
+    unsigned long long* dbg;
     const void* x; const float* ss; const void* dy; float* dw; float* dbias;
     int N, H, W, Cin, Ho, Wo, Cout;
     int Hl, Wl, pad_top, pad_left, act, upsample;
@@ -22,11 +25,18 @@ struct WgradParams {
 };
 
 #ifndef MAS_WGRAD_BCI
-#define MAS_WGRAD_BCI 64
+#define MAS_WGRAD_BCI 32
 #endif
 // work-group = 128 co x BCI ci x all taps; 4 waves per 32 ci, so BCI = 32 -> 256 threads and two independent
 // work-groups per CU (one stages while the other runs MFMAs), BCI = 64 -> 512 threads, one per CU
-constexpr int BCI = MAS_WGRAD_BCI, NTW = 64 * 4 * (BCI / 32), TWW = 16, BCO = 128;
+constexpr int BCI = MAS_WGRAD_BCI, TWW = 16, BCO = 128;
+// 3x3: each 32x32 (co x ci) accumulator tile is shared by SPLIT = 2 waves that split the 9 taps 5 / 4, so a wave holds
+// 80 accumulator VGPRs instead of 144 (which left no registers to batch the staging loads and forced spills) and the
+// work-group is 16 waves = 4 per SIMD.  1x1: one wave per tile, 8 waves.
+#ifndef MAS_WGRAD_SPLIT
+#define MAS_WGRAD_SPLIT 2
+#endif
+template <int KS> struct WSplit { static constexpr int SPLIT = KS == 3 ? MAS_WGRAD_SPLIT : 1, NTW = 64 * 4 * (BCI / 32) * SPLIT; };
 
 template <typename T, int KS, int STRIDE, int THW>
 struct WGeo {
@@ -63,9 +73,31 @@ __device__ __forceinline__ f32x8 shifted8(const float* p, int shift) {
     return r;
 }
 
+// Rotates the EPU elements packed in a 16-byte register vector: out[e] = in[(e + r) % EPU] (select network on
+// packed data, no dynamic register indexing).  Used so that at transposed-store step e lane `cu` writes channel
+// (e + cu) % EPU: channel rows of one 16-byte unit are a multiple of 32 LDS banks apart, so without the rotation
+// all channel units of a wave-instruction hit ONE bank (measured: ~27 cycles per ds_write_b16).
+template <typename T> __device__ __forceinline__ u32x4 rot_elems(u32x4 v, int r);
+template <> __device__ __forceinline__ u32x4 rot_elems<bf16_t>(u32x4 v, int r) {
+    if (r & 1) {
+        const u32x4 t = {__builtin_amdgcn_alignbit(v[1], v[0], 16), __builtin_amdgcn_alignbit(v[2], v[1], 16),
+                         __builtin_amdgcn_alignbit(v[3], v[2], 16), __builtin_amdgcn_alignbit(v[0], v[3], 16)};
+        v = t;
+    }
+    if (r & 2) { const u32x4 t = {v[1], v[2], v[3], v[0]}; v = t; }
+    if (r & 4) { const u32x4 t = {v[2], v[3], v[0], v[1]}; v = t; }
+    return v;
+}
+template <> __device__ __forceinline__ u32x4 rot_elems<float>(u32x4 v, int r) {
+    if (r & 1) { const u32x4 t = {v[1], v[2], v[3], v[0]}; v = t; }
+    if (r & 2) { const u32x4 t = {v[2], v[3], v[0], v[1]}; v = t; }
+    return v;
+}
+
 template <typename T, int KS, int STRIDE, int THW>
-__global__ __launch_bounds__(NTW, 2) void conv_wgrad_kernel(WgradParams p) {
+__global__ __launch_bounds__(WSplit<KS>::NTW) void conv_wgrad_kernel(WgradParams p) {
     using G = WGeo<T, KS, STRIDE, THW>;
+    constexpr int NTW = WSplit<KS>::NTW, SPLIT = WSplit<KS>::SPLIT;
     using V8 = typename Vec8<T>::type;
     constexpr int EPU = G::EPU, DS = G::DS, CS = G::CS, PW = G::PW, PH = G::PH, PWA = G::PWA;
     constexpr int NTAP = KS * KS;
@@ -80,7 +112,10 @@ __global__ __launch_bounds__(NTW, 2) void conv_wgrad_kernel(WgradParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 5, l31 = lane & 31;
-    const int wco = (wave & 3) * 32, wci = (wave >> 2) * 32;
+    constexpr int NTILE = 4 * (BCI / 32);        // 32x32 accumulator tiles per work-group
+    const int wtile = wave % NTILE, half = wave / NTILE;
+    const int wco = (wtile & 3) * 32, wci = (wtile >> 2) * 32;
+    constexpr int TPH = (KS * KS + SPLIT - 1) / SPLIT;   // taps per wave
 
     int bid = blockIdx.x;
     const int split = bid % p.nsplit; bid /= p.nsplit;
@@ -90,9 +125,9 @@ __global__ __launch_bounds__(NTW, 2) void conv_wgrad_kernel(WgradParams p) {
     const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
     const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
 
-    f32x16 acc[NTAP];
+    f32x16 acc[TPH];                             // taps [half*TPH, min(NTAP, (half+1)*TPH))
 #pragma unroll
-    for (int t = 0; t < NTAP; ++t)
+    for (int t = 0; t < TPH; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
@@ -106,12 +141,99 @@ __global__ __launch_bounds__(NTW, 2) void conv_wgrad_kernel(WgradParams p) {
     const T* a_frag_base = dyt + (wco + l31) * DS + g * 8;
     const T* b_frag_base = at + (wci + l31) * CS + g * 8;
 
+#ifdef MAS_TIMELINE
+    int tl_iter = 0;
+#define WTS(id) do { if (lane == 0 && blockIdx.x == 100 && tl_iter < 4 && p.dbg) p.dbg[(tl_iter * 8 + wave) * 8 + (id)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WTS(id) do {} while (0)
+#endif
     for (int pt = split; pt < p.n_pt; pt += p.nsplit) {
         int t = pt;
         const int tw_i = t % p.tiles_w; t /= p.tiles_w;
         const int th_i = t % p.tiles_h; const int n = t / p.tiles_h;
         const int h0 = th_i * THW, w0 = tw_i * TWW;
+        WTS(0);
         __syncthreads();                         // previous tile's fragment reads are done
+        WTS(1);
+        if (vec_dy && vec_x) {
+            // ---- fast staging: ALL global loads of the tile are issued first (one HBM round trip instead of
+            // one per unit: the measured staging time was 13K of a 21K-cycle tile, all exposed load latency),
+            // then converted / transposed into LDS
+            constexpr int DY_PER_T = (DY_UNITS + NTW - 1) / NTW, A_PER_T = (A_UNITS + NTW - 1) / NTW;
+            u32x4 rdy[DY_PER_T], ra[A_PER_T];
+            bool okdy[DY_PER_T], oka[A_PER_T];
+            const int cbd = co0 + dy_cu * EPU, cba = ci0 + a_cu * EPU;
+#pragma unroll
+            for (int i = 0; i < DY_PER_T; ++i) {
+                const int u = tid + i * NTW;
+                const int pix = u / DY_UPP;
+                const int ho = h0 + (pix >> 4), wo = w0 + (pix & 15);
+                okdy[i] = (u < DY_UNITS) && (ho < p.Ho) && (wo < p.Wo) && (cbd < p.Cout);
+                const size_t off = okdy[i] ? ((size_t)(n * p.Ho + ho) * p.Wo + wo) * p.Cout + cbd : 0;
+                rdy[i] = *reinterpret_cast<const u32x4*>(DY + off);
+            }
+#pragma unroll
+            for (int i = 0; i < A_PER_T; ++i) {
+                const int u = tid + i * NTW;
+                const int pp = u / A_UPP;
+                const int pr = pp / PW, pc = pp - pr * PW;
+                int ih = h0 * STRIDE + pr - p.pad_top, iw = w0 * STRIDE + pc - p.pad_left;
+                oka[i] = (u < A_UNITS) && (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl) && (cba < p.Cin);
+                if (p.upsample) { ih >>= 1; iw >>= 1; }
+                const size_t off = oka[i] ? ((size_t)(n * p.H + ih) * p.W + iw) * p.Cin + cba : 0;
+                ra[i] = *reinterpret_cast<const u32x4*>(X + off);
+            }
+            float sc[EPU], sh[EPU];
+            if (p.act != MAS_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < EPU; ++e) {
+                    const int c = cba + e;
+                    sc[e] = (c < p.Cin) ? p.ss[((size_t)n * p.Cin + c) * 2 + 0] : 0.0f;
+                    sh[e] = (c < p.Cin) ? p.ss[((size_t)n * p.Cin + c) * 2 + 1] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < DY_PER_T; ++i) {
+                const int u = tid + i * NTW;
+                if (u >= DY_UNITS) continue;
+                const int pix = u / DY_UPP;
+                u32x4 raw = rdy[i];
+                if (!okdy[i]) raw = u32x4{0u, 0u, 0u, 0u};
+                if (do_bias) {
+                    const T* rv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+                    for (int e = 0; e < EPU; ++e) bsum[e] += (float)rv[e];
+                }
+                const u32x4 rot = rot_elems<T>(raw, dy_cu);
+                const T* ov = reinterpret_cast<const T*>(&rot);
+#pragma unroll
+                for (int e = 0; e < EPU; ++e) dyt[(dy_cu * EPU + ((e + dy_cu) & (EPU - 1))) * DS + pix] = ov[e];
+            }
+            WTS(2);
+#pragma unroll
+            for (int i = 0; i < A_PER_T; ++i) {
+                const int u = tid + i * NTW;
+                if (u >= A_UNITS) continue;
+                const int pp = u / A_UPP;
+                const int pr = pp / PW, pc = pp - pr * PW;
+                const int off = (STRIDE == 1) ? (pr * PWA + pc) : (pr * 2 * PWA + (pc & 1) * PWA + (pc >> 1));
+                u32x4 raw = ra[i];
+                if (!oka[i]) raw = u32x4{0u, 0u, 0u, 0u};
+                else if (p.act != MAS_ACT_NONE) {
+                    T* tv = reinterpret_cast<T*>(&raw);
+#pragma unroll
+                    for (int e = 0; e < EPU; ++e) {
+                        float a = (float)tv[e] * sc[e] + sh[e];
+                        if (p.act == MAS_ACT_AFFINE_SILU) a = silu_f(a);
+                        tv[e] = (T)((cba + e < p.Cin) ? a : 0.0f);
+                    }
+                }
+                const u32x4 rot = rot_elems<T>(raw, a_cu);
+                const T* ov = reinterpret_cast<const T*>(&rot);
+#pragma unroll
+                for (int e = 0; e < EPU; ++e) at[(a_cu * EPU + ((e + a_cu) & (EPU - 1))) * CS + off] = ov[e];
+            }
+        } else {
         // ---- stage dY^T ------------------------------------------------------------
         for (int u = tid; u < DY_UNITS; u += NTW) {
             const int pix = u / DY_UPP;
@@ -185,39 +307,67 @@ __global__ __launch_bounds__(NTW, 2) void conv_wgrad_kernel(WgradParams p) {
                 for (int e = 0; e < EPU; ++e) at[(a_cu * EPU + e) * CS + off] = (T)v[e];
             }
         }
-        __syncthreads();
-        // ---- MFMA: for every patch row, every tap that touches it -------------------
-#pragma unroll
-        for (int pr = 0; pr < PH; ++pr) {
-            V8 bf[KS];
-#pragma unroll
-            for (int kw = 0; kw < KS; ++kw) {
-                const int plane = (STRIDE == 1) ? 0 : (kw & 1);
-                const int shift = (STRIDE == 1) ? kw : (kw >> 1);
-                bf[kw] = shifted8(b_frag_base + (pr * G::PLANES + plane) * PWA, shift);
-            }
-#pragma unroll
-            for (int kh = 0; kh < KS; ++kh) {
-                const int rr = pr - kh;
-                if (rr < 0 || (rr % STRIDE) != 0 || (rr / STRIDE) >= THW) continue;
-                const V8 af = ld8<T>(a_frag_base + (rr / STRIDE) * 16);
-#pragma unroll
-                for (int kw = 0; kw < KS; ++kw) mma16(acc[kh * KS + kw], af, bf[kw]);
-            }
         }
+        WTS(3);
+        __syncthreads();
+        WTS(4);
+        // ---- MFMA: for every patch row, every tap of this wave's range that touches it -----------------
+        auto mfma_phase = [&](auto HALF) {
+            constexpr int LO = decltype(HALF)::value * TPH, HI = (LO + TPH < NTAP) ? LO + TPH : NTAP;
+#pragma unroll
+            for (int pr = 0; pr < PH; ++pr) {
+                V8 bf[KS];
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw) {
+                    bool need = false;
+#pragma unroll
+                    for (int kh = 0; kh < KS; ++kh) {
+                        const int rr = pr - kh, tap = kh * KS + kw;
+                        if (rr >= 0 && (rr % STRIDE) == 0 && (rr / STRIDE) < THW && tap >= LO && tap < HI) need = true;
+                    }
+                    if (!need) continue;
+                    const int plane = (STRIDE == 1) ? 0 : (kw & 1);
+                    const int shift = (STRIDE == 1) ? kw : (kw >> 1);
+                    bf[kw] = shifted8(b_frag_base + (pr * G::PLANES + plane) * PWA, shift);
+                }
+#pragma unroll
+                for (int kh = 0; kh < KS; ++kh) {
+                    const int rr = pr - kh;
+                    if (rr < 0 || (rr % STRIDE) != 0 || (rr / STRIDE) >= THW) continue;
+                    if (kh * KS + KS <= LO || kh * KS >= HI) continue;
+                    const V8 af = ld8<T>(a_frag_base + (rr / STRIDE) * 16);
+#pragma unroll
+                    for (int kw = 0; kw < KS; ++kw) {
+                        const int tap = kh * KS + kw;
+                        if (tap >= LO && tap < HI) mma16(acc[tap - LO], af, bf[kw]);
+                    }
+                }
+            }
+        };
+        if (SPLIT == 1 || half == 0) mfma_phase(std::integral_constant<int, 0>{});
+        else mfma_phase(std::integral_constant<int, SPLIT - 1>{});
+        WTS(5);
+#ifdef MAS_TIMELINE
+        ++tl_iter;
+#endif
     }
 
     // ---- commit: fp32 atomics into dW[co][kh][kw][ci] --------------------------------
     const int ci = ci0 + wci + l31;
-    if (ci < p.Cin) {
+    auto commit = [&](auto HALF) {
+        constexpr int LO = decltype(HALF)::value * TPH, HI = (LO + TPH < NTAP) ? LO + TPH : NTAP;
+        if (ci < p.Cin) {
 #pragma unroll
-        for (int t = 0; t < NTAP; ++t)
+            for (int t = LO; t < HI; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wco + acc_row(lane, r);
-                if (co < p.Cout) atomicAdd(p.dw + ((size_t)co * NTAP + t) * p.Cin + ci, acc[t][r]);
-            }
-    }
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wco + acc_row(lane, r);
+                    if (co < p.Cout) atomicAdd(p.dw + ((size_t)co * NTAP + t) * p.Cin + ci, acc[t - LO][r]);
+                }
+        }
+    };
+    if (SPLIT == 1 || half == 0) commit(std::integral_constant<int, 0>{});
+    else commit(std::integral_constant<int, SPLIT - 1>{});
     if (do_bias) {
         // reduce the per-thread column sums over threads that share a channel group (through LDS)
         __syncthreads();
@@ -246,11 +396,11 @@ int launch(WgradParams p, hipStream_t s) {
     p.n_pt = p.N * p.tiles_h * p.tiles_w;
     p.n_co_t = mas_cdiv(p.Cout, BCO); p.n_ci_t = mas_cdiv(p.Cin, BCI);
     const int out_tiles = p.n_co_t * p.n_ci_t;
-    int nsplit = mas_cdiv(512, out_tiles);
+    int nsplit = mas_cdiv(mas_num_cus(), out_tiles);   // one (8- or 16-wave) work-group per CU
     if (nsplit > p.n_pt) nsplit = p.n_pt;
     if (nsplit < 1) nsplit = 1;
     p.nsplit = nsplit;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(out_tiles * nsplit)), dim3(NTW), G::LDS_BYTES, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(out_tiles * nsplit)), dim3(WSplit<KS>::NTW), G::LDS_BYTES, s, p);
     MAS_CHECK_LAUNCH("conv_wgrad");
     return MAS_OK;
 }
@@ -272,6 +422,8 @@ extern "C" int mas_conv_wgrad(const MasConvDesc* d, const void* x, const float* 
     if (d->act != MAS_ACT_NONE && !scale_shift) MAS_FAIL(MAS_EINVAL, "conv_wgrad: act prologue needs scale_shift");
     if (d->upsample && d->stride != 1) MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad: upsample fold needs stride 1");
     WgradParams p;
+    p.dbg = nullptr;
+    if (const char* e = getenv("MAS_DBG_PTR")) p.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
     p.x = x; p.ss = scale_shift; p.dy = dy; p.dw = dw; p.dbias = dbias;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
     p.Hl = d->upsample ? 2 * d->H : d->H; p.Wl = d->upsample ? 2 * d->W : d->W;
