@@ -160,11 +160,21 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_fwd_kernel(ConvParams
         const int cb = ci0 + sl * EPU;
         float sc[EPU], sh[EPU];
         if (p.act != MAS_ACT_NONE) {
+            if constexpr (vec_in) {            // 16-byte loads of the [c][2] pairs (channels past Cin are masked below)
+                const int cc = (cb + EPU <= p.Cin) ? cb : (p.Cin - EPU);
+                const f32x4* sp = reinterpret_cast<const f32x4*>(p.ss + ((size_t)n * p.Cin + cc) * 2);
 #pragma unroll
-            for (int e = 0; e < EPU; ++e) {
-                const int c = cb + e;
-                sc[e] = (c < p.Cin) ? p.ss[((size_t)n * p.Cin + c) * 2 + 0] : 0.0f;
-                sh[e] = (c < p.Cin) ? p.ss[((size_t)n * p.Cin + c) * 2 + 1] : 0.0f;
+                for (int q = 0; q < EPU / 2; ++q) {
+                    const f32x4 v = sp[q];
+                    sc[2 * q] = v[0]; sh[2 * q] = v[1]; sc[2 * q + 1] = v[2]; sh[2 * q + 1] = v[3];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPU; ++e) {
+                    const int c = cb + e;
+                    sc[e] = (c < p.Cin) ? p.ss[((size_t)n * p.Cin + c) * 2 + 0] : 0.0f;
+                    sh[e] = (c < p.Cin) ? p.ss[((size_t)n * p.Cin + c) * 2 + 1] : 0.0f;
+                }
             }
         }
 #pragma unroll

@@ -183,13 +183,16 @@ __global__ __launch_bounds__(WSplit<KS>::NTW) void conv_wgrad_kernel(WgradParams
                 const size_t off = oka[i] ? ((size_t)(n * p.H + ih) * p.W + iw) * p.Cin + cba : 0;
                 ra[i] = *reinterpret_cast<const u32x4*>(X + off);
             }
+            // scale/shift of this thread's EPU channels: unconditional 16-byte loads (clamped; masked by oka later) so
+            // the VMEM stream stays branch-free and hipcc's counted vmcnt does not drain it early
             float sc[EPU], sh[EPU];
             if (p.act != MAS_ACT_NONE) {
+                const int cc = (cba + EPU <= p.Cin) ? cba : (p.Cin - EPU);
+                const f32x4* sp = reinterpret_cast<const f32x4*>(p.ss + ((size_t)n * p.Cin + cc) * 2);
 #pragma unroll
-                for (int e = 0; e < EPU; ++e) {
-                    const int c = cba + e;
-                    sc[e] = (c < p.Cin) ? p.ss[((size_t)n * p.Cin + c) * 2 + 0] : 0.0f;
-                    sh[e] = (c < p.Cin) ? p.ss[((size_t)n * p.Cin + c) * 2 + 1] : 0.0f;
+                for (int q = 0; q < EPU / 2; ++q) {
+                    const f32x4 v = sp[q];
+                    sc[2 * q] = v[0]; sh[2 * q] = v[1]; sc[2 * q + 1] = v[2]; sh[2 * q + 1] = v[3];
                 }
             }
 #pragma unroll

@@ -66,9 +66,10 @@ __device__ __forceinline__ typename Vec8<T>::type zero8() {
     return v;
 }
 
-__device__ __forceinline__ float silu_f(float u) { return u / (1.0f + __expf(-u)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence: this runs once per staged element
+__device__ __forceinline__ float silu_f(float u) { return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)); }
 // d silu(u)/du = s*(1+u*(1-s)),  s = sigmoid(u)
-__device__ __forceinline__ float dsilu_f(float u) { float s = 1.0f / (1.0f + __expf(-u)); return s * (1.0f + u * (1.0f - s)); }
+__device__ __forceinline__ float dsilu_f(float u) { float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u)); return s * (1.0f + u * (1.0f - s)); }
 
 // ---- MFMA: one 32x32 tile, K-chunk of 16 (8 elements per lane: k = 8*(lane>>5)+j) ---
 // D[row=(r&3)+8*(r>>2)+4*(lane>>5)][col=lane&31] += sum_k A[row][k]*B[k][col]
