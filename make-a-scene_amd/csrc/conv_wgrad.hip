@@ -42,11 +42,14 @@ template <typename T, int KS, int STRIDE, int THW>
 struct WGeo {
     static constexpr int EPU = 16 / (int)sizeof(T);
     static constexpr int NPIX = THW * TWW;
-    static constexpr int DS = NPIX + EPU;                       // dY^T row stride (elements)
+    // QUAD staging (bf16, stride 1; see the kernel): rows of channel unit cu are skewed by (cu&7)*16 bytes instead of
+    // rotating elements, so the 16 channel units of a ds_write_b64 group land on different banks with zero VALU cost
+    static constexpr bool QUAD = (STRIDE == 1) && (sizeof(T) == 2);
+    static constexpr int DS = QUAD ? NPIX + 72 : NPIX + EPU;    // dY^T row stride (elements); 400 B = 25 slots (odd) in QUAD mode
     static constexpr int PH = (THW - 1) * STRIDE + KS, PW = (TWW - 1) * STRIDE + KS;
     static constexpr int PWA = 24;                              // padded plane width (>= 8*1+10)
     static constexpr int PLANES = STRIDE;                       // stride 2: even / odd input columns
-    static constexpr int CS = PH * PLANES * PWA + EPU;          // per-channel stride (elements)
+    static constexpr int CS = QUAD ? PH * PLANES * PWA + 72 : PH * PLANES * PWA + EPU;   // per-channel stride; QUAD: odd number of 16-byte slots
     static constexpr size_t LDS_BYTES = (size_t)(BCO * DS + BCI * CS) * sizeof(T);
 };
 
@@ -94,6 +97,19 @@ template <> __device__ __forceinline__ u32x4 rot_elems<float>(u32x4 v, int r) {
     return v;
 }
 
+// Transposed store of a 4-pixel x 8-channel bf16 block (o[j] = pixel j's 8 channels): for every channel the four pixels
+// are packed with v_perm_b32 into one 8-byte ds_write_b64 at row cu*8+e, column `col` + the row skew.
+__device__ __forceinline__ void store_quad_bf16(bf16_t* base, int row_stride, int cu, int col, const u32x4 (&o)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned lo01 = __builtin_amdgcn_perm(o[1][k], o[0][k], 0x05040100u), lo23 = __builtin_amdgcn_perm(o[3][k], o[2][k], 0x05040100u);
+        const unsigned hi01 = __builtin_amdgcn_perm(o[1][k], o[0][k], 0x07060302u), hi23 = __builtin_amdgcn_perm(o[3][k], o[2][k], 0x07060302u);
+        bf16_t* dst = base + (cu * 8 + 2 * k) * row_stride + (cu & 7) * 8 + col;    // rows skewed by (cu&7)*16 B
+        *reinterpret_cast<u32x2*>(dst) = u32x2{lo01, lo23};
+        *reinterpret_cast<u32x2*>(dst + row_stride) = u32x2{hi01, hi23};
+    }
+}
+
 template <typename T, int KS, int STRIDE, int THW>
 __global__ __launch_bounds__(WSplit<KS>::NTW) void conv_wgrad_kernel(WgradParams p) {
     using G = WGeo<T, KS, STRIDE, THW>;
@@ -138,8 +154,9 @@ __global__ __launch_bounds__(WSplit<KS>::NTW) void conv_wgrad_kernel(WgradParams
     for (int e = 0; e < EPU; ++e) bsum[e] = 0.0f;
     const bool do_bias = (p.dbias != nullptr) && (ci_t == 0);
 
-    const T* a_frag_base = dyt + (wco + l31) * DS + g * 8;
-    const T* b_frag_base = at + (wci + l31) * CS + g * 8;
+    const int skew_a = G::QUAD ? (((wco + l31) >> 3) & 7) * 8 : 0, skew_b = G::QUAD ? (((wci + l31) >> 3) & 7) * 8 : 0;
+    const T* a_frag_base = dyt + (wco + l31) * DS + skew_a + g * 8;
+    const T* b_frag_base = at + (wci + l31) * CS + skew_b + g * 8;
 
 #ifdef MAS_TIMELINE
     int tl_iter = 0;
@@ -147,6 +164,173 @@ __global__ __launch_bounds__(WSplit<KS>::NTW) void conv_wgrad_kernel(WgradParams
 #else
 #define WTS(id) do {} while (0)
 #endif
+    // ---- fast staging (16-byte aligned channel slots): the global loads of tile k+1 are issued into registers right
+    // before the MFMA phase of tile k and converted / transposed into LDS after it, so HBM latency hides under the MFMAs
+    const bool fast = vec_dy && vec_x;
+    // QUAD staging (bf16, stride 1): a thread owns 4 ADJACENT pixels of one 16-byte channel unit, so the transposed
+    // store is 8 x ds_write_b64 (4 pixels of one channel) instead of 32 x ds_write_b16 -- LDS store issue was the
+    // measured cost of staging (~10 cycles per wave-level ds_write_b16)
+    constexpr bool QUAD = G::QUAD;
+    constexpr int NG = (PW + 3) / 4;             // 4-column groups per patch row
+    constexpr int A_QUADS = (PH * NG * A_UPP + NTW - 1) / NTW;
+    constexpr int DY_PER_T = (DY_UNITS + NTW - 1) / NTW, A_PER_T = QUAD ? 4 * A_QUADS : (A_UNITS + NTW - 1) / NTW;
+    u32x4 rdy[DY_PER_T];                         // dY slots of the NEXT tile, in flight across the MFMA phase
+    const int cbd = co0 + dy_cu * EPU, cba = ci0 + a_cu * EPU;
+    auto coords = [&](int pt, int& n, int& h0, int& w0) {
+        int t = pt;
+        const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+        const int th_i = t % p.tiles_h; n = t / p.tiles_h;
+        h0 = th_i * THW; w0 = tw_i * TWW;
+    };
+    auto dy_ok = [&](int i, int h0, int w0, int& pix) {
+        const int u = tid + i * NTW;
+        if constexpr (QUAD) pix = 4 * (tid / DY_UPP + (i >> 2) * (NTW / DY_UPP)) + (i & 3);
+        else pix = u / DY_UPP;
+        const int ho = h0 + (pix >> 4), wo = w0 + (pix & 15);
+        return (QUAD || u < DY_UNITS) && (ho < p.Ho) && (wo < p.Wo) && (cbd < p.Cout);
+    };
+    auto a_ok = [&](int i, int h0, int w0, int& ih, int& iw, int& off) {
+        const int u = tid + i * NTW;
+        int pr, pc;
+        bool live;
+        if constexpr (QUAD) {
+            const int grp = tid / A_UPP + (i >> 2) * (NTW / A_UPP);
+            pr = grp / NG; pc = 4 * (grp - pr * NG) + (i & 3);
+            live = (grp < PH * NG) && (pc < PW);
+        } else {
+            const int pp = u / A_UPP;
+            pr = pp / PW; pc = pp - pr * PW;
+            live = u < A_UNITS;
+        }
+        ih = h0 * STRIDE + pr - p.pad_top; iw = w0 * STRIDE + pc - p.pad_left;
+        const bool ok = live && (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl) && (cba < p.Cin);
+        if (p.upsample) { ih >>= 1; iw >>= 1; }
+        off = (STRIDE == 1) ? (pr * PWA + pc) : (pr * 2 * PWA + (pc & 1) * PWA + (pc >> 1));
+        return ok;
+    };
+    auto issue = [&](int pt) {                   // unconditional (clamped) loads: a branch-free VMEM stream
+        int n, h0, w0;
+        coords(pt, n, h0, w0);
+#pragma unroll
+        for (int i = 0; i < DY_PER_T; ++i) {
+            int pix;
+            const bool ok = dy_ok(i, h0, w0, pix);
+            const size_t off = ok ? ((size_t)(n * p.Ho + h0 + (pix >> 4)) * p.Wo + w0 + (pix & 15)) * p.Cout + cbd : 0;
+            rdy[i] = *reinterpret_cast<const u32x4*>(DY + off);
+        }
+    };
+    auto commit_tile = [&](int pt) {             // registers -> (prologue) -> transposed LDS images
+        int n, h0, w0;
+        coords(pt, n, h0, w0);
+        u32x4 ra[A_PER_T];                       // input patch slots: issued here, land while the dY stores run
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) {
+            int ih, iw, o;
+            const bool ok = a_ok(i, h0, w0, ih, iw, o);
+            const size_t off = ok ? ((size_t)(n * p.H + ih) * p.W + iw) * p.Cin + cba : 0;
+            ra[i] = *reinterpret_cast<const u32x4*>(X + off);
+        }
+        f32x4 rss[EPU / 2];                      // scale/shift of this thread's channels (L2 hit; lands during the dY stores)
+        if (p.act != MAS_ACT_NONE) {
+            const int cc = (cba + EPU <= p.Cin) ? cba : (p.Cin - EPU);
+            const f32x4* sp = reinterpret_cast<const f32x4*>(p.ss + ((size_t)n * p.Cin + cc) * 2);
+#pragma unroll
+            for (int q = 0; q < EPU / 2; ++q) rss[q] = sp[q];
+        }
+        if constexpr (QUAD) {
+#pragma unroll
+            for (int qi = 0; qi < DY_PER_T / 4; ++qi) {
+                u32x4 o[4];
+                int pix0 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int pix;
+                    const bool ok = dy_ok(qi * 4 + j, h0, w0, pix);
+                    if (j == 0) pix0 = pix;
+                    u32x4 raw = rdy[qi * 4 + j];
+                    if (!ok) raw = u32x4{0u, 0u, 0u, 0u};
+                    if (do_bias) {
+                        const T* rv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+                        for (int e = 0; e < EPU; ++e) bsum[e] += (float)rv[e];
+                    }
+                    o[j] = raw;
+                }
+                store_quad_bf16(reinterpret_cast<bf16_t*>(dyt), DS, dy_cu, pix0, o);
+            }
+            WTS(2);
+#pragma unroll
+            for (int qi = 0; qi < A_PER_T / 4; ++qi) {
+                const int grp = tid / A_UPP + qi * (NTW / A_UPP);
+                if (grp >= PH * NG) continue;
+                u32x4 o[4];
+                int off0 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int ih, iw, off;
+                    const bool ok = a_ok(qi * 4 + j, h0, w0, ih, iw, off);
+                    if (j == 0) off0 = off;
+                    u32x4 raw = ra[qi * 4 + j];
+                    if (!ok) raw = u32x4{0u, 0u, 0u, 0u};
+                    else if (p.act != MAS_ACT_NONE) {
+                        T* tv = reinterpret_cast<T*>(&raw);
+#pragma unroll
+                        for (int e = 0; e < EPU; ++e) {
+                            const float sc = rss[e >> 1][(e & 1) * 2], sh = rss[e >> 1][(e & 1) * 2 + 1];
+                            float a = (float)tv[e] * sc + sh;
+                            if (p.act == MAS_ACT_AFFINE_SILU) a = silu_f(a);
+                            tv[e] = (T)((cba + e < p.Cin) ? a : 0.0f);
+                        }
+                    }
+                    o[j] = raw;
+                }
+                store_quad_bf16(reinterpret_cast<bf16_t*>(at), CS, a_cu, off0, o);
+            }
+        } else {
+#pragma unroll
+        for (int i = 0; i < DY_PER_T; ++i) {
+            int pix;
+            const bool ok = dy_ok(i, h0, w0, pix);
+            if (tid + i * NTW >= DY_UNITS) continue;
+            u32x4 raw = rdy[i];
+            if (!ok) raw = u32x4{0u, 0u, 0u, 0u};
+            if (do_bias) {
+                const T* rv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+                for (int e = 0; e < EPU; ++e) bsum[e] += (float)rv[e];
+            }
+            const u32x4 rot = rot_elems<T>(raw, dy_cu);
+            const T* ov = reinterpret_cast<const T*>(&rot);
+#pragma unroll
+            for (int e = 0; e < EPU; ++e) dyt[(dy_cu * EPU + ((e + dy_cu) & (EPU - 1))) * DS + pix] = ov[e];
+        }
+        WTS(2);
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) {
+            int ih, iw, off;
+            const bool ok = a_ok(i, h0, w0, ih, iw, off);
+            if (tid + i * NTW >= A_UNITS) continue;
+            u32x4 raw = ra[i];
+            if (!ok) raw = u32x4{0u, 0u, 0u, 0u};
+            else if (p.act != MAS_ACT_NONE) {
+                T* tv = reinterpret_cast<T*>(&raw);
+#pragma unroll
+                for (int e = 0; e < EPU; ++e) {
+                    const float sc = rss[e >> 1][(e & 1) * 2], sh = rss[e >> 1][(e & 1) * 2 + 1];
+                    float a = (float)tv[e] * sc + sh;
+                    if (p.act == MAS_ACT_AFFINE_SILU) a = silu_f(a);
+                    tv[e] = (T)((cba + e < p.Cin) ? a : 0.0f);
+                }
+            }
+            const u32x4 rot = rot_elems<T>(raw, a_cu);
+            const T* ov = reinterpret_cast<const T*>(&rot);
+#pragma unroll
+            for (int e = 0; e < EPU; ++e) at[(a_cu * EPU + ((e + a_cu) & (EPU - 1))) * CS + off] = ov[e];
+        }
+        }
+    };
+    if (fast && split < p.n_pt) issue(split);
+
     for (int pt = split; pt < p.n_pt; pt += p.nsplit) {
         int t = pt;
         const int tw_i = t % p.tiles_w; t /= p.tiles_w;
@@ -155,87 +339,8 @@ __global__ __launch_bounds__(WSplit<KS>::NTW) void conv_wgrad_kernel(WgradParams
         WTS(0);
         __syncthreads();                         // previous tile's fragment reads are done
         WTS(1);
-        if (vec_dy && vec_x) {
-            // ---- fast staging: ALL global loads of the tile are issued first (one HBM round trip instead of
-            // one per unit: the measured staging time was 13K of a 21K-cycle tile, all exposed load latency),
-            // then converted / transposed into LDS
-            constexpr int DY_PER_T = (DY_UNITS + NTW - 1) / NTW, A_PER_T = (A_UNITS + NTW - 1) / NTW;
-            u32x4 rdy[DY_PER_T], ra[A_PER_T];
-            bool okdy[DY_PER_T], oka[A_PER_T];
-            const int cbd = co0 + dy_cu * EPU, cba = ci0 + a_cu * EPU;
-#pragma unroll
-            for (int i = 0; i < DY_PER_T; ++i) {
-                const int u = tid + i * NTW;
-                const int pix = u / DY_UPP;
-                const int ho = h0 + (pix >> 4), wo = w0 + (pix & 15);
-                okdy[i] = (u < DY_UNITS) && (ho < p.Ho) && (wo < p.Wo) && (cbd < p.Cout);
-                const size_t off = okdy[i] ? ((size_t)(n * p.Ho + ho) * p.Wo + wo) * p.Cout + cbd : 0;
-                rdy[i] = *reinterpret_cast<const u32x4*>(DY + off);
-            }
-#pragma unroll
-            for (int i = 0; i < A_PER_T; ++i) {
-                const int u = tid + i * NTW;
-                const int pp = u / A_UPP;
-                const int pr = pp / PW, pc = pp - pr * PW;
-                int ih = h0 * STRIDE + pr - p.pad_top, iw = w0 * STRIDE + pc - p.pad_left;
-                oka[i] = (u < A_UNITS) && (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl) && (cba < p.Cin);
-                if (p.upsample) { ih >>= 1; iw >>= 1; }
-                const size_t off = oka[i] ? ((size_t)(n * p.H + ih) * p.W + iw) * p.Cin + cba : 0;
-                ra[i] = *reinterpret_cast<const u32x4*>(X + off);
-            }
-            // scale/shift of this thread's EPU channels: unconditional 16-byte loads (clamped; masked by oka later) so
-            // the VMEM stream stays branch-free and hipcc's counted vmcnt does not drain it early
-            float sc[EPU], sh[EPU];
-            if (p.act != MAS_ACT_NONE) {
-                const int cc = (cba + EPU <= p.Cin) ? cba : (p.Cin - EPU);
-                const f32x4* sp = reinterpret_cast<const f32x4*>(p.ss + ((size_t)n * p.Cin + cc) * 2);
-#pragma unroll
-                for (int q = 0; q < EPU / 2; ++q) {
-                    const f32x4 v = sp[q];
-                    sc[2 * q] = v[0]; sh[2 * q] = v[1]; sc[2 * q + 1] = v[2]; sh[2 * q + 1] = v[3];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < DY_PER_T; ++i) {
-                const int u = tid + i * NTW;
-                if (u >= DY_UNITS) continue;
-                const int pix = u / DY_UPP;
-                u32x4 raw = rdy[i];
-                if (!okdy[i]) raw = u32x4{0u, 0u, 0u, 0u};
-                if (do_bias) {
-                    const T* rv = reinterpret_cast<const T*>(&raw);
-#pragma unroll
-                    for (int e = 0; e < EPU; ++e) bsum[e] += (float)rv[e];
-                }
-                const u32x4 rot = rot_elems<T>(raw, dy_cu);
-                const T* ov = reinterpret_cast<const T*>(&rot);
-#pragma unroll
-                for (int e = 0; e < EPU; ++e) dyt[(dy_cu * EPU + ((e + dy_cu) & (EPU - 1))) * DS + pix] = ov[e];
-            }
-            WTS(2);
-#pragma unroll
-            for (int i = 0; i < A_PER_T; ++i) {
-                const int u = tid + i * NTW;
-                if (u >= A_UNITS) continue;
-                const int pp = u / A_UPP;
-                const int pr = pp / PW, pc = pp - pr * PW;
-                const int off = (STRIDE == 1) ? (pr * PWA + pc) : (pr * 2 * PWA + (pc & 1) * PWA + (pc >> 1));
-                u32x4 raw = ra[i];
-                if (!oka[i]) raw = u32x4{0u, 0u, 0u, 0u};
-                else if (p.act != MAS_ACT_NONE) {
-                    T* tv = reinterpret_cast<T*>(&raw);
-#pragma unroll
-                    for (int e = 0; e < EPU; ++e) {
-                        float a = (float)tv[e] * sc[e] + sh[e];
-                        if (p.act == MAS_ACT_AFFINE_SILU) a = silu_f(a);
-                        tv[e] = (T)((cba + e < p.Cin) ? a : 0.0f);
-                    }
-                }
-                const u32x4 rot = rot_elems<T>(raw, a_cu);
-                const T* ov = reinterpret_cast<const T*>(&rot);
-#pragma unroll
-                for (int e = 0; e < EPU; ++e) at[(a_cu * EPU + ((e + a_cu) & (EPU - 1))) * CS + off] = ov[e];
-            }
+        if (fast) {
+            commit_tile(pt);
         } else {
         // ---- stage dY^T ------------------------------------------------------------
         for (int u = tid; u < DY_UNITS; u += NTW) {
@@ -262,7 +367,7 @@ __global__ __launch_bounds__(WSplit<KS>::NTW) void conv_wgrad_kernel(WgradParams
                 for (int e = 0; e < EPU; ++e) bsum[e] += v[e];
             }
 #pragma unroll
-            for (int e = 0; e < EPU; ++e) dyt[(dy_cu * EPU + e) * DS + pix] = (T)v[e];
+            for (int e = 0; e < EPU; ++e) dyt[(dy_cu * EPU + e) * DS + (G::QUAD ? (dy_cu & 7) * 8 : 0) + pix] = (T)v[e];
         }
         // ---- stage A^T (activated input patch) ---------------------------------------
         {
@@ -307,13 +412,17 @@ __global__ __launch_bounds__(WSplit<KS>::NTW) void conv_wgrad_kernel(WgradParams
                 }
                 const int off = (STRIDE == 1) ? (pr * PWA + pc) : (pr * 2 * PWA + (pc & 1) * PWA + (pc >> 1));
 #pragma unroll
-                for (int e = 0; e < EPU; ++e) at[(a_cu * EPU + e) * CS + off] = (T)v[e];
+                for (int e = 0; e < EPU; ++e) at[(a_cu * EPU + e) * CS + (G::QUAD ? (a_cu & 7) * 8 : 0) + off] = (T)v[e];
             }
         }
         }
         WTS(3);
         __syncthreads();
         WTS(4);
+        if (fast) {                              // next tile's loads fly during this tile's MFMAs (a harmless re-read at the end)
+            const int npt = (pt + p.nsplit < p.n_pt) ? pt + p.nsplit : pt;
+            issue(npt);
+        }
         // ---- MFMA: for every patch row, every tap of this wave's range that touches it -----------------
         auto mfma_phase = [&](auto HALF) {
             constexpr int LO = decltype(HALF)::value * TPH, HI = (LO + TPH < NTAP) ? LO + TPH : NTAP;
