@@ -120,6 +120,15 @@ int    mas_vq_argmin_fwd(const float* z, const float* codebook, int M, int K, in
 int    mas_vq_bwd(const float* z, const float* codebook, const int64_t* idx, const float* g_zq,
                   const float* g_loss, float beta, int M, int K, int D, float* dz, float* dcodebook, void* stream);
 
+/* ---- causal multi-head self-attention forward (flash style)  (replaces calculate_attention + Softmax +
+ * matmul(probs, v), models/transformer.py:44-71,90-97, training configuration: pb-relax shift is softmax-invariant,
+ * the net mask is pure causal -- SURVEY 3.4).  q,k,v: element (b, s, h, d) at ptr[b*bs + s*ld + h*hd + d] (so the
+ * fused [B,S,3*H*hd] qkv tensor is addressed in place); o: [B,S,H*hd] contiguous; lse: [B,H,S] fp32 (log-sum-exp of
+ * the scaled scores, for the backward) or NULL.  hd in {16,32,64,128}.                                          */
+int mas_attn_causal_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B, int H,
+                        int S, int hd, int ld_q, int ld_k, int ld_v, long long q_bs, long long k_bs, long long v_bs,
+                        float scale, void* stream);
+
 /* ---- small NHWC helpers on the path -------------------------------------------------
  * nearest x2 upsample (F.interpolate, modules.py:56) and its adjoint (2x2 sum);
  * zero-stuffing used by the stride-2 data gradient (adjoint of modules.py:76-78).      */

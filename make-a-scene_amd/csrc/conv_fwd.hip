@@ -465,10 +465,11 @@ int launch_v(const ConvParams& p0, hipStream_t s) {
     ConvParams p = p0;
     p.tiles_h = mas_cdiv(p.Ho, G::TH); p.tiles_w = mas_cdiv(p.Wo, TW);
     constexpr int TPS = (BIG && KS == 3) ? 3 : 1;
-    const size_t lds = (size_t)G::PATCH_BYTES + 2 * TPS * BC * 128;
+    size_t lds = (size_t)G::PATCH_BYTES + 2 * TPS * BC * 128;
+    if (const char* e = getenv("MAS_CONV_LDS_PAD")) lds += (size_t)atoi(e);   // experiment: lower residency
     auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, BC, WC, VEC, BIG>;
     static bool attr_done = false;
-    if (!attr_done) {
+    if (!attr_done || getenv("MAS_CONV_LDS_PAD")) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             MAS_FAIL(MAS_ELAUNCH, "conv_fwd: cannot set dynamic LDS size %zu", lds);
         attr_done = true;
@@ -477,7 +478,8 @@ int launch_v(const ConvParams& p0, hipStream_t s) {
     q.n_ct = mas_cdiv(p.Cout, BC);
     const long long tiles = (long long)p.N * p.tiles_h * p.tiles_w * q.n_ct;
     if (tiles <= 0 || tiles > 0x7fffffffLL) MAS_FAIL(MAS_EINVAL, "conv_fwd: bad tile count %lld", tiles);
-    const long long resident = (BIG ? 1LL : 2LL) * mas_num_cus();   // work-groups per CU allowed by the LDS / VGPR budget
+    long long resident = (BIG ? 1LL : 2LL) * mas_num_cus();
+    if (const char* e = getenv("MAS_CONV_WGS_PER_CU")) resident = (long long)atoi(e) * mas_num_cus();   // work-groups per CU allowed by the LDS / VGPR budget
     const unsigned blocks = (unsigned)(tiles < resident ? tiles : resident);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, s, q);
     MAS_CHECK_LAUNCH("conv_fwd");

@@ -328,3 +328,53 @@ def spatial_attention(qkv: torch.Tensor, c: int) -> torch.Tensor:
     p = torch.softmax(s, dim=2)
     o = torch.bmm(p, v)
     return o.reshape(n, h, w, c).permute(0, 3, 1, 2)            # [N,C,H,W] logical, NHWC memory
+
+
+# --------------------------------------------------------------------------- #
+# causal multi-head attention (transformer path, reference models/transformer.py:44-115)
+# --------------------------------------------------------------------------- #
+class _CausalAttention(torch.autograd.Function):
+    """context = softmax_causal((q/sqrt(hd)) k^T) v on the fused qkv projection [B,S,3*H*hd].
+
+    Forward: the flash-style HIP kernel (never writes the [S,S] scores).  Backward (round 1): the scores are
+    recomputed with library batched GEMMs per call -- the hand-written backward kernel is DESIGN.md section 7."""
+
+    @staticmethod
+    def forward(ctx, qkv, n_heads):
+        _require_cuda(qkv, "causal_attention")
+        cd = compute_dtype()
+        x = qkv.to(cd).contiguous()
+        b, s, d3 = x.shape
+        d = d3 // 3
+        hd = d // n_heads
+        o = torch.empty((b, s, d), dtype=cd, device=x.device)
+        lse = torch.empty((b, n_heads, s), dtype=torch.float32, device=x.device)
+        esz = x.element_size()
+        base = x.data_ptr()
+        check(lib().mas_attn_causal_fwd(C.c_void_p(base), C.c_void_p(base + d * esz), C.c_void_p(base + 2 * d * esz), _ptr(o), _ptr(lse),
+                                        _DT[cd], b, n_heads, s, hd, d3, d3, d3, s * d3, s * d3, s * d3, float(hd) ** -0.5, _stream()),
+              "attn_causal_fwd")
+        ctx.n_heads = n_heads
+        ctx.save_for_backward(x)
+        return o.to(qkv.dtype)
+
+    @staticmethod
+    def backward(ctx, do):
+        (x,) = ctx.saved_tensors
+        b, s, d3 = x.shape
+        h = ctx.n_heads
+        d = d3 // 3
+        hd = d // h
+        with torch.enable_grad():
+            xx = x.detach().requires_grad_(True)
+            q, k, v = (t.view(b, s, h, hd).permute(0, 2, 1, 3) for t in torch.split(xx, d, dim=-1))
+            sc = torch.matmul(q * (float(hd) ** -0.5), k.transpose(-1, -2))
+            causal = torch.ones(s, s, dtype=torch.bool, device=x.device).tril_()
+            p = torch.softmax(sc.float().masked_fill(~causal, float("-inf")), dim=-1).to(x.dtype)
+            ctxt = torch.matmul(p, v).permute(0, 2, 1, 3).reshape(b, s, d)
+        (g,) = torch.autograd.grad(ctxt, xx, do.to(x.dtype))
+        return g.to(do.dtype), None
+
+
+def causal_attention(qkv: torch.Tensor, n_heads: int) -> torch.Tensor:
+    return _CausalAttention.apply(qkv, n_heads)
