@@ -129,6 +129,12 @@ int mas_attn_causal_fwd(const void* q, const void* k, const void* v, void* o, fl
                         int S, int hd, int ld_q, int ld_k, int ld_v, long long q_bs, long long k_bs, long long v_bs,
                         float scale, void* stream);
 
+/* backward of mas_attn_causal_fwd on the fused projection: qkv and dqkv are [B,S,3*H*hd] contiguous (q|k|v stacked on
+ * the last axis), o / dout [B,S,H*hd], lse from the forward, delta [B,H,S] fp32 scratch.  Every element of dqkv is
+ * written exactly once (no atomics, deterministic).                                                             */
+int mas_attn_causal_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv,
+                        int dtype, int B, int H, int S, int hd, float scale, void* stream);
+
 /* ---- small NHWC helpers on the path -------------------------------------------------
  * nearest x2 upsample (F.interpolate, modules.py:56) and its adjoint (2x2 sum);
  * zero-stuffing used by the stride-2 data gradient (adjoint of modules.py:76-78).      */

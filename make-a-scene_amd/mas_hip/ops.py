@@ -335,9 +335,8 @@ def spatial_attention(qkv: torch.Tensor, c: int) -> torch.Tensor:
 # --------------------------------------------------------------------------- #
 class _CausalAttention(torch.autograd.Function):
     """context = softmax_causal((q/sqrt(hd)) k^T) v on the fused qkv projection [B,S,3*H*hd].
-
-    Forward: the flash-style HIP kernel (never writes the [S,S] scores).  Backward (round 1): the scores are
-    recomputed with library batched GEMMs per call -- the hand-written backward kernel is DESIGN.md section 7."""
+    Forward and backward are the flash-style HIP kernels (the [S,S] scores are never written; the backward
+    recomputes them tile by tile from the saved log-sum-exp and writes d(qkv) in place, no atomics)."""
 
     @staticmethod
     def forward(ctx, qkv, n_heads):
@@ -355,25 +354,22 @@ class _CausalAttention(torch.autograd.Function):
                                         _DT[cd], b, n_heads, s, hd, d3, d3, d3, s * d3, s * d3, s * d3, float(hd) ** -0.5, _stream()),
               "attn_causal_fwd")
         ctx.n_heads = n_heads
-        ctx.save_for_backward(x)
+        ctx.in_dtype = qkv.dtype
+        ctx.save_for_backward(x, o, lse)
         return o.to(qkv.dtype)
 
     @staticmethod
     def backward(ctx, do):
-        (x,) = ctx.saved_tensors
+        x, o, lse = ctx.saved_tensors
         b, s, d3 = x.shape
         h = ctx.n_heads
-        d = d3 // 3
-        hd = d // h
-        with torch.enable_grad():
-            xx = x.detach().requires_grad_(True)
-            q, k, v = (t.view(b, s, h, hd).permute(0, 2, 1, 3) for t in torch.split(xx, d, dim=-1))
-            sc = torch.matmul(q * (float(hd) ** -0.5), k.transpose(-1, -2))
-            causal = torch.ones(s, s, dtype=torch.bool, device=x.device).tril_()
-            p = torch.softmax(sc.float().masked_fill(~causal, float("-inf")), dim=-1).to(x.dtype)
-            ctxt = torch.matmul(p, v).permute(0, 2, 1, 3).reshape(b, s, d)
-        (g,) = torch.autograd.grad(ctxt, xx, do.to(x.dtype))
-        return g.to(do.dtype), None
+        hd = d3 // 3 // h
+        g = do.to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        delta = torch.empty_like(lse)
+        check(lib().mas_attn_causal_bwd(_ptr(x), _ptr(o), _ptr(g), _ptr(lse), _ptr(delta), _ptr(dx), _DT[x.dtype], b, h, s, hd,
+                                        float(hd) ** -0.5, _stream()), "attn_causal_bwd")
+        return dx.to(ctx.in_dtype), None
 
 
 def causal_attention(qkv: torch.Tensor, n_heads: int) -> torch.Tensor:
