@@ -494,6 +494,248 @@ __global__ __launch_bounds__(WSplit<KS>::NTW) void conv_wgrad_kernel(WgradParams
     }
 }
 
+
+// =========================================================================================================
+// bf16 / stride-1 weight gradient on the LDS TRANSPOSE READ (ds_read_b64_tr_b16).
+// The K dimension of the wgrad GEMM is the pixel index -- the OUTER dimension of both NHWC operands.  The kernel
+// above transposes both operands while staging them; here they are staged in their natural [pixel][channel] layout
+// (plain 16-byte copies) and the MFMA fragments are fetched with the hardware transpose read.  Semantics measured
+// on gfx950 (tools/probes/tr_probe.hip): inside a 16-lane group lane s reads the 8 bytes at ITS address and lane l
+// receives { M[4j + (l>>2)][l&3] : j=0..3 } where M[s][e] is element e of lane s's 8 bytes.  With lane s pointed at
+// pixel (s>>2), channels 4(s&3)..+3, lane l ends up with channel l of 4 consecutive pixels -- an MFMA operand run.
+// Per-lane addresses also make the 3x3 tap shifts free (any pixel offset is just an address).
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* a0, const unsigned char* a1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+    const __attribute__((ext_vector_type(8))) short v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return *reinterpret_cast<const bf16x8*>(&v);
+}
+
+template <int KS, int BCI_>
+struct TrGeo {
+    static constexpr int THW = 8, NPIX = THW * TWW, PH = THW + KS - 1, PW = TWW + KS - 1;
+    static constexpr int RSY = BCO * 2 + 64;                 // dY row stride (bytes): 4 consecutive pixel rows x 64 B tile the 256-B bank row
+    static constexpr int RSX = BCI_ == 32 ? 64 : BCI_ * 2 + 64;
+    static constexpr int DY_BYTES = NPIX * RSY, X_BYTES = PH * PW * RSX;
+    static constexpr size_t LDS_BYTES = (size_t)DY_BYTES + X_BYTES;
+    static constexpr int NTILE = 4 * (BCI_ / 32), SPLIT = 8 / NTILE, NT = 512;
+    static constexpr int TPH = (KS * KS + SPLIT - 1) / SPLIT;
+};
+
+template <int KS, int BCI_>
+__global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgradParams p) {
+    using G = TrGeo<KS, BCI_>;
+    using T = bf16_t;
+    constexpr int NT = G::NT, THW = G::THW, PH = G::PH, PW = G::PW, RSY = G::RSY, RSX = G::RSX, NTAP = KS * KS;
+    constexpr int SPLIT = G::SPLIT, TPH = G::TPH, NTILE = G::NTILE;
+    constexpr int DY_PER_T = G::NPIX * (BCO / 8) / NT;                       // 16-byte slots per thread: 4
+    constexpr int X_UPP = BCI_ / 8, X_UNITS = PH * PW * X_UPP, X_PER_T = (X_UNITS + NT - 1) / NT;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* dys = smem;                   // [128 px][RSY]
+    unsigned char* xs = smem + G::DY_BYTES;      // [PH*PW px][RSX]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 5, l31 = lane & 31, G16 = (lane >> 4) & 1, sl = lane & 15;
+    const int wtile = wave % NTILE, half = wave / NTILE;
+    const int wco = (wtile & 3) * 32, wci = (wtile >> 2) * 32;
+
+    int bid = blockIdx.x;
+    const int split = bid % p.nsplit; bid /= p.nsplit;
+    const int ci_t = bid % p.n_ci_t; const int co_t = bid / p.n_ci_t;
+    const int co0 = co_t * BCO, ci0 = ci_t * BCI_;
+    const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
+
+    f32x16 acc[TPH];
+#pragma unroll
+    for (int t = 0; t < TPH; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // transpose-read lane addressing: pixel (8g + (sl>>2)) of a k-chunk, channels 16*G16 + 4*(sl&3) .. +3
+    const unsigned char* a_lane = dys + (8 * g + (sl >> 2)) * RSY + (wco + 16 * G16 + 4 * (sl & 3)) * 2;
+    const unsigned char* b_lane = xs + (8 * g + (sl >> 2)) * RSX + (wci + 16 * G16 + 4 * (sl & 3)) * 2;
+
+    const int dy_cu = tid & 15, x_cu = tid % X_UPP;
+    const int cbd = co0 + dy_cu * 8, cbx = ci0 + x_cu * 8;
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.0f;
+    const bool do_bias = (p.dbias != nullptr) && (ci_t == 0);
+
+    auto coords = [&](int pt, int& n, int& h0, int& w0) {
+        int t = pt;
+        const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+        const int th_i = t % p.tiles_h; n = t / p.tiles_h;
+        h0 = th_i * THW; w0 = tw_i * TWW;
+    };
+    u32x4 rdy[DY_PER_T];                         // dY slots of the next tile: in flight across the MFMA phase
+    auto issue = [&](int pt) {
+        int n, h0, w0;
+        coords(pt, n, h0, w0);
+#pragma unroll
+        for (int i = 0; i < DY_PER_T; ++i) {
+            const int pix = (tid >> 4) + i * (NT / 16);
+            const int ho = h0 + (pix >> 4), wo = w0 + (pix & 15);
+            const bool ok = (ho < p.Ho) && (wo < p.Wo) && (cbd < p.Cout);
+            const size_t off = ok ? ((size_t)(n * p.Ho + ho) * p.Wo + wo) * p.Cout + cbd : 0;
+            rdy[i] = *reinterpret_cast<const u32x4*>(DY + off);
+        }
+    };
+    auto commit_tile = [&](int pt) {
+        int n, h0, w0;
+        coords(pt, n, h0, w0);
+        u32x4 rx[X_PER_T];
+        bool okx[X_PER_T];
+#pragma unroll
+        for (int i = 0; i < X_PER_T; ++i) {      // input patch slots: issued first, land while the dY stores run
+            const int u = tid + i * NT;
+            const int pp = u / X_UPP;
+            const int pr = pp / PW, pc = pp - pr * PW;
+            int ih = h0 + pr - p.pad_top, iw = w0 + pc - p.pad_left;
+            okx[i] = (u < X_UNITS) && (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl) && (cbx < p.Cin);
+            if (p.upsample) { ih >>= 1; iw >>= 1; }
+            const size_t off = okx[i] ? ((size_t)(n * p.H + ih) * p.W + iw) * p.Cin + cbx : 0;
+            rx[i] = *reinterpret_cast<const u32x4*>(X + off);
+        }
+        f32x4 rss[4];
+        if (p.act != MAS_ACT_NONE) {
+            const int cc = (cbx + 8 <= p.Cin) ? cbx : (p.Cin - 8);
+            const f32x4* sp = reinterpret_cast<const f32x4*>(p.ss + ((size_t)n * p.Cin + cc) * 2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rss[q] = sp[q];
+        }
+#pragma unroll
+        for (int i = 0; i < DY_PER_T; ++i) {     // natural layout: one ds_write_b128 per slot
+            const int pix = (tid >> 4) + i * (NT / 16);
+            const int ho = h0 + (pix >> 4), wo = w0 + (pix & 15);
+            u32x4 raw = rdy[i];
+            if (!((ho < p.Ho) && (wo < p.Wo) && (cbd < p.Cout))) raw = u32x4{0u, 0u, 0u, 0u};
+            if (do_bias) {
+                const T* rv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[e] += (float)rv[e];
+            }
+            *reinterpret_cast<u32x4*>(dys + pix * RSY + dy_cu * 16) = raw;
+        }
+#pragma unroll
+        for (int i = 0; i < X_PER_T; ++i) {
+            const int u = tid + i * NT;
+            if (u >= X_UNITS) continue;
+            u32x4 raw = rx[i];
+            if (!okx[i]) raw = u32x4{0u, 0u, 0u, 0u};
+            else if (p.act != MAS_ACT_NONE) {
+                T* tv = reinterpret_cast<T*>(&raw);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float a = (float)tv[e] * rss[e >> 1][(e & 1) * 2] + rss[e >> 1][(e & 1) * 2 + 1];
+                    if (p.act == MAS_ACT_AFFINE_SILU) a = silu_f(a);
+                    tv[e] = (T)((cbx + e < p.Cin) ? a : 0.0f);
+                }
+            }
+            *reinterpret_cast<u32x4*>(xs + (u / X_UPP) * RSX + x_cu * 16) = raw;
+        }
+    };
+
+    if (split < p.n_pt) issue(split);
+    for (int pt = split; pt < p.n_pt; pt += p.nsplit) {
+        __syncthreads();                         // previous tile's fragment reads are done
+        commit_tile(pt);
+        __syncthreads();
+        issue((pt + p.nsplit < p.n_pt) ? pt + p.nsplit : pt);     // next tile's dY (a harmless re-read at the end)
+        auto mfma_phase = [&](auto HALF) {
+            constexpr int LO = decltype(HALF)::value * TPH, HI = (LO + TPH < NTAP) ? LO + TPH : NTAP;
+#pragma unroll
+            for (int pr = 0; pr < PH; ++pr) {
+                bf16x8 bf[KS];
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw) {
+                    bool need = false;
+#pragma unroll
+                    for (int kh = 0; kh < KS; ++kh) {
+                        const int rr = pr - kh, tap = kh * KS + kw;
+                        if (rr >= 0 && rr < THW && tap >= LO && tap < HI) need = true;
+                    }
+                    if (!need) continue;
+                    const unsigned char* b0 = b_lane + (pr * PW + kw) * RSX;    // patch pixels (pr, kw + 8g + j)
+                    bf[kw] = tr_frag(b0, b0 + 4 * RSX);
+                }
+#pragma unroll
+                for (int kh = 0; kh < KS; ++kh) {
+                    const int rr = pr - kh;
+                    if (rr < 0 || rr >= THW) continue;
+                    if (kh * KS + KS <= LO || kh * KS >= HI) continue;
+                    const unsigned char* a0 = a_lane + (rr * 16) * RSY;          // dY pixels (rr, 8g + j)
+                    const bf16x8 af = tr_frag(a0, a0 + 4 * RSY);
+#pragma unroll
+                    for (int kw = 0; kw < KS; ++kw) {
+                        const int tap = kh * KS + kw;
+                        if (tap >= LO && tap < HI) mma16(acc[tap - LO], af, bf[kw]);
+                    }
+                }
+            }
+        };
+        if (SPLIT == 1 || half == 0) mfma_phase(std::integral_constant<int, 0>{});
+        else mfma_phase(std::integral_constant<int, SPLIT - 1>{});
+    }
+
+    const int ci = ci0 + wci + l31;
+    auto commit = [&](auto HALF) {
+        constexpr int LO = decltype(HALF)::value * TPH, HI = (LO + TPH < NTAP) ? LO + TPH : NTAP;
+        if (ci < p.Cin) {
+#pragma unroll
+            for (int t = LO; t < HI; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wco + acc_row(lane, r);
+                    if (co < p.Cout) atomicAdd(p.dw + ((size_t)co * NTAP + t) * p.Cin + ci, acc[t - LO][r]);
+                }
+        }
+    };
+    if (SPLIT == 1 || half == 0) commit(std::integral_constant<int, 0>{});
+    else commit(std::integral_constant<int, SPLIT - 1>{});
+    if (do_bias) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        for (int i = tid; i < BCO; i += NT) red[i] = 0.0f;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(&red[dy_cu * 8 + e], bsum[e]);
+        __syncthreads();
+        for (int i = tid; i < BCO; i += NT)
+            if (co0 + i < p.Cout) atomicAdd(p.dbias + co0 + i, red[i]);
+    }
+}
+
+#ifndef MAS_WGRAD_TR_BCI
+#define MAS_WGRAD_TR_BCI 64
+#endif
+template <int KS>
+int launch_tr(WgradParams p, hipStream_t s) {
+    constexpr int BCI_ = MAS_WGRAD_TR_BCI;
+    using G = TrGeo<KS, BCI_>;
+    auto kern = conv_wgrad_tr_kernel<KS, BCI_>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess)
+            MAS_FAIL(MAS_ELAUNCH, "conv_wgrad_tr: cannot set dynamic LDS size %zu", (size_t)G::LDS_BYTES);
+        attr_done = true;
+    }
+    p.tiles_h = mas_cdiv(p.Ho, G::THW); p.tiles_w = mas_cdiv(p.Wo, TWW);
+    p.n_pt = p.N * p.tiles_h * p.tiles_w;
+    p.n_co_t = mas_cdiv(p.Cout, BCO); p.n_ci_t = mas_cdiv(p.Cin, BCI_);
+    const int out_tiles = p.n_co_t * p.n_ci_t;
+    int nsplit = mas_cdiv(mas_num_cus(), out_tiles);
+    if (nsplit > p.n_pt) nsplit = p.n_pt;
+    if (nsplit < 1) nsplit = 1;
+    p.nsplit = nsplit;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(out_tiles * nsplit)), dim3(G::NT), G::LDS_BYTES, s, p);
+    MAS_CHECK_LAUNCH("conv_wgrad_tr");
+    return MAS_OK;
+}
+
 template <typename T, int KS, int STRIDE, int THW>
 int launch(WgradParams p, hipStream_t s) {
     using G = WGeo<T, KS, STRIDE, THW>;
@@ -519,6 +761,12 @@ int launch(WgradParams p, hipStream_t s) {
 
 template <typename T>
 int launch_t(const WgradParams& p, int ks, int stride, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        if (stride == 1 && (p.Cout % 8) == 0 && (p.Cin % 8) == 0 && !getenv("MAS_WGRAD_NO_TR")) {
+            if (ks == 3) return launch_tr<3>(p, s);
+            if (ks == 1) return launch_tr<1>(p, s);
+        }
+    }
     if (ks == 1 && stride == 1) return launch<T, 1, 1, 8>(p, s);
     if (ks == 3 && stride == 1) return launch<T, 3, 1, 8>(p, s);
     if (ks == 3 && stride == 2) return launch<T, 3, 2, 4>(p, s);

@@ -71,6 +71,19 @@ def main():
         da = torch.randn_like(x)
         ms = timeit(lambda: ops.gn_bwd(x, da, None, 32, a.act or 2, g, mr, ss), a.iters)
         print(f"gn_bwd n={n} c={c} hw={h}: {ms:.4f} ms  {5*x.numel()*esz/ms/1e6:.1f} GB/s (2 reads x2 + 1 write)")
+    elif a.kind == "attn":
+        b, h, sq, hd = a.n, 16, a.hw if a.hw != 256 else 1536, 64
+        qkv = torch.randn(b, sq, 3 * h * hd, device=dev).to(dt).requires_grad_(True)
+        ops.set_compute_dtype(dt)
+        fl = 4.0 * b * h * sq * sq * hd / 2          # causal: half of the full S x S products
+        ms = timeit(lambda: ops.causal_attention(qkv.detach(), h), a.iters)
+        print(f"attn fwd B={b} H={h} S={sq} hd={hd} {a.dtype}: {ms:.4f} ms  {fl/ms/1e9:.1f} TFLOP/s (causal FLOPs)")
+        go = torch.randn(b, sq, h * hd, device=dev).to(dt)
+        def fb():
+            qkv.grad = None
+            ops.causal_attention(qkv, h).backward(go)
+        ms2 = timeit(fb, a.iters)
+        print(f"attn fwd+bwd: {ms2:.4f} ms  {3.5*fl/ms2/1e9:.1f} TFLOP/s (fwd 1x + bwd 2.5x causal FLOPs)")
     elif a.kind == "vq":
         z = torch.randn(n, 256, 16, 16, device=dev).contiguous(memory_format=torch.channels_last)
         cb = torch.randn(8192, 256, device=dev)
