@@ -36,11 +36,12 @@ struct ConvParams {
 };
 
 constexpr int TW = 16;
-// BIG = 512 threads / 16x16-pixel tile (weights fetched once per 256 pixels); otherwise 256 threads / 8x16
+// BIG = 0: 256 threads / 8x16-pixel tile, 2 work-groups per CU; 1: 512 threads / 16x16 (weights fetched once per 256
+// pixels), 1 per CU; 2: 512 threads / 32x16, each wave a 64(cout) x 128(pixel) block (0.75 LDS reads per MFMA)
 
-template <typename T, int KS, int STRIDE, bool BIG>
+template <typename T, int KS, int STRIDE, int BIG>
 struct Geo {
-    static constexpr int TH = BIG ? 16 : 8, NT = BIG ? 512 : 256;
+    static constexpr int TH = BIG == 2 ? 32 : (BIG ? 16 : 8), NT = BIG ? 512 : 256;
     static constexpr int EPU = 16 / (int)sizeof(T);          // elements per 16-byte slot
     static constexpr int CK = 128 / (int)sizeof(T);          // channels per chunk (one 128-byte pixel row)
     static constexpr int PH = (TH - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
@@ -48,7 +49,7 @@ struct Geo {
     static constexpr int PATCH_BYTES = PH * PWL * 128;
     static constexpr int P_UNITS = PH * PWL * 8;             // 16-byte slots in the patch
     static constexpr int NPU = (P_UNITS + NT - 1) / NT;      // slots per thread
-    static constexpr int PB = NPU < 6 ? NPU : 6;             // slots per staging batch (registers)
+    static constexpr int PB = (BIG == 2 && NPU <= 10) ? NPU : (NPU < 6 ? NPU : 6);   // slots per staging batch (registers)
 };
 
 // 8 consecutive K elements of one 128-byte row whose 16-byte slots are XOR-swizzled with h
@@ -67,7 +68,7 @@ __device__ __forceinline__ f32x8 ld_frag<float>(const unsigned char* row, int h,
     return r;
 }
 
-template <typename T, typename TO, int KS, int STRIDE, int BC, int WC, bool VEC, bool BIG>
+template <typename T, typename TO, int KS, int STRIDE, int BC, int WC, bool VEC, int BIG>
 __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_fwd_kernel(ConvParams p) {
     using G = Geo<T, KS, STRIDE, BIG>;
     constexpr int TH = G::TH, NT = G::NT, NWAVE = NT / 64;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_fwd_kernel(ConvParams
     constexpr int NTAP = KS * KS;
     // weight stage = TPS consecutive taps staged (and barrier-synchronised) together: the measured cost of a
     // work-group barrier is ~650 cycles of wave skew, so the big tile amortises it over 48 MFMAs instead of 16
-    constexpr int TPS = (BIG && KS == 3) ? 3 : 1;
+    constexpr int TPS = (BIG == 1 && KS == 3) ? 3 : 1;
     constexpr int NSTAGE = NTAP / TPS;
     constexpr bool PREFETCH = VEC && (NPU <= PB);   // whole chunk fits one register batch -> issue early / write late
     constexpr int PPT = (NPU + NSTAGE - 1) / NSTAGE;   // prefetch slots issued per stage
@@ -458,13 +459,13 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_fwd_kernel(ConvParams
     }
 }
 
-template <typename T, typename TO, int KS, int STRIDE, int BC, int WC, bool VEC, bool BIG>
+template <typename T, typename TO, int KS, int STRIDE, int BC, int WC, bool VEC, int BIG>
 int launch_v(const ConvParams& p0, hipStream_t s) {
     using G = Geo<T, KS, STRIDE, BIG>;
     constexpr int NT = G::NT;
     ConvParams p = p0;
     p.tiles_h = mas_cdiv(p.Ho, G::TH); p.tiles_w = mas_cdiv(p.Wo, TW);
-    constexpr int TPS = (BIG && KS == 3) ? 3 : 1;
+    constexpr int TPS = (BIG == 1 && KS == 3) ? 3 : 1;
     size_t lds = (size_t)G::PATCH_BYTES + 2 * TPS * BC * 128;
     if (const char* e = getenv("MAS_CONV_LDS_PAD")) lds += (size_t)atoi(e);   // experiment: lower residency
     auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, BC, WC, VEC, BIG>;
@@ -492,11 +493,15 @@ int launch(const ConvParams& p, hipStream_t s) {
         if constexpr (KS == 3 && STRIDE == 1 && BC == 128 && sizeof(T) == 2) {
             // 16x16 tiles when they still fill the chip at one (8-wave) work-group per CU
             const long long big_tiles = (long long)p.N * mas_cdiv(p.Ho, 16) * mas_cdiv(p.Wo, TW) * mas_cdiv(p.Cout, BC);
-            if (big_tiles >= 2LL * mas_num_cus() && !getenv("MAS_CONV_SMALL_TILE")) return launch_v<T, TO, KS, STRIDE, BC, WC, true, true>(p, s);
+            const long long huge_tiles = (long long)p.N * mas_cdiv(p.Ho, 32) * mas_cdiv(p.Wo, TW) * mas_cdiv(p.Cout, BC);
+            const char* force = getenv("MAS_CONV_TILE");   // experiments: 0 / 1 / 2
+            (void)huge_tiles;   // level 2 spills today (acc 128 + prefetch 40 + fragments 48 VGPRs): experiment only
+            if (force && atoi(force) == 2) return launch_v<T, TO, KS, STRIDE, BC, WC, true, 2>(p, s);
+            if (force ? atoi(force) == 1 : (big_tiles >= 2LL * mas_num_cus())) return launch_v<T, TO, KS, STRIDE, BC, WC, true, 1>(p, s);
         }
-        return launch_v<T, TO, KS, STRIDE, BC, WC, true, false>(p, s);
+        return launch_v<T, TO, KS, STRIDE, BC, WC, true, 0>(p, s);
     }
-    return launch_v<T, TO, KS, STRIDE, BC, WC, false, false>(p, s);
+    return launch_v<T, TO, KS, STRIDE, BC, WC, false, 0>(p, s);
 }
 
 template <typename T, typename TO, int KS, int STRIDE>
