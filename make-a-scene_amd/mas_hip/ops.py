@@ -265,6 +265,21 @@ def norm_act_conv(x, weight, bias, gn_w=None, gn_b=None, residual=None, *, strid
                upsample=bool(upsample), groups=groups, eps=eps, in_dtype=cd, out_dtype=out_dtype or cd)
     if cfg["in_dtype"] == torch.float32 and cfg["out_dtype"] != torch.float32:
         raise RuntimeError("conv: fp32 input requires fp32 output")
+    # Channel counts that are not a multiple of one 16-byte slot (RGB in/out, the 159 VQ-SEG classes) would take the
+    # kernels' element-wise loaders; zero-padding the channel axis (differentiable torch ops on tiny tensors; the padded
+    # weights are exactly zero-gradient-free slices) keeps every launch on the vectorised / transpose-read paths.
+    epu = 8 if cd == torch.bfloat16 else 4
+    cout, cin = weight.shape[0], weight.shape[1]
+    if act == ACT_NONE and cin % epu:
+        padc = epu - cin % epu
+        x = torch.nn.functional.pad(nhwc(x, cd), (0, 0, 0, 0, 0, padc))
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, padc))
+    if cout % epu and residual is None:
+        padc = epu - cout % epu
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, padc))
+        if bias is not None:
+            bias = torch.nn.functional.pad(bias, (0, padc))
+        return _NormActConv.apply(x, weight, bias, gn_w, gn_b, residual, cfg)[:, :cout]
     return _NormActConv.apply(x, weight, bias, gn_w, gn_b, residual, cfg)
 
 
