@@ -283,6 +283,57 @@ def norm_act_conv(x, weight, bias, gn_w=None, gn_b=None, residual=None, *, strid
     return _NormActConv.apply(x, weight, bias, gn_w, gn_b, residual, cfg)
 
 
+class _ResBlock(torch.autograd.Function):
+    """x + conv2(silu(gn2(conv1(silu(gn1(x))))))  for Cin == Cout (reference ResnetBlock.forward, models/modules.py:119-136)
+    as ONE autograd node: same kernels as two ``_NormActConv`` calls, but the backward hands the skip-connection gradient
+    to the GroupNorm-backward kernel of norm1 (``dres``), so the two gradient branches of x are summed inside that
+    streaming pass instead of by a separate elementwise add over the full activation."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, groups, eps, cd):
+        _require_cuda(x, "resblock")
+        x = nhwc(x, cd)
+        n, c, h, w = x.shape
+        f32 = lambda t: t.detach().float()
+        mr1, ss1 = gn_stats(x, f32(n1w), f32(n1b), groups, eps)
+        hh = conv_fwd_raw(x, ss1, _pack_cache.get(c1w, False, cd), f32(c1b), None, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU, False, cd)
+        mr2, ss2 = gn_stats(hh, f32(n2w), f32(n2b), groups, eps)
+        y = conv_fwd_raw(hh, ss2, _pack_cache.get(c2w, False, cd), f32(c2b), x, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU, False, cd)
+        ctx.groups, ctx.cd = groups, cd
+        ctx.save_for_backward(x, hh, mr1, ss1, mr2, ss2, n1w, c1w, n2w, c2w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, hh, mr1, ss1, mr2, ss2, n1w, c1w, n2w, c2w = ctx.saved_tensors
+        cd, groups = ctx.cd, ctx.groups
+        n, c, h, w = x.shape
+        dy = nhwc(dy, cd)
+        ng = ctx.needs_input_grad
+        geo = (n, h, w, c, h, w, c, 3, 1, 1, 1)
+        # conv2 / norm2
+        dw2 = db2 = dw1 = db1 = None
+        if ng[7] or ng[8]:
+            dw2, db2 = conv_wgrad_raw(hh, ss2, dy, *geo, ACT_AFFINE_SILU, False, True)
+        da2 = conv_fwd_raw(dy, None, _pack_cache.get(c2w, True, cd), None, None, *geo, ACT_NONE, False, cd)
+        dh, dg2w, dg2b = gn_bwd(hh, da2, None, groups, ACT_AFFINE_SILU, n2w.detach().float(), mr2, ss2)
+        # conv1 / norm1 (+ the skip connection's gradient, fused into the GroupNorm-backward apply pass)
+        if ng[3] or ng[4]:
+            dw1, db1 = conv_wgrad_raw(x, ss1, dh, *geo, ACT_AFFINE_SILU, False, True)
+        dx = dg1w = dg1b = None
+        if ng[0] or ng[1] or ng[2]:
+            da1 = conv_fwd_raw(dh, None, _pack_cache.get(c1w, True, cd), None, None, *geo, ACT_NONE, False, cd)
+            dx, dg1w, dg1b = gn_bwd(x, da1, dy, groups, ACT_AFFINE_SILU, n1w.detach().float(), mr1, ss1)
+        cast = lambda g, ref: g.to(ref.dtype) if g is not None else None
+        return (dx, cast(dg1w, n1w), cast(dg1b, n1w), cast(dw1, c1w), cast(db1, c1w), cast(dg2w, n2w), cast(dg2b, n2w),
+                cast(dw2, c2w), cast(db2, c2w), None, None, None)
+
+
+def resblock(x, norm1, conv1, norm2, conv2):
+    return _ResBlock.apply(x, norm1.weight, norm1.bias, conv1.weight, conv1.bias, norm2.weight, norm2.bias, conv2.weight,
+                           conv2.bias, norm1.num_groups, norm1.eps, compute_dtype())
+
+
 # --------------------------------------------------------------------------- #
 # vector quantiser
 # --------------------------------------------------------------------------- #

@@ -128,6 +128,9 @@ class ResnetBlock(nn.Module):
     def forward(self, x):
         if self.training and self.dropout.p > 0:
             raise NotImplementedError("dropout > 0 is off the hot path (the reference always builds blocks with dropout=0.0)")
+        if self.in_channels == self.out_channels and self.conv1.in_dtype is None and self.conv2.out_dtype is None \
+                and self.conv1.bias is not None and self.conv2.bias is not None:
+            return ops.resblock(x, self.norm1, self.conv1, self.norm2, self.conv2)     # one autograd node (fused skip gradient)
         h = self.conv1.fused(x, self.norm1, ACT_AFFINE_SILU)
         if self.in_channels != self.out_channels:
             x = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x)
