@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE config: 32)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dp", default="mas", choices=["mas", "ddp"],
+                    help="N>1 gradient averaging: mas_hip.dp.GradReducer (default) or torch DistributedDataParallel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-batch", type=int, default=1)
     return ap.parse_args()
@@ -111,8 +113,10 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    ddp = world > 1 or os.environ.get("MAS_BENCH_FORCE_DDP") == "1"     # the env knob exercises the N>1 code path on one GPU
+    if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
 
     from mas_hip import ops
@@ -126,9 +130,12 @@ def main():
         model.quantize.embedding.weight.normal_(0.0, 1.0)
     model = model.to(dev).train()
     model.quantize.q_counter = model.quantize.q_re_end      # steady state: VQ lookup on the path, no warm-up bypass
-    net = model
-    if world > 1:
+    net, reducer = model, None
+    if ddp and args.dp == "ddp":                            # the reference's wrapper (train.py:31-34)
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True)
+    elif ddp:                                               # same semantics, 3 flat buckets instead of 345 per-parameter copies
+        from mas_hip.dp import GradReducer
+        reducer = GradReducer(model.parameters())
     opt = torch.optim.Adam(model.parameters(), lr=5e-6, betas=(0.5, 0.9), fused=True)   # conf/img_config.yaml:36-41
 
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)          # distinct data per rank
@@ -155,6 +162,8 @@ def main():
         rec, q = net(x)
         loss = (x - rec).abs().mean() + q
         loss.backward()
+        if reducer is not None:
+            reducer.finish()
         opt.step()
         opt.zero_grad(set_to_none=True)
         return loss
@@ -162,7 +171,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if ddp:
         dist.barrier()
     torch.cuda.synchronize()
     dom["on"] = True
@@ -170,13 +179,13 @@ def main():
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if ddp:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dom["on"] = False
     ops.set_launch_hook(None)
-    if world > 1:
+    if ddp:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -191,7 +200,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "VQ-IMG 256x256, codebook 8192x256, conf/img_config.yaml model block (95.2 M params), "
                                    "fwd+bwd of L1+q_loss + Adam step", "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}" + (" (DDP bucketed RCCL all-reduce + SyncBatchNorm)" if world > 1 else "")},
+                       "parallelism": f"dp{world}" + ((" (DistributedDataParallel" if args.dp == "ddp" else " (mas_hip.dp.GradReducer: 128 MiB flat buckets,")
+                                                       + " RCCL all-reduce overlapped with backward + SyncBatchNorm)" if ddp else "")},
             "final_loss": round(final_loss, 5),
             "model_tflops_per_gpu": round(value / world * FWD_BWD_GFLOP_PER_IMG / 1e3, 1),
         }
@@ -210,11 +220,37 @@ def main():
                                "algorithmic_gflop_per_launch": round(flops / 1e9, 1),
                                "algorithmic_hbm_gbs": round(bytes_ / (avg_ms * 1e-3) / 1e9, 1),
                                "hbm_frac": round(bytes_ / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        out["encoder_stack"] = _encoder_stack(model, x, args.batch, args.dtype)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if ddp:
         dist.destroy_process_group()
+
+
+def _encoder_stack(model, x, batch, dtype):
+    """The north_star's own target line: the fused conv+GN+SiLU encoder stack (forward) against the
+    HBM and MFMA rooflines, from SURVEY.md section 8(d)'s per-image figures (152.34 Melem of
+    algorithmic traffic, 152.19 GFLOP).  Timed after the bench region, outside `value`."""
+    esz = 2 if dtype == "bf16" else 4
+    with torch.no_grad():
+        for _ in range(2):
+            model.encoder(x)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            model.encoder(x)
+        e1.record()
+        e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    gbs = 152.34e6 * esz * batch / (ms * 1e-3) / 1e9
+    tfs = 152.19e9 * batch / (ms * 1e-3) / 1e12
+    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else 157.3
+    return {"what": "Encoder.forward, all 23 layers, batch %d" % batch, "fwd_ms": round(ms, 3),
+            "algorithmic_hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
+            "tflops": round(tfs, 1), "mfma_frac": round(tfs / peak, 4), "binding_bound": "mfma",
+            "north_star_target_hbm_frac": 0.40}
 
 
 def _pmc_traffic():

@@ -647,6 +647,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgradParams p) {
         issue((pt + p.nsplit < p.n_pt) ? pt + p.nsplit : pt);     // next tile's dY (a harmless re-read at the end)
         auto mfma_phase = [&](auto HALF) {
             constexpr int LO = decltype(HALF)::value * TPH, HI = (LO + TPH < NTAP) ? LO + TPH : NTAP;
+            bf16x8 aw[KS];                           // sliding window of dY rows: row rr lives in aw[rr % KS] for KS patch rows
 #pragma unroll
             for (int pr = 0; pr < PH; ++pr) {
                 bf16x8 bf[KS];
@@ -662,17 +663,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgradParams p) {
                     const unsigned char* b0 = b_lane + (pr * PW + kw) * RSX;    // patch pixels (pr, kw + 8g + j)
                     bf[kw] = tr_frag(b0, b0 + 4 * RSX);
                 }
+                if (pr < THW) {
+                    const unsigned char* a0 = a_lane + (pr * 16) * RSY;          // dY pixels (pr, 8g + j)
+                    aw[pr % KS] = tr_frag(a0, a0 + 4 * RSY);
+                }
 #pragma unroll
                 for (int kh = 0; kh < KS; ++kh) {
                     const int rr = pr - kh;
                     if (rr < 0 || rr >= THW) continue;
                     if (kh * KS + KS <= LO || kh * KS >= HI) continue;
-                    const unsigned char* a0 = a_lane + (rr * 16) * RSY;          // dY pixels (rr, 8g + j)
-                    const bf16x8 af = tr_frag(a0, a0 + 4 * RSY);
 #pragma unroll
                     for (int kw = 0; kw < KS; ++kw) {
                         const int tap = kh * KS + kw;
-                        if (tap >= LO && tap < HI) mma16(acc[tap - LO], af, bf[kw]);
+                        if (tap >= LO && tap < HI) mma16(acc[tap - LO], aw[rr % KS], bf[kw]);
                     }
                 }
             }

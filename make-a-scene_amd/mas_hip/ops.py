@@ -149,8 +149,10 @@ def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stri
 
 
 def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, upsample, want_bias):
-    dw = torch.zeros((cout, ks, ks, cin), dtype=torch.float32, device=x.device)
-    db = torch.zeros(cout, dtype=torch.float32, device=x.device) if want_bias else None
+    nw = cout * ks * ks * cin                       # dw and db share one zero-filled allocation (one fill launch)
+    acc = torch.zeros(nw + (cout if want_bias else 0), dtype=torch.float32, device=x.device)
+    dw = acc[:nw].view(cout, ks, ks, cin)
+    db = acc[nw:] if want_bias else None
     d = _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, x.dtype, x.dtype, act, upsample)
 
     def launch():

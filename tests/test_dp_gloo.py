@@ -112,3 +112,70 @@ def test_two_rank_data_parallel_equals_full_batch(tmp_path):
             assert np.abs(got[k] - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-6, k   # conv biases in front of a GroupNorm have analytically zero gradient
             checked += 1
     assert checked > 40
+
+
+# --------------------------------------------------------------------------------------------------------
+# mas_hip.dp.GradReducer (the bucketed reducer bench.py uses for --gpus N): 2 gloo ranks == full batch
+# --------------------------------------------------------------------------------------------------------
+def _toy():
+    torch.manual_seed(7)
+    net = torch.nn.Sequential(torch.nn.Linear(12, 20), torch.nn.Tanh(), torch.nn.Linear(20, 20), torch.nn.Tanh(),
+                              torch.nn.Linear(20, 3))
+    net.unused = torch.nn.Parameter(torch.ones(5))                   # never receives a gradient
+    return net, torch.randn(8, 12), torch.randn(8, 3)
+
+
+def _reducer_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    sys.path.insert(0, os.path.join(ROOT, "make-a-scene_amd"))
+    from mas_hip.dp import GradReducer
+    net, x, y = _toy()
+    if rank == 1:                                                     # construction must broadcast rank 0's values
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)
+    red = GradReducer(net.parameters(), bucket_bytes=1200)            # several buckets, one of them closed only by finish()
+    assert len(red.buckets) >= 3
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    res = {}
+    for step, to_none in enumerate((True, False, False)):              # both zero_grad modes; views survive re-use
+        ((net(xs) - ys) ** 2).mean().backward()
+        red.finish()
+        for k, p in net.named_parameters():
+            res[f"s{step}.{k}"] = p.grad.clone().numpy()
+        with torch.no_grad():
+            for p in net.parameters():
+                p.sub_(0.1 * p.grad)                                  # plain SGD so step 1/2 gradients depend on step 0's reduction
+        for p in net.parameters():
+            if to_none:
+                p.grad = None
+            else:
+                p.grad.zero_()
+    if rank == 0:
+        np.savez(out, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_two_ranks_equals_full_batch(tmp_path):
+    if not dist.is_gloo_available():
+        pytest.skip("gloo unavailable")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "red.npz")
+    mp.spawn(_reducer_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    net, x, y = _toy()
+    for step in range(3):
+        net.zero_grad(set_to_none=True)
+        ((net(x) - y) ** 2).mean().backward()                         # mean over the full batch == average of the shard means
+        for k, p in net.named_parameters():
+            ref = p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+            assert np.allclose(got[f"s{step}.{k}"], ref, rtol=1e-5, atol=1e-6), (step, k)
+        with torch.no_grad():
+            for p in net.parameters():
+                if p.grad is not None:
+                    p.sub_(0.1 * p.grad)

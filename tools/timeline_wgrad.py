@@ -17,8 +17,13 @@ for _ in range(3):
     ops.conv_wgrad_raw(x, ss, dy, n, h, h, c, h, h, c, 3, 1, 1, 1, act, False, True)
 torch.cuda.synchronize()
 d = dbg.cpu().view(4, 8, 8).double()
-names = ["tile top", "barrier0 released", "dY staged", "A staged", "barrier1 released", "MFMA issued"]
+if os.environ.get("MAS_WGRAD_NO_TR"):
+    names = ["tile top", "barrier0 released", "dY staged", "A staged", "barrier1 released", "MFMA issued"]
+else:       # transpose-read kernel: two LDS stages, one barrier per tile
+    names = ["tile top", "next loads issued", "MFMA issued", "next tile staged", "barrier released"]
 for it in range(1, 4):
     t0 = d[it, :, 0].min()
-    print(f"tile {it}: " + "  ".join(f"{names[k]}={int(d[it, :, k].mean() - t0)}" for k in range(6)) +
+    print(f"tile {it}: " + "  ".join(f"{names[k]}={int(d[it, :, k].mean() - t0)}" for k in range(len(names))) +
           f"   next tile top={int(d[it + 1, :, 0].mean() - t0) if it < 3 else -1}")
+    for wv in range(8):
+        print("     wave", wv, [int(d[it, wv, k] - t0) for k in range(len(names))])
