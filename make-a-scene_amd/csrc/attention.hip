@@ -13,6 +13,8 @@
 // fp32 online softmax (running max / sum per query), bf16 or exact-fp32 MFMA operands (template T).
 #include "mas_common.h"
 #include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -159,6 +161,216 @@ __global__ __launch_bounds__(NT) void attn_causal_fwd_kernel(AttnParams p) {
             }
         if (p.lse && g == 0) p.lse[((size_t)b * p.H + h) * p.S + query] = m + __logf(l);
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// bf16 fast path of the forward (head_dim 64 / 128, 16-byte aligned rows): same "swapped" products, but
+//   * 64-key tiles, two LDS stages: the next tile's K / V rows are in flight in registers (16-byte coalesced
+//     global loads) across the whole compute phase and stored to the other stage afterwards -- one barrier per tile;
+//   * K and V are both staged in their natural [key][head_dim] layout; the V^T operand of O^T += V^T P^T is fetched
+//     with the LDS transpose read (ds_read_b64_tr_b16; semantics in conv_wgrad.hip), whose per-lane addresses
+//     also absorb the accumulator-order key permutation key(t,g,j) = 16t + 8(j>>2) + 4g + (j&3);
+//   * exp2 softmax (scale*log2(e) folded into one FMA), masking only on tiles that touch the diagonal or S;
+//   * heaviest (last) query blocks are launched first.
+// Row strides: K 2*HD+16 B (16 consecutive keys x 16 B tile the 64 banks for ds_read_b128), V 2*HD+64 B (4
+// consecutive keys x 64 B tile the 256-byte bank row for the transpose read).
+typedef __attribute__((ext_vector_type(4))) short fa_s16x4;
+__device__ __forceinline__ bf16x8 fa_tr_frag(const unsigned char* a0, const unsigned char* a1) {
+    const fa_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fa_s16x4*)a0);
+    const fa_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fa_s16x4*)a1);
+    const __attribute__((ext_vector_type(8))) short v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return *reinterpret_cast<const bf16x8*>(&v);
+}
+
+// value of the lane 32 away (the other half of an MFMA column), through v_permlane32_swap: no LDS round trip
+__device__ __forceinline__ float fa_other_half(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);    // r[0] = {lo, lo}, r[1] = {hi, hi}
+    const unsigned lo = r[0], hi = r[1];
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? lo : hi);
+}
+typedef __attribute__((ext_vector_type(2))) float fa_f32x2;
+
+template <int HD>
+struct FaGeo {
+    static constexpr int KT2 = 64, RSK = HD * 2 + 16, RSV = HD * 2 + 64;
+    static constexpr int K_BYTES = KT2 * RSK, STAGE = KT2 * (RSK + RSV);
+    static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE;
+};
+
+template <int HD>
+__global__ __launch_bounds__(NT, 2) void attn_causal_fwd_bf16_kernel(AttnParams p) {
+    using T = bf16_t;
+    using G = FaGeo<HD>;
+    constexpr int KT2 = G::KT2, RSK = G::RSK, RSV = G::RSV, NKK = HD / 16, NMI = HD / 32;
+    constexpr int UPR = HD / 8;                      // 16-byte slots per row
+    constexpr int SPT = KT2 * UPR / NT;              // slots per thread and tensor: 2 (HD 64) / 4 (HD 128)
+    extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-level branches stay branches
+    const int g = lane >> 5, l31 = lane & 31, G16 = (lane >> 4) & 1, sl = lane & 15;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * QT;     // heavy blocks first
+    const int qw = q0 + wave * 32, query = qw + l31;
+
+    const T* __restrict__ Q = reinterpret_cast<const T*>(p.q) + (size_t)b * p.q_bs + (size_t)h * HD;
+    const T* __restrict__ K = reinterpret_cast<const T*>(p.k) + (size_t)b * p.k_bs + (size_t)h * HD;
+    const T* __restrict__ V = reinterpret_cast<const T*>(p.v) + (size_t)b * p.v_bs + (size_t)h * HD;
+
+    bf16x8 qf[NKK];                                  // Q^T fragments (B operand): lane = query, 8 consecutive head dims
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        u32x4 raw = u32x4{0u, 0u, 0u, 0u};
+        if (query < p.S) raw = *reinterpret_cast<const u32x4*>(Q + (size_t)query * p.ld_q + kk * 16 + g * 8);
+        qf[kk] = *reinterpret_cast<const bf16x8*>(&raw);
+    }
+    f32x16 oacc[NMI];
+#pragma unroll
+    for (int i = 0; i < NMI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.0f;
+    float m = -1e30f, l = 0.0f;                      // running max (log2 domain) and sum per query
+    const float c2 = p.scale * 1.4426950408889634f;
+
+    u32x4 rk[SPT], rv[SPT];
+    auto issue = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int u = tid + i * NT, key = k0 + u / UPR, cu = u % UPR;
+            const bool ok = key < p.S;
+            const size_t row = ok ? (size_t)key : 0;
+            rk[i] = *reinterpret_cast<const u32x4*>(K + row * p.ld_k + cu * 8);
+            rv[i] = *reinterpret_cast<const u32x4*>(V + row * p.ld_v + cu * 8);
+            if (!ok) { rk[i] = u32x4{0u, 0u, 0u, 0u}; rv[i] = u32x4{0u, 0u, 0u, 0u}; }
+        }
+    };
+    auto commit = [&](unsigned char* stage) {
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int u = tid + i * NT, key = u / UPR, cu = u % UPR;
+            *reinterpret_cast<u32x4*>(stage + key * RSK + cu * 16) = rk[i];
+            *reinterpret_cast<u32x4*>(stage + G::K_BYTES + key * RSV + cu * 16) = rv[i];
+        }
+    };
+
+    const int q_last = min(q0 + QT, p.S) - 1;        // keys beyond the work-group's last query are never needed
+    const int n_tiles = q_last / KT2 + 1;
+    issue(0);
+    commit(fa_smem);
+    __syncthreads();
+    int cur = 0;
+    for (int it = 0; it < n_tiles; ++it) {
+        const int k0 = it * KT2;
+        const bool more = it + 1 < n_tiles;
+        if (more) issue(k0 + KT2);
+        if (k0 <= qw + 31) {                         // wave-uniform: otherwise the tile is entirely above this wave's diagonal
+            const unsigned char* kt = fa_smem + cur * G::STAGE;
+            const unsigned char* vt = kt + G::K_BYTES;
+            f32x16 s[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[sub][r] = 0.0f;
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + (sub * 32 + l31) * RSK + kk * 32 + g * 16);
+                    mma16(s[sub], kf, qf[kk]);
+                }
+            }
+            // softmax in the log2 domain: p = exp2(s*c2 - m).  c2 > 0, so the row maximum is taken on the raw scores.
+            if ((k0 + KT2 - 1 > qw) || (k0 + KT2 > p.S)) {          // tile touches the diagonal or the sequence end: mask
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = k0 + sub * 32 + acc_row(lane, r);
+                        if (!(key <= query && key < p.S)) s[sub][r] = -1e30f;
+                    }
+            }
+            float tmax = -1e30f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[sub][r]);
+            tmax = fmaxf(tmax, fa_other_half(tmax)) * c2;
+            const float m_new = fmaxf(m, tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            fa_f32x2 rs2 = fa_f32x2{0.0f, 0.0f};
+            const fa_f32x2 c22 = fa_f32x2{c2, c2}, nm2 = fa_f32x2{-m_new, -m_new};
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {                    // packed fp32 FMA / add: two scores per instruction
+                    fa_f32x2 t2 = fa_f32x2{s[sub][r], s[sub][r + 1]} * c22 + nm2;
+                    t2[0] = __builtin_amdgcn_exp2f(t2[0]);
+                    t2[1] = __builtin_amdgcn_exp2f(t2[1]);
+                    s[sub][r] = t2[0]; s[sub][r + 1] = t2[1];
+                    rs2 += t2;
+                }
+            float rsum = rs2[0] + rs2[1];
+            rsum += fa_other_half(rsum);
+            l = l * alpha + rsum;
+            m = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // the running maximum rarely moves after the first tiles
+#pragma unroll
+                for (int i = 0; i < NMI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (T)s[sub][8 * t + j];
+#pragma unroll
+                    for (int i = 0; i < NMI; ++i) {
+                        // lane s of a 16-lane group addresses key row base + (s>>2), head dims 4(s&3)..+3 of this 16-dim block
+                        const unsigned char* a0 = vt + (sub * 32 + 16 * t + 4 * g + (sl >> 2)) * RSV + (i * 32 + 16 * G16 + 4 * (sl & 3)) * 2;
+                        mma16(oacc[i], fa_tr_frag(a0, a0 + 8 * RSV), pf);
+                    }
+                }
+        }
+        if (more) commit(fa_smem + (cur ^ 1) * G::STAGE);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (query < p.S) {                               // lane = query, accumulator rows = head dims (4 consecutive per register quad)
+        const float inv = 1.0f / l;
+        T* dst = reinterpret_cast<T*>(p.o) + ((size_t)b * p.S + query) * ((size_t)p.H * HD) + (size_t)h * HD;
+#pragma unroll
+        for (int i = 0; i < NMI; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                bf16x4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = (T)(oacc[i][4 * rq + e] * inv);
+                *reinterpret_cast<bf16x4*>(dst + i * 32 + 8 * rq + 4 * g) = o4;
+            }
+        if (p.lse && g == 0) p.lse[((size_t)b * p.H + h) * p.S + query] = m * 0.6931471805599453f + __logf(l);
+    }
+}
+
+template <int HD>
+int launch_fwd_fast(const AttnParams& p, hipStream_t s) {
+    using G = FaGeo<HD>;
+    auto kern = attn_causal_fwd_bf16_kernel<HD>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess)
+            MAS_FAIL(MAS_ELAUNCH, "attn_causal_fwd: cannot set dynamic LDS size %zu", (size_t)G::LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(mas_cdiv(p.S, QT), p.B * p.H), dim3(NT), G::LDS_BYTES, s, p);
+    MAS_CHECK_LAUNCH("attn_causal_fwd");
+    return MAS_OK;
+}
+
+inline bool fa_aligned(const void* ptr, long long bs, int ld) {
+    return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && (bs % 8) == 0 && (ld % 8) == 0;
 }
 
 
@@ -403,6 +615,316 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnBwdParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16 / head_dim 64 fast path of the backward: the same two kernels (dK,dV per key block; dQ per query block, every
+// output element written exactly once, no atomics) restructured like the fast forward:
+//   * 64-row tiles of the streamed operands (Q,dO for dK/dV; K,V for dQ), two LDS stages, 16-byte coalesced global
+//     loads in flight in registers across the compute phase, one barrier per tile;
+//   * ONE natural-layout [row][64] image per operand serves both uses: row fragments (ds_read_b128, the A operand of
+//     S = Q K^T / dP = dO V^T) and transposed fragments (ds_read_b64_tr_b16, the A operand of dV^T += dO^T P,
+//     dK^T += Q^T dS, dQ^T += K^T dS^T).  Rows are 128 B with the 16-byte slot XOR-swizzled by the BIT-REVERSED
+//     (row>>1)&7: 16 rows of a ds_read_b128 group still hit 16 distinct slots, and the 4 consecutive rows of a
+//     transpose read fall in 4 distinct 64-byte bank segments -- both conflict-free without padding;
+//   * exp2 with lse*log2(e) staged per row, masking only on tiles that touch the diagonal / the sequence end.
+__device__ __forceinline__ int fa_swz(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
+__device__ __forceinline__ int fa_phys(int row, int slot) { return row * 128 + ((slot ^ fa_swz(row)) << 4); }
+
+struct FaTile {                       // one operand tile: 64 rows x 64 bf16, swizzled
+    static constexpr int BYTES = 64 * 128;
+};
+
+// 16-byte slots of a 64 x 64 tile: thread tid owns (row = u >> 3, slot = u & 7) for u = tid, tid + 256
+__device__ __forceinline__ void fa_issue_tile(const bf16_t* __restrict__ src, long long ld, int row0, int S, int tid, u32x4 (&r)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = tid + i * NT, row = row0 + (u >> 3), slot = u & 7;
+        const bool ok = row < S;
+        r[i] = *reinterpret_cast<const u32x4*>(src + (size_t)(ok ? row : 0) * ld + slot * 8);
+        if (!ok) r[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+}
+__device__ __forceinline__ void fa_commit_tile(unsigned char* tile, int tid, const u32x4 (&r)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = tid + i * NT;
+        *reinterpret_cast<u32x4*>(tile + fa_phys(u >> 3, u & 7)) = r[i];
+    }
+}
+// A operand, rows = tile rows: lane (l31 = row, g) holds 8 consecutive head dims of k-step kk
+__device__ __forceinline__ bf16x8 fa_row_frag(const unsigned char* tile, int row, int kk, int g) {
+    return *reinterpret_cast<const bf16x8*>(tile + fa_phys(row, kk * 2 + g));
+}
+// A operand, rows = head dims i*32 + l31, k = tile rows rb + {4g + 0..3, 8 + 4g + 0..3} (the accumulator-register order)
+__device__ __forceinline__ bf16x8 fa_tr_tile_frag(const unsigned char* tile, int rb, int i, int g, int G16, int sl) {
+    const int slot = i * 4 + G16 * 2 + ((sl & 3) >> 1), within = (sl & 1) * 8;
+    const int r0 = rb + 4 * g + (sl >> 2);
+    return fa_tr_frag(tile + fa_phys(r0, slot) + within, tile + fa_phys(r0 + 8, slot) + within);
+}
+
+__global__ __launch_bounds__(NT, 2) void attn_bwd_dkv_bf16_kernel(AttnBwdParams p) {
+    using T = bf16_t;
+    constexpr int HD = 64, NKK = 4, NMI = 2, QT2 = 64;
+    constexpr int STAGE = 2 * FaTile::BYTES + 2 * QT2 * (int)sizeof(float);
+    extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31, G16 = (lane >> 4) & 1, sl = lane & 15;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int k0 = blockIdx.x * QT;                 // 128 keys per work-group; block 0 is the heaviest (all queries)
+    const int kw = k0 + wave * 32, key = kw + l31;
+    const size_t head = (size_t)b * p.bs + (size_t)h * HD;
+    const T* __restrict__ Q = reinterpret_cast<const T*>(p.q) + head;
+    const T* __restrict__ K = reinterpret_cast<const T*>(p.k) + head;
+    const T* __restrict__ V = reinterpret_cast<const T*>(p.v) + head;
+    const long long g_stride = (long long)p.H * HD;
+    const T* __restrict__ G = reinterpret_cast<const T*>(p.dout) + ((size_t)b * p.S) * (size_t)g_stride + (size_t)h * HD;
+    const float* __restrict__ LSE = p.lse + ((size_t)b * p.H + h) * p.S;
+    const float* __restrict__ DEL = p.delta + ((size_t)b * p.H + h) * p.S;
+
+    bf16x8 kf[NKK], vf[NKK];                        // B operands: lane = key column, 8 consecutive head dims
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        u32x4 a = u32x4{0u, 0u, 0u, 0u}, c = a;
+        if (key < p.S) {
+            a = *reinterpret_cast<const u32x4*>(K + (size_t)key * p.ld + kk * 16 + g * 8);
+            c = *reinterpret_cast<const u32x4*>(V + (size_t)key * p.ld + kk * 16 + g * 8);
+        }
+        kf[kk] = *reinterpret_cast<const bf16x8*>(&a);
+        vf[kk] = *reinterpret_cast<const bf16x8*>(&c);
+    }
+    f32x16 dk[NMI], dv[NMI];
+#pragma unroll
+    for (int i = 0; i < NMI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[i][r] = 0.0f; dv[i][r] = 0.0f; }
+    const float c2 = p.scale * 1.4426950408889634f;
+
+    u32x4 rq[2], rg[2];
+    float rl = 0.0f, rd = 0.0f;
+    auto issue = [&](int q0) {
+        fa_issue_tile(Q, p.ld, q0, p.S, tid, rq);
+        fa_issue_tile(G, g_stride, q0, p.S, tid, rg);
+        if (tid < QT2) {
+            const bool ok = q0 + tid < p.S;
+            rl = ok ? LSE[q0 + tid] * 1.4426950408889634f : 0.0f;
+            rd = ok ? DEL[q0 + tid] : 0.0f;
+        }
+    };
+    auto commit = [&](unsigned char* st) {
+        fa_commit_tile(st, tid, rq);
+        fa_commit_tile(st + FaTile::BYTES, tid, rg);
+        if (tid < QT2) {
+            reinterpret_cast<float*>(st + 2 * FaTile::BYTES)[tid] = rl;
+            reinterpret_cast<float*>(st + 2 * FaTile::BYTES)[QT2 + tid] = rd;
+        }
+    };
+
+    const int q_start = (k0 / QT2) * QT2;           // causal: queries before the work-group's first key never see it
+    const int n_tiles = (p.S - q_start + QT2 - 1) / QT2;
+    issue(q_start);
+    commit(fa_smem);
+    __syncthreads();
+    int cur = 0;
+    for (int it = 0; it < n_tiles; ++it) {
+        const int q0 = q_start + it * QT2;
+        const bool more = it + 1 < n_tiles;
+        if (more) issue(q0 + QT2);
+        const unsigned char* qt = fa_smem + cur * STAGE;
+        const unsigned char* gt = qt + FaTile::BYTES;
+        const float* lse_s = reinterpret_cast<const float*>(qt + 2 * FaTile::BYTES);
+        const float* del_s = lse_s + QT2;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int qs = q0 + sub * 32;           // first query of this 32-row block
+            if (qs + 31 < kw) continue;             // wave-uniform: every query of the block precedes this wave's keys
+            f32x16 s, dp;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {      // rows = queries (A from LDS), columns = keys (B in registers)
+                const bf16x8 qa = fa_row_frag(qt, sub * 32 + l31, kk, g);
+                const bf16x8 ga = fa_row_frag(gt, sub * 32 + l31, kk, g);
+                if (kk == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                    s = z; dp = z;
+                }
+                mma16(s, qa, kf[kk]);
+                mma16(dp, ga, vf[kk]);
+            }
+            f32x4 l4[4], d4[4];                     // rows r = 4j..4j+3 are queries 8j + 4g + 0..3 of the block
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                l4[j] = *reinterpret_cast<const f32x4*>(lse_s + sub * 32 + 8 * j + 4 * g);
+                d4[j] = *reinterpret_cast<const f32x4*>(del_s + sub * 32 + 8 * j + 4 * g);
+            }
+            const bool needs_mask = (qs < kw + 31) || (qs + 32 > p.S) || (kw + 32 > p.S);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -l4[r >> 2][r & 3]));
+                if (needs_mask) {
+                    const int query = qs + acc_row(lane, r);
+                    if (!((key <= query) && (query < p.S) && (key < p.S))) pv = 0.0f;
+                }
+                s[r] = pv;                                           // P[query][key]
+                dp[r] = pv * (dp[r] - d4[r >> 2][r & 3]) * p.scale;  // dS[query][key]
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bf16x8 pf, sf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { pf[j] = (T)s[8 * t + j]; sf[j] = (T)dp[8 * t + j]; }
+#pragma unroll
+                for (int i = 0; i < NMI; ++i) {
+                    mma16(dv[i], fa_tr_tile_frag(gt, sub * 32 + 16 * t, i, g, G16, sl), pf);    // dV^T += dO^T P
+                    mma16(dk[i], fa_tr_tile_frag(qt, sub * 32 + 16 * t, i, g, G16, sl), sf);    // dK^T += Q^T dS
+                }
+            }
+        }
+        if (more) commit(fa_smem + (cur ^ 1) * STAGE);
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (key < p.S) {                                 // lane = key, accumulator rows = head dims (4 consecutive per register quad)
+        T* dkp = reinterpret_cast<T*>(p.dk) + head + (size_t)key * p.ld;
+        T* dvp = reinterpret_cast<T*>(p.dv) + head + (size_t)key * p.ld;
+#pragma unroll
+        for (int i = 0; i < NMI; ++i)
+#pragma unroll
+            for (int rq4 = 0; rq4 < 4; ++rq4) {
+                bf16x4 a, c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] = (T)dk[i][4 * rq4 + e]; c[e] = (T)dv[i][4 * rq4 + e]; }
+                *reinterpret_cast<bf16x4*>(dkp + i * 32 + 8 * rq4 + 4 * g) = a;
+                *reinterpret_cast<bf16x4*>(dvp + i * 32 + 8 * rq4 + 4 * g) = c;
+            }
+    }
+}
+
+__global__ __launch_bounds__(NT, 2) void attn_bwd_dq_bf16_kernel(AttnBwdParams p) {
+    using T = bf16_t;
+    constexpr int HD = 64, NKK = 4, NMI = 2, KT2 = 64;
+    constexpr int STAGE = 2 * FaTile::BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31, G16 = (lane >> 4) & 1, sl = lane & 15;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * QT;     // heavy (late) query blocks first
+    const int qw = q0 + wave * 32, query = qw + l31;
+    const size_t head = (size_t)b * p.bs + (size_t)h * HD;
+    const T* __restrict__ Q = reinterpret_cast<const T*>(p.q) + head;
+    const T* __restrict__ K = reinterpret_cast<const T*>(p.k) + head;
+    const T* __restrict__ V = reinterpret_cast<const T*>(p.v) + head;
+    const long long g_stride = (long long)p.H * HD;
+    const T* __restrict__ G = reinterpret_cast<const T*>(p.dout) + ((size_t)b * p.S) * (size_t)g_stride + (size_t)h * HD;
+
+    bf16x8 qf[NKK], gf[NKK];                        // B operands: lane = query column
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        u32x4 a = u32x4{0u, 0u, 0u, 0u}, c = a;
+        if (query < p.S) {
+            a = *reinterpret_cast<const u32x4*>(Q + (size_t)query * p.ld + kk * 16 + g * 8);
+            c = *reinterpret_cast<const u32x4*>(G + (size_t)query * g_stride + kk * 16 + g * 8);
+        }
+        qf[kk] = *reinterpret_cast<const bf16x8*>(&a);
+        gf[kk] = *reinterpret_cast<const bf16x8*>(&c);
+    }
+    const float my_lse2 = query < p.S ? p.lse[((size_t)b * p.H + h) * p.S + query] * 1.4426950408889634f : 0.0f;
+    const float my_delta = query < p.S ? p.delta[((size_t)b * p.H + h) * p.S + query] : 0.0f;
+    const float c2 = p.scale * 1.4426950408889634f;
+    f32x16 dq[NMI];
+#pragma unroll
+    for (int i = 0; i < NMI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[i][r] = 0.0f;
+
+    u32x4 rk[2], rv[2];
+    const int q_last = min(q0 + QT, p.S) - 1;
+    const int n_tiles = q_last / KT2 + 1;
+    fa_issue_tile(K, p.ld, 0, p.S, tid, rk);
+    fa_issue_tile(V, p.ld, 0, p.S, tid, rv);
+    fa_commit_tile(fa_smem, tid, rk);
+    fa_commit_tile(fa_smem + FaTile::BYTES, tid, rv);
+    __syncthreads();
+    int cur = 0;
+    for (int it = 0; it < n_tiles; ++it) {
+        const int k0 = it * KT2;
+        const bool more = it + 1 < n_tiles;
+        if (more) {
+            fa_issue_tile(K, p.ld, k0 + KT2, p.S, tid, rk);
+            fa_issue_tile(V, p.ld, k0 + KT2, p.S, tid, rv);
+        }
+        const unsigned char* kt = fa_smem + cur * STAGE;
+        const unsigned char* vt = kt + FaTile::BYTES;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int ks = k0 + sub * 32;
+            if (ks > qw + 31) continue;             // wave-uniform: block entirely above this wave's diagonal
+            f32x16 s, dp;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {      // rows = keys (A from LDS), columns = queries (B in registers)
+                const bf16x8 ka = fa_row_frag(kt, sub * 32 + l31, kk, g);
+                const bf16x8 va = fa_row_frag(vt, sub * 32 + l31, kk, g);
+                if (kk == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                    s = z; dp = z;
+                }
+                mma16(s, ka, qf[kk]);
+                mma16(dp, va, gf[kk]);
+            }
+            const bool needs_mask = (ks + 31 > qw) || (ks + 32 > p.S);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -my_lse2));
+                if (needs_mask) {
+                    const int key = ks + acc_row(lane, r);
+                    if (!((key <= query) && (key < p.S))) pv = 0.0f;
+                }
+                dp[r] = pv * (dp[r] - my_delta) * p.scale;           // dS^T[key][query]
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bf16x8 sf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sf[j] = (T)dp[8 * t + j];
+#pragma unroll
+                for (int i = 0; i < NMI; ++i) mma16(dq[i], fa_tr_tile_frag(kt, sub * 32 + 16 * t, i, g, G16, sl), sf);   // dQ^T += K^T dS^T
+            }
+        }
+        if (more) {
+            fa_commit_tile(fa_smem + (cur ^ 1) * STAGE, tid, rk);
+            fa_commit_tile(fa_smem + (cur ^ 1) * STAGE + FaTile::BYTES, tid, rv);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (query < p.S) {
+        T* dst = reinterpret_cast<T*>(p.dq) + head + (size_t)query * p.ld;
+#pragma unroll
+        for (int i = 0; i < NMI; ++i)
+#pragma unroll
+            for (int rq4 = 0; rq4 < 4; ++rq4) {
+                bf16x4 a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = (T)dq[i][4 * rq4 + e];
+                *reinterpret_cast<bf16x4*>(dst + i * 32 + 8 * rq4 + 4 * g) = a;
+            }
+    }
+}
+
+int launch_bwd_fast64(const AttnBwdParams& p, hipStream_t s) {
+    const long long rows = (long long)p.B * p.H * p.S;
+    hipLaunchKernelGGL((attn_bwd_delta_kernel<bf16_t, 64>), dim3((unsigned)((rows + NT - 1) / NT)), dim3(NT), 0, s, p);
+    const dim3 grid(mas_cdiv(p.S, QT), p.B * p.H);
+    constexpr size_t lds_dkv = 2 * (2 * FaTile::BYTES + 2 * 64 * sizeof(float)), lds_dq = 2 * (2 * FaTile::BYTES);
+    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, dim3(NT), lds_dkv, s, p);
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, dim3(NT), lds_dq, s, p);
+    MAS_CHECK_LAUNCH("attn_causal_bwd");
+    return MAS_OK;
+}
+
 template <typename T, int HD>
 int launch_bwd(const AttnBwdParams& p, hipStream_t s) {
     const long long rows = (long long)p.B * p.H * p.S;
@@ -452,7 +974,12 @@ extern "C" int mas_attn_causal_fwd(const void* q, const void* k, const void* v, 
     p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.ld_q = ld_q; p.ld_k = ld_k; p.ld_v = ld_v;
     p.B = B; p.H = H; p.S = S; p.scale = scale;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MAS_BF16) return launch_hd<bf16_t>(p, hd, s);
+    if (dtype == MAS_BF16) {
+        const bool fast = (hd == 64 || hd == 128) && fa_aligned(q, q_bs, ld_q) && fa_aligned(k, k_bs, ld_k) && fa_aligned(v, v_bs, ld_v) &&
+                          (reinterpret_cast<uintptr_t>(o) & 7) == 0 && !getenv("MAS_ATTN_GENERIC");
+        if (fast) return hd == 64 ? launch_fwd_fast<64>(p, s) : launch_fwd_fast<128>(p, s);
+        return launch_hd<bf16_t>(p, hd, s);
+    }
     if (dtype == MAS_F32) return launch_hd<float>(p, hd, s);
     MAS_FAIL(MAS_EUNSUPPORTED, "attn_causal_fwd: dtype %d", dtype);
 }
@@ -472,7 +999,11 @@ extern "C" int mas_attn_causal_bwd(const void* qkv, const void* o, const void* d
     p.o = o; p.dout = dout; p.lse = lse; p.delta = delta;
     p.ld = 3 * d; p.bs = (long long)S * 3 * d; p.B = B; p.H = H; p.S = S; p.scale = scale;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MAS_BF16) return launch_bwd_hd<bf16_t>(p, hd, s);
+    if (dtype == MAS_BF16) {
+        const bool al = ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dqkv) | reinterpret_cast<uintptr_t>(dout)) & 15) == 0 && (d % 8) == 0;
+        if (hd == 64 && al && !getenv("MAS_ATTN_GENERIC")) return launch_bwd_fast64(p, s);
+        return launch_bwd_hd<bf16_t>(p, hd, s);
+    }
     if (dtype == MAS_F32) return launch_bwd_hd<float>(p, hd, s);
     MAS_FAIL(MAS_EUNSUPPORTED, "attn_causal_bwd: dtype %d", dtype);
 }

@@ -33,7 +33,7 @@ def _restore_dtype():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 4, 24, 16), (1, 2, 200, 64), (2, 16, 1536, 64), (1, 3, 130, 32)])
+@pytest.mark.parametrize("shape", [(2, 4, 24, 16), (1, 2, 200, 64), (2, 16, 1536, 64), (1, 3, 130, 32), (2, 2, 333, 64), (1, 1, 65, 64)])
 def test_causal_attention_vs_oracle(shape, dtype):
     from mas_hip import ops
     from oracle import transformer_oracle as TO
