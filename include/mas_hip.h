@@ -142,6 +142,23 @@ int mas_upsample2x(const void* x, void* y, int dtype, int N, int H, int W, int C
 int mas_sumpool2x(const void* x, void* y, int dtype, int N, int Ho, int Wo, int C, void* stream);
 int mas_zero_stuff2x(const void* x, void* y, int dtype, int N, int H, int W, int C, int Hout, int Wout, void* stream);
 
+/* -------------------------------------------------------------------------------------------
+ * Transformer row operators (streaming, HBM-bound).
+ * mas_gelu_tanh_*: OpenAI tanh-GELU of reference models/transformer.py:11-14 (MLP.forward :129) over n elements.
+ * mas_layernorm_*: torch.nn.LayerNorm(D, eps) as used four times per TransformerLayer
+ *   (models/transformer.py:159-163,197-210), rows x D, with an optional fused residual  y = residual + LN(x)
+ *   (residual / y / dy have out_dtype; x / dx have in_dtype; gamma, beta, dgamma, dbeta fp32).
+ *   mean_rstd [rows][2] fp32 is written by the forward (may be NULL when no backward follows) and read by the
+ *   backward.  D must be a multiple of the 16-byte vector (8 for bf16->bf16, else 4) and at most 256 vectors.      */
+int mas_gelu_tanh_fwd(const void* x, void* y, int dtype, long long n, void* stream);
+int mas_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int dtype, long long n, void* stream);
+int mas_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y,
+                      float* mean_rstd, int in_dtype, int out_dtype, int rows, int D, float eps, void* stream);
+size_t mas_layernorm_bwd_workspace(int rows, int D);
+int mas_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, void* dx,
+                      float* dgamma, float* dbeta, int in_dtype, int out_dtype, int rows, int D,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,354 @@
+// Streaming (HBM-bound) row operators of the transformer layer for gfx950:
+//   * tanh-GELU forward / backward          (reference models/transformer.py:11-14, used by MLP :129)
+//   * LayerNorm(eps) forward / backward with an optional fused residual add  y = res + LN(x)
+//     (reference TransformerLayer.forward, models/transformer.py:197-210: pre-LN + sandwich-LN + residual)
+// In eager PyTorch the GELU alone is ~9 elementwise launches forward and as many backward over the
+// [B, S, 4d] tensor, and every LayerNorm is bracketed by dtype-cast copies; here each is one pass with
+// 16-byte loads/stores and fp32 arithmetic, bf16 or fp32 storage on either side.
+#include "mas_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int NT = 256;
+
+template <typename T> struct EwVec;     // 16-byte vectors
+template <> struct EwVec<float> { static constexpr int N = 4; };
+template <> struct EwVec<bf16_t> { static constexpr int N = 8; };
+
+template <typename T, int N>
+__device__ __forceinline__ void ld_vec(const T* p, float (&v)[N]) {
+    u32x4 raw = *reinterpret_cast<const u32x4*>(p);
+    const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = (float)e[i];
+}
+template <typename T, int N>
+__device__ __forceinline__ void st_vec(T* p, const float (&v)[N]) {
+    u32x4 raw;
+    T* e = reinterpret_cast<T*>(&raw);
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = (T)v[i];
+    *reinterpret_cast<u32x4*>(p) = raw;
+}
+
+// N consecutive elements (8 or 16 bytes) as floats
+template <typename T, int N>
+__device__ __forceinline__ void ld_n(const T* p, float (&v)[N]) {
+    typedef T VT __attribute__((ext_vector_type(N)));
+    const VT raw = *reinterpret_cast<const VT*>(p);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = (float)raw[i];
+}
+template <typename T, int N>
+__device__ __forceinline__ void st_n(T* p, const float (&v)[N]) {
+    typedef T VT __attribute__((ext_vector_type(N)));
+    VT raw;
+#pragma unroll
+    for (int i = 0; i < N; ++i) raw[i] = (T)v[i];
+    *reinterpret_cast<VT*>(p) = raw;
+}
+
+// tanh-GELU: y = 0.5 x (1 + tanh(u)),  u = k x (1 + c x^2);   dy/dx = 0.5 (1 + t) + 0.5 x (1 - t^2) k (1 + 3 c x^2)
+constexpr float GK = 0.7978845608028654f, GC = 0.044715f;
+template <bool EXACT>
+__device__ __forceinline__ float tanh_f(float u) {
+    if (EXACT) return tanhf(u);
+    const float e = __expf(2.0f * u);                 // 1 - 2/(1+e^{2u}); saturates correctly at +-inf
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long n) {
+    constexpr int N = EwVec<T>::N;
+    constexpr bool EXACT = sizeof(T) == 4;
+    const long long nv = n / N, stride = (long long)gridDim.x * NT;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < nv; i += stride) {
+        float v[N];
+        ld_vec<T, N>(x + i * N, v);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const float a = v[e], t = tanh_f<EXACT>(GK * a * (1.0f + GC * a * a));
+            v[e] = 0.5f * a * (1.0f + t);
+        }
+        st_vec<T, N>(y + i * N, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - nv * N)) {        // ragged tail
+        const long long i = nv * N + threadIdx.x;
+        const float a = (float)x[i], t = tanh_f<EXACT>(GK * a * (1.0f + GC * a * a));
+        y[i] = (T)(0.5f * a * (1.0f + t));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long long n) {
+    constexpr int N = EwVec<T>::N;
+    constexpr bool EXACT = sizeof(T) == 4;
+    auto grad = [](float a, float g) {
+        const float a2 = a * a, t = tanh_f<EXACT>(GK * a * (1.0f + GC * a2));
+        return g * (0.5f * (1.0f + t) + 0.5f * a * (1.0f - t * t) * GK * (1.0f + 3.0f * GC * a2));
+    };
+    const long long nv = n / N, stride = (long long)gridDim.x * NT;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < nv; i += stride) {
+        float v[N], g[N];
+        ld_vec<T, N>(x + i * N, v);
+        ld_vec<T, N>(dy + i * N, g);
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = grad(v[e], g[e]);
+        st_vec<T, N>(dx + i * N, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - nv * N)) {
+        const long long i = nv * N + threadIdx.x;
+        dx[i] = (T)grad((float)x[i], (float)dy[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm.  One wave per row; a lane owns the same columns of every row (column = (k*64 + lane)*VEC + e for
+// k < KMAX), the row lives in registers, statistics are exact two-pass (mean, then centred sum of squares) in
+// fp32 with wave-level DPP/permute reductions -- no LDS, no second read of x.
+constexpr int LN_KMAX = 4;              // D <= 64 * VEC * 4  (2048 bf16 / 1024 fp32 columns)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(NT) void layernorm_fwd_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const TO* __restrict__ res,
+                                                           TO* __restrict__ y, float* __restrict__ mean_rstd, int rows, int D, float eps) {
+    constexpr int VEC = 16 / (int)sizeof(TI) < 16 / (int)sizeof(TO) ? 16 / (int)sizeof(TI) : 16 / (int)sizeof(TO);   // common vector width
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nvec = D / VEC;
+    for (int row = blockIdx.x * (NT / 64) + wave; row < rows; row += gridDim.x * (NT / 64)) {
+        const TI* xr = x + (size_t)row * D;
+        float v[LN_KMAX][VEC];
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < LN_KMAX; ++k) {
+            const int c = k * 64 + lane;
+            if (c < nvec) {
+                ld_n<TI, VEC>(xr + c * VEC, v[k]);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s += v[k][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[k][e] = 0.0f;
+            }
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.0f;
+#pragma unroll
+        for (int k = 0; k < LN_KMAX; ++k)
+            if (k * 64 + lane < nvec)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { const float d = v[k][e] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+        if (lane == 0 && mean_rstd) { mean_rstd[2 * (size_t)row] = mean; mean_rstd[2 * (size_t)row + 1] = rstd; }
+        TO* yr = y + (size_t)row * D;
+#pragma unroll
+        for (int k = 0; k < LN_KMAX; ++k) {
+            const int c = k * 64 + lane;
+            if (c < nvec) {
+                float ga[VEC], be[VEC], o[VEC];
+                ld_n<float, VEC>(gamma + c * VEC, ga);
+                ld_n<float, VEC>(beta + c * VEC, be);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] = (v[k][e] - mean) * rstd * ga[e] + be[e];
+                if (res) {
+                    float rr[VEC];
+                    ld_n<TO, VEC>(res + (size_t)row * D + c * VEC, rr);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) o[e] += rr[e];
+                }
+                st_n<TO, VEC>(yr + c * VEC, o);
+            }
+        }
+    }
+}
+
+// backward: g = dy*gamma, xhat = (x-mean)*rstd, dx = rstd*(g - mean_D(g) - xhat*mean_D(g*xhat));
+// per-block partial sums of dgamma = sum_rows dy*xhat and dbeta = sum_rows dy: partial[blk][2][D]
+template <typename TI, typename TO>
+__global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const TI* __restrict__ x, const TO* __restrict__ dy,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                           TI* __restrict__ dx, float* __restrict__ partial, int rows, int D) {
+    constexpr int VEC = 16 / (int)sizeof(TI) < 16 / (int)sizeof(TO) ? 16 / (int)sizeof(TI) : 16 / (int)sizeof(TO);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nvec = D / VEC;
+    float ag[LN_KMAX][VEC], ab[LN_KMAX][VEC];
+#pragma unroll
+    for (int k = 0; k < LN_KMAX; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { ag[k][e] = 0.0f; ab[k][e] = 0.0f; }
+    for (int row = blockIdx.x * (NT / 64) + wave; row < rows; row += gridDim.x * (NT / 64)) {
+        const float mean = mean_rstd[2 * (size_t)row], rstd = mean_rstd[2 * (size_t)row + 1];
+        const TI* xr = x + (size_t)row * D;
+        const TO* gr = dy + (size_t)row * D;
+        float xh[LN_KMAX][VEC], g[LN_KMAX][VEC];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < LN_KMAX; ++k) {
+            const int c = k * 64 + lane;
+            if (c < nvec) {
+                float xv[VEC], dv[VEC], ga[VEC];
+                ld_n<TI, VEC>(xr + c * VEC, xv);
+                ld_n<TO, VEC>(gr + c * VEC, dv);
+                ld_n<float, VEC>(gamma + c * VEC, ga);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float d = dv[e];
+                    xh[k][e] = (xv[e] - mean) * rstd;
+                    g[k][e] = d * ga[e];
+                    s1 += g[k][e]; s2 += g[k][e] * xh[k][e];
+                    ag[k][e] += d * xh[k][e]; ab[k][e] += d;
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+        TI* dr = dx + (size_t)row * D;
+#pragma unroll
+        for (int k = 0; k < LN_KMAX; ++k) {
+            const int c = k * 64 + lane;
+            if (c < nvec) {
+                float o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] = rstd * (g[k][e] - m1 - xh[k][e] * m2);
+                st_n<TI, VEC>(dr + c * VEC, o);
+            }
+        }
+    }
+    // fixed-order reduction over the block's waves through LDS, then one partial row per block
+    __shared__ float red[(NT / 64)][2][64 * 8 + 1];            // per k: [wave][gamma|beta][lane*VEC + e]
+#pragma unroll
+    for (int k = 0; k < LN_KMAX; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { red[wave][0][lane * VEC + e] = ag[k][e]; red[wave][1][lane * VEC + e] = ab[k][e]; }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * 64 * VEC; i += NT) {
+            const int which = i / (64 * VEC), j = i % (64 * VEC);
+            const int col = k * 64 * VEC + j;
+            if (col < D) {
+                float a = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NT / 64; ++w) a += red[w][which][j];
+                partial[((size_t)blockIdx.x * 2 + which) * D + col] = a;
+            }
+        }
+    }
+}
+
+// dgamma / dbeta = fixed-order sum of the per-block partials: a block owns 32 columns, 8 row groups stride over the blocks
+__global__ __launch_bounds__(NT) void layernorm_param_reduce(const float* __restrict__ partial, int nblk, int D,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[8][2][32];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + c;
+    float a = 0.0f, b = 0.0f;
+    if (col < D)
+        for (int k = rg; k < nblk; k += 8) { a += partial[((size_t)k * 2) * D + col]; b += partial[((size_t)k * 2 + 1) * D + col]; }
+    red[rg][0][c] = a; red[rg][1][c] = b;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int which = threadIdx.x >> 5;
+        float t = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][which][c];
+        if (col < D) (which ? dbeta : dgamma)[col] = t;
+    }
+}
+
+int ln_blocks(int rows) {
+    int nb = mas_cdiv(rows, NT / 64);
+    const int cap = 4 * mas_num_cus();
+    return nb < cap ? nb : cap;
+}
+
+template <typename T>
+int gelu_launch(bool bwd, const void* x, const void* dy, void* out, long long n, hipStream_t s) {
+    constexpr int N = EwVec<T>::N;
+    long long nb = (n / N + NT - 1) / NT;
+    const long long cap = 16LL * mas_num_cus();
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    if (bwd) hipLaunchKernelGGL(gelu_bwd_kernel<T>, dim3((unsigned)nb), dim3(NT), 0, s, (const T*)x, (const T*)dy, (T*)out, n);
+    else hipLaunchKernelGGL(gelu_fwd_kernel<T>, dim3((unsigned)nb), dim3(NT), 0, s, (const T*)x, (T*)out, n);
+    MAS_CHECK_LAUNCH(bwd ? "gelu_tanh_bwd" : "gelu_tanh_fwd");
+    return MAS_OK;
+}
+
+int ln_check(int in_dtype, int out_dtype, int rows, int D, const char* what) {
+    if (rows <= 0 || D <= 0) MAS_FAIL(MAS_EINVAL, "%s: bad shape rows=%d D=%d", what, rows, D);
+    if ((in_dtype != MAS_F32 && in_dtype != MAS_BF16) || (out_dtype != MAS_F32 && out_dtype != MAS_BF16))
+        MAS_FAIL(MAS_EUNSUPPORTED, "%s: dtypes %d -> %d", what, in_dtype, out_dtype);
+    const int vec = (in_dtype == MAS_BF16 && out_dtype == MAS_BF16) ? 8 : 4;
+    if (D % vec != 0 || D > 64 * vec * LN_KMAX)
+        MAS_FAIL(MAS_EUNSUPPORTED, "%s: D=%d must be a multiple of %d and <= %d for these dtypes", what, D, vec, 64 * vec * LN_KMAX);
+    return MAS_OK;
+}
+
+}  // namespace
+
+extern "C" int mas_gelu_tanh_fwd(const void* x, void* y, int dtype, long long n, void* stream) {
+    MAS_ENTER();
+    if (!x || !y || n <= 0) MAS_FAIL(MAS_EINVAL, "gelu_tanh_fwd: null argument or n=%lld", n);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MAS_BF16) return gelu_launch<bf16_t>(false, x, nullptr, y, n, s);
+    if (dtype == MAS_F32) return gelu_launch<float>(false, x, nullptr, y, n, s);
+    MAS_FAIL(MAS_EUNSUPPORTED, "gelu_tanh_fwd: dtype %d", dtype);
+}
+
+extern "C" int mas_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int dtype, long long n, void* stream) {
+    MAS_ENTER();
+    if (!x || !dy || !dx || n <= 0) MAS_FAIL(MAS_EINVAL, "gelu_tanh_bwd: null argument or n=%lld", n);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MAS_BF16) return gelu_launch<bf16_t>(true, x, dy, dx, n, s);
+    if (dtype == MAS_F32) return gelu_launch<float>(true, x, dy, dx, n, s);
+    MAS_FAIL(MAS_EUNSUPPORTED, "gelu_tanh_bwd: dtype %d", dtype);
+}
+
+extern "C" int mas_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y,
+                                 float* mean_rstd, int in_dtype, int out_dtype, int rows, int D, float eps, void* stream) {
+    MAS_ENTER();
+    if (!x || !gamma || !beta || !y) MAS_FAIL(MAS_EINVAL, "layernorm_fwd: null argument");
+    if (int rc = ln_check(in_dtype, out_dtype, rows, D, "layernorm_fwd")) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(ln_blocks(rows)), block(NT);
+#define MAS_LN_FWD(TI, TO) hipLaunchKernelGGL((layernorm_fwd_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, gamma, beta, (const TO*)residual, (TO*)y, mean_rstd, rows, D, eps)
+    if (in_dtype == MAS_BF16 && out_dtype == MAS_BF16) MAS_LN_FWD(bf16_t, bf16_t);
+    else if (in_dtype == MAS_BF16) MAS_LN_FWD(bf16_t, float);
+    else if (out_dtype == MAS_BF16) MAS_LN_FWD(float, bf16_t);
+    else MAS_LN_FWD(float, float);
+#undef MAS_LN_FWD
+    MAS_CHECK_LAUNCH("layernorm_fwd");
+    return MAS_OK;
+}
+
+extern "C" size_t mas_layernorm_bwd_workspace(int rows, int D) {
+    if (rows <= 0 || D <= 0) return 0;
+    return (size_t)ln_blocks(rows) * 2 * (size_t)D * sizeof(float);
+}
+
+extern "C" int mas_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, void* dx,
+                                 float* dgamma, float* dbeta, int in_dtype, int out_dtype, int rows, int D,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    MAS_ENTER();
+    if (!x || !dy || !gamma || !mean_rstd || !dx || !dgamma || !dbeta || !workspace) MAS_FAIL(MAS_EINVAL, "layernorm_bwd: null argument");
+    if (int rc = ln_check(in_dtype, out_dtype, rows, D, "layernorm_bwd")) return rc;
+    if (workspace_bytes < mas_layernorm_bwd_workspace(rows, D)) MAS_FAIL(MAS_EINVAL, "layernorm_bwd: workspace too small");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nblk = ln_blocks(rows);
+    float* partial = reinterpret_cast<float*>(workspace);
+#define MAS_LN_BWD(TI, TO) hipLaunchKernelGGL((layernorm_bwd_kernel<TI, TO>), dim3(nblk), dim3(NT), 0, s, (const TI*)x, (const TO*)dy, gamma, mean_rstd, (TI*)dx, partial, rows, D)
+    if (in_dtype == MAS_BF16 && out_dtype == MAS_BF16) MAS_LN_BWD(bf16_t, bf16_t);
+    else if (in_dtype == MAS_BF16) MAS_LN_BWD(bf16_t, float);
+    else if (out_dtype == MAS_BF16) MAS_LN_BWD(float, bf16_t);
+    else MAS_LN_BWD(float, float);
+#undef MAS_LN_BWD
+    hipLaunchKernelGGL(layernorm_param_reduce, dim3(mas_cdiv(D, 32)), dim3(NT), 0, s, partial, nblk, D, dgamma, dbeta);
+    MAS_CHECK_LAUNCH("layernorm_bwd");
+    return MAS_OK;
+}

@@ -442,3 +442,93 @@ class _CausalAttention(torch.autograd.Function):
 
 def causal_attention(qkv: torch.Tensor, n_heads: int) -> torch.Tensor:
     return _CausalAttention.apply(qkv, n_heads)
+
+
+# --------------------------------------------------------------------------- #
+# transformer row operators: tanh-GELU, LayerNorm (+ fused residual)
+# --------------------------------------------------------------------------- #
+def _check_dtype(t: torch.Tensor, what: str):
+    if t.dtype not in _DT:
+        raise RuntimeError(f"{what}: dtype {t.dtype} not supported (float32 / bfloat16)")
+
+
+class _GeluTanh(torch.autograd.Function):
+    """OpenAI tanh-GELU (reference models/transformer.py:11-14), one streaming pass each way."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x, "gelu_tanh")
+        _check_dtype(x, "gelu_tanh")
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib().mas_gelu_tanh_fwd(_ptr(x), _ptr(y), _DT[x.dtype], x.numel(), _stream()), "gelu_tanh_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        check(lib().mas_gelu_tanh_bwd(_ptr(x), _ptr(dy), _ptr(dx), _DT[x.dtype], x.numel(), _stream()), "gelu_tanh_bwd")
+        return dx
+
+
+def gelu_tanh(x: torch.Tensor) -> torch.Tensor:
+    return _GeluTanh.apply(x)
+
+
+class _LayerNorm(torch.autograd.Function):
+    """y = [residual +] LayerNorm(x) over the last dimension (reference TransformerLayer, models/transformer.py:197-210).
+    x / dx have the input's dtype, y / residual / dy have ``out_dtype``; statistics and arithmetic are fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, eps, out_dtype):
+        _require_cuda(x, "layer_norm")
+        _check_dtype(x, "layer_norm")
+        d = x.shape[-1]
+        rows = x.numel() // d
+        x = x.contiguous()
+        if residual is not None:
+            if residual.shape != x.shape:
+                raise RuntimeError("layer_norm: residual shape must equal the input shape")
+            residual = residual.to(out_dtype).contiguous()
+        y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+        mr = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        check(lib().mas_layernorm_fwd(_ptr(x), _ptr(w32), _ptr(b32), _ptr(residual), _ptr(y), _ptr(mr), _DT[x.dtype],
+                                      _DT[out_dtype], rows, d, float(eps), _stream()), "layernorm_fwd")
+        ctx.save_for_backward(x, weight, mr)
+        ctx.has_res, ctx.out_dtype = residual is not None, out_dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mr = ctx.saved_tensors
+        d = x.shape[-1]
+        rows = x.numel() // d
+        dy = dy.to(ctx.out_dtype).contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.empty(d, dtype=torch.float32, device=x.device)
+        db = torch.empty(d, dtype=torch.float32, device=x.device)
+        wsb = lib().mas_layernorm_bwd_workspace(rows, d)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
+        w32 = weight.detach().float().contiguous()
+        check(lib().mas_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(w32), _ptr(mr), _ptr(dx), _ptr(dg), _ptr(db), _DT[x.dtype],
+                                      _DT[ctx.out_dtype], rows, d, _ptr(ws), wsb, _stream()), "layernorm_bwd")
+        return dx, dg.to(weight.dtype), db.to(weight.dtype), (dy if ctx.has_res else None), None, None
+
+
+def layer_norm(x, weight, bias, eps=1e-5, residual=None, out_dtype=None):
+    """``out_dtype`` None: the residual's dtype if one is given, else the autocast dtype when autocast is on (the
+    consumer is a Linear that would cast anyway), else the input's dtype."""
+    if out_dtype is None:
+        if residual is not None:
+            out_dtype = residual.dtype
+        elif torch.is_autocast_enabled():
+            out_dtype = torch.get_autocast_gpu_dtype()
+        else:
+            out_dtype = x.dtype
+    if out_dtype not in _DT:
+        raise RuntimeError(f"layer_norm: output dtype {out_dtype} not supported")
+    return _LayerNorm.apply(x, weight, bias, residual, eps, out_dtype)

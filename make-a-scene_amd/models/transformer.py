@@ -17,8 +17,18 @@ from mas_hip import ops
 
 
 def gelu(x):
-    """OpenAI tanh-GELU (reference transformer.py:11-14)."""
-    return 0.5 * x * (1.0 + torch.tanh(0.7978845608028654 * x * (1.0 + 0.044715 * x * x)))
+    """OpenAI tanh-GELU (reference transformer.py:11-14): one fused HIP pass instead of ~9 elementwise launches."""
+    return ops.gelu_tanh(x)
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm parameters / state_dict keys, HIP forward + backward; ``residual`` fuses the ``x + LN(.)`` of the
+    sandwich LayerNorms (reference transformer.py:201-203,207-209)."""
+
+    def forward(self, x, residual=None):
+        if not self.elementwise_affine or len(self.normalized_shape) != 1:
+            raise NotImplementedError("libmas_hip LayerNorm: affine, over the last dimension")
+        return ops.layer_norm(x, self.weight, self.bias, self.eps, residual)
 
 
 class SelfAttention(nn.Module):
@@ -67,11 +77,11 @@ class TransformerLayer(nn.Module):
         self.cogview_sandwich_layernorm = cogview_sandwich_layernorm
         self.cogview_layernorm_prescale = cogview_layernorm_prescale
         self.rudalle_relax = rudalle_relax
-        self.ln_in = nn.LayerNorm(hidden_dim, eps=1e-5)
-        self.ln_out = nn.LayerNorm(hidden_dim, eps=1e-5)
+        self.ln_in = LayerNorm(hidden_dim, eps=1e-5)
+        self.ln_out = LayerNorm(hidden_dim, eps=1e-5)
         if cogview_sandwich_layernorm:
-            self.first_ln_sandwich = nn.LayerNorm(hidden_dim, eps=1e-5)
-            self.second_ln_sandwich = nn.LayerNorm(hidden_dim, eps=1e-5)
+            self.first_ln_sandwich = LayerNorm(hidden_dim, eps=1e-5)
+            self.second_ln_sandwich = LayerNorm(hidden_dim, eps=1e-5)
         self.attn = SelfAttention(hidden_dim=hidden_dim, num_attn_heads=num_attn_heads, attn_dropout_prob=attn_dropout_prop,
                                   out_dropout_prob=out_dropout_prob, cogview_pb_relax=cogview_pb_relax, rudalle_relax=rudalle_relax)
         self.mlp = MLP(hidden_dim=hidden_dim, dropout_prob=out_dropout_prob, rudalle_relax=rudalle_relax)
@@ -82,11 +92,12 @@ class TransformerLayer(nn.Module):
     def forward(self, x, mask, cache=None, use_cache=False, mlp_cache=False):
         attn_out, new_cache = self.attn(self.ln_in(self._prescale(x)), mask, use_cache, cache)
         if self.cogview_sandwich_layernorm:
-            attn_out = self.first_ln_sandwich(self._prescale(attn_out))
-        x = x + attn_out
+            x = self.first_ln_sandwich(self._prescale(attn_out), residual=x)        # x + LN(attn_out), one pass
+        else:
+            x = x + attn_out
         mlp_out = self.mlp(self.ln_out(self._prescale(x)))
         if self.cogview_sandwich_layernorm:
-            mlp_out = self.second_ln_sandwich(mlp_out)
+            return self.second_ln_sandwich(mlp_out, residual=x), new_cache
         return x + mlp_out, new_cache
 
 
@@ -102,7 +113,7 @@ class Transformer(nn.Module):
             TransformerLayer(hidden_dim, num_attn_heads, attn_dropout_prop, out_dropout_prob, cogview_pb_relax,
                              cogview_sandwich_layernorm, cogview_layernorm_prescale, rudalle_relax) for _ in range(num_layers)])
         self.register_buffer("mask", self._create_mask(text_length, seg_tokens_per_dim, image_tokens_per_dim))
-        self.final_ln = nn.LayerNorm(hidden_dim, eps=1e-5)
+        self.final_ln = LayerNorm(hidden_dim, eps=1e-5)
 
     def _create_mask(self, text_length, seg_tokens_per_dim, image_tokens_per_dim):
         size = text_length + seg_tokens_per_dim ** 2 + image_tokens_per_dim ** 2
@@ -141,7 +152,7 @@ class MakeAScene(nn.Module):
         for m in (self.text_pos_embeddings, self.seg_row_embeddings, self.seg_col_embeddings, self.image_row_embeddings,
                   self.image_col_embeddings):
             self._init_weights(m)
-        self.to_logits = torch.nn.Sequential(torch.nn.LayerNorm(hidden_dim), torch.nn.Linear(hidden_dim, image_vocab_size))
+        self.to_logits = torch.nn.Sequential(LayerNorm(hidden_dim), torch.nn.Linear(hidden_dim, image_vocab_size))
 
     @property
     def device(self):

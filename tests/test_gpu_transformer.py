@@ -102,3 +102,68 @@ def test_make_a_scene_bf16_logits_close(golden_dir):
     with torch.no_grad():
         logits = m(text, seg, img)
     assert relerr(logits, g["logits"]) < 3e-2
+
+
+def _gelu_ref(x):
+    return 0.5 * x * (1.0 + torch.tanh(0.7978845608028654 * x * (1.0 + 0.044715 * x * x)))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n", [8 * 1024 * 33, 100003, 5])
+def test_gelu_tanh_fwd_bwd(n, dtype):
+    """reference models/transformer.py:11-14; ragged tails (n not a multiple of the 16-byte vector) included"""
+    from mas_hip import ops
+    dev = _dev()
+    rs = np.random.RandomState(n % 97)
+    x = torch.from_numpy((3.0 * rs.randn(n)).astype(np.float32)).to(dtype)
+    go = torch.from_numpy(rs.randn(n).astype(np.float32)).to(dtype)
+    ref_in = x.float().clone().requires_grad_(True)
+    ref = _gelu_ref(ref_in)
+    ref.backward(go.float())
+    xd = x.to(dev).requires_grad_(True)
+    y = ops.gelu_tanh(xd)
+    y.backward(go.to(dev))
+    tol = 2e-6 if dtype == torch.float32 else 1e-2
+    assert y.dtype == dtype and relerr(y, ref) < tol
+    assert relerr(xd.grad, ref_in.grad) < tol
+
+
+@pytest.mark.parametrize("case", [
+    # rows, D, in dtype, out dtype, residual
+    (37, 64, torch.float32, torch.float32, False),
+    (37, 64, torch.float32, torch.float32, True),
+    (3 * 1536, 1024, torch.float32, torch.bfloat16, False),     # pre-LN under autocast: fp32 residual stream -> bf16 GEMM input
+    (3 * 1536, 1024, torch.bfloat16, torch.float32, True),      # sandwich LN: bf16 GEMM output + fp32 residual stream
+    (130, 200, torch.bfloat16, torch.bfloat16, True),
+    (5, 2048, torch.bfloat16, torch.bfloat16, False),
+    (1, 1024, torch.float32, torch.float32, True),
+])
+def test_layer_norm_fwd_bwd(case):
+    """torch.nn.LayerNorm(D, eps=1e-5) [+ residual] (reference models/transformer.py:159-163,197-210) vs torch fp32 on CPU"""
+    from mas_hip import ops
+    rows, d, tin, tout, has_res = case
+    dev = _dev()
+    rs = np.random.RandomState(rows + d)
+    x = torch.from_numpy((2.0 * rs.randn(rows, d) + 0.5).astype(np.float32)).to(tin)
+    w = torch.from_numpy((1.0 + 0.2 * rs.randn(d)).astype(np.float32))
+    b = torch.from_numpy((0.1 * rs.randn(d)).astype(np.float32))
+    res = torch.from_numpy(rs.randn(rows, d).astype(np.float32)).to(tout) if has_res else None
+    go = torch.from_numpy(rs.randn(rows, d).astype(np.float32)).to(tout)
+    rx, rw, rb = x.float().clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rres = res.float().clone().requires_grad_(True) if has_res else None
+    ref = torch.nn.functional.layer_norm(rx, (d,), rw, rb, 1e-5)
+    if has_res:
+        ref = ref + rres
+    ref.backward(go.float())
+    xd = x.to(dev).requires_grad_(True)
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    resd = res.to(dev).requires_grad_(True) if has_res else None
+    y = ops.layer_norm(xd, wd, bd, 1e-5, resd, out_dtype=tout)
+    y.backward(go.to(dev))
+    lo = tin == torch.bfloat16 or tout == torch.bfloat16
+    assert y.dtype == tout and relerr(y, ref) < (1e-2 if tout == torch.bfloat16 else 2e-6)
+    assert relerr(xd.grad, rx.grad) < (1e-2 if lo else 1e-5)
+    assert relerr(wd.grad, rw.grad) < (1e-2 if lo else 1e-5)
+    assert relerr(bd.grad, rb.grad) < (1e-2 if lo else 1e-5)
+    if has_res:
+        assert torch.equal(resd.grad.float().cpu(), go.float())
