@@ -71,14 +71,6 @@ def main():
         da = torch.randn_like(x)
         ms = timeit(lambda: ops.gn_bwd(x, da, None, 32, a.act or 2, g, mr, ss), a.iters)
         print(f"gn_bwd n={n} c={c} hw={h}: {ms:.4f} ms  {5*x.numel()*esz/ms/1e6:.1f} GB/s (2 reads x2 + 1 write)")
-        for ch in (1, 2, 4, 8):                     # image-chunked launches: does the apply pass hit the Infinity Cache?
-            if ch >= n:
-                break
-            def chunked():
-                for i in range(0, n, ch):
-                    ops.gn_bwd(x[i:i + ch], da[i:i + ch], None, 32, a.act or 2, g, mr[i:i + ch], ss[i:i + ch])
-            ms = timeit(chunked, a.iters)
-            print(f"   chunks of {ch} images: {ms:.4f} ms  {5*x.numel()*esz/ms/1e6:.1f} GB/s")
     elif a.kind == "attn":
         b, h, sq, hd = a.n, 16, a.hw if a.hw != 256 else 1536, 64
         qkv = torch.randn(b, sq, 3 * h * hd, device=dev).to(dt).requires_grad_(True)
