@@ -201,3 +201,31 @@ def test_vq_full_size_properties():
     assert torch.equal(idx.cpu(), pick)                                  # planted nearest codes are recovered
     zq2, _, idx2 = ops.vq_lookup(zq.detach(), cb.to(dev), 0.25)          # idempotence: quantising z_q is a fixed point
     assert torch.equal(idx2, idx) and torch.equal(zq2, zq)
+
+
+def test_conv_full_size_properties():
+    """BASELINE config 2's dominant launch (B=32, 128->128 3x3 at 256x256, bf16) -- too big for the CPU oracle, so
+    size-independent properties: per-sample independence of the forward (bitwise), additivity of the weight gradient
+    over the batch, and exact homogeneity (a power-of-two scale of dy commutes with bf16 rounding)."""
+    from mas_hip import ops
+    dev = _dev()
+    n, c, h = 32, 128, 256
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(n, c, h, h, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(n, c, h, h, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+    w = (0.05 * torch.randn(c, c, 3, 3, generator=g)).to(dev)
+    wp = ops.pack_conv_weight(w, False, torch.bfloat16)
+    geo = (h, h, c, h, h, c, 3, 1, 1, 1)
+    y = ops.conv_fwd_raw(x, None, wp, None, None, n, *geo, 0, False, torch.bfloat16)
+    for i in (0, 17, 31):
+        yi = ops.conv_fwd_raw(x[i:i + 1], None, wp, None, None, 1, *geo, 0, False, torch.bfloat16)
+        assert torch.equal(yi[0], y[i])
+    assert torch.isfinite(y.float()).all()
+    dw, db = ops.conv_wgrad_raw(x, None, dy, n, *geo, 0, False, True)
+    dwa, dba = ops.conv_wgrad_raw(x[:16], None, dy[:16], 16, *geo, 0, False, True)
+    dwb, dbb = ops.conv_wgrad_raw(x[16:], None, dy[16:], 16, *geo, 0, False, True)
+    assert relerr(dwa + dwb, dw) < 1e-4 and relerr(dba + dbb, db) < 1e-4          # fp32 atomics: order-dependent last bits only
+    dw2, db2 = ops.conv_wgrad_raw(x, None, dy * 2, n, *geo, 0, False, True)
+    assert relerr(dw2, 2 * dw) < 1e-5 and relerr(db2, 2 * db) < 1e-5
+    # column sums of dy == bias gradient (independent fp64 reduction on the GPU tensor)
+    assert relerr(db, dy.double().sum((0, 2, 3)).float()) < 1e-4

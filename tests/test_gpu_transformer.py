@@ -167,3 +167,32 @@ def test_layer_norm_fwd_bwd(case):
     assert relerr(bd.grad, rb.grad) < (1e-2 if lo else 1e-5)
     if has_res:
         assert torch.equal(resd.grad.float().cpu(), go.float())
+
+
+def test_causal_attention_full_size_properties():
+    """BASELINE config 4 shapes (16 heads x 64, S = 1536, bf16): rows of the softmax sum to one (V = 1 gives O = 1),
+    causality (changing tokens >= t leaves every output < t bitwise unchanged, forward and dq/dk/dv), finiteness."""
+    from mas_hip import ops
+    dev = _dev()
+    b, h, s, hd = 2, 16, 1536, 64
+    d = h * hd
+    ops.set_compute_dtype(torch.bfloat16)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    qkv = torch.randn(b, s, 3 * d, generator=g).bfloat16().to(dev)
+    ones = qkv.clone()
+    ones[..., 2 * d:] = 1.0
+    o = ops.causal_attention(ones, h)
+    assert (o.float() - 1.0).abs().max() < 1e-2
+    t = 1000
+    a = qkv.clone().requires_grad_(True)
+    pert = qkv.clone()
+    pert[:, t:] = torch.randn(b, s - t, 3 * d, generator=g).bfloat16().to(dev)
+    p = pert.requires_grad_(True)
+    oa, op_ = ops.causal_attention(a, h), ops.causal_attention(p, h)
+    assert torch.equal(oa[:, :t], op_[:, :t]) and torch.isfinite(oa.float()).all()
+    go = torch.zeros_like(oa)
+    go[:, :t] = torch.randn(b, t, d, generator=g).bfloat16().to(dev)      # only the first t outputs are differentiated
+    oa.backward(go)
+    op_.backward(go)
+    assert torch.equal(a.grad[:, :t], p.grad[:, :t])                      # their gradients cannot see tokens >= t either
+    assert float(a.grad[:, t:].abs().max()) == 0.0
