@@ -369,6 +369,7 @@ int launch_fwd_fast(const AttnParams& p, hipStream_t s) {
     return MAS_OK;
 }
 
+inline bool attn_generic() { static const int v = mas_env_int("MAS_ATTN_GENERIC", 0); return v != 0; }   // A/B knob
 inline bool fa_aligned(const void* ptr, long long bs, int ld) {
     return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && (bs % 8) == 0 && (ld % 8) == 0;
 }
@@ -976,7 +977,7 @@ extern "C" int mas_attn_causal_fwd(const void* q, const void* k, const void* v, 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MAS_BF16) {
         const bool fast = (hd == 64 || hd == 128) && fa_aligned(q, q_bs, ld_q) && fa_aligned(k, k_bs, ld_k) && fa_aligned(v, v_bs, ld_v) &&
-                          (reinterpret_cast<uintptr_t>(o) & 7) == 0 && !getenv("MAS_ATTN_GENERIC");
+                          (reinterpret_cast<uintptr_t>(o) & 7) == 0 && !attn_generic();
         if (fast) return hd == 64 ? launch_fwd_fast<64>(p, s) : launch_fwd_fast<128>(p, s);
         return launch_hd<bf16_t>(p, hd, s);
     }
@@ -1001,7 +1002,7 @@ extern "C" int mas_attn_causal_bwd(const void* qkv, const void* o, const void* d
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MAS_BF16) {
         const bool al = ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dqkv) | reinterpret_cast<uintptr_t>(dout)) & 15) == 0 && (d % 8) == 0;
-        if (hd == 64 && al && !getenv("MAS_ATTN_GENERIC")) return launch_bwd_fast64(p, s);
+        if (hd == 64 && al && !attn_generic()) return launch_bwd_fast64(p, s);
         return launch_bwd_hd<bf16_t>(p, hd, s);
     }
     if (dtype == MAS_F32) return launch_bwd_hd<float>(p, hd, s);

@@ -78,7 +78,6 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_fwd_kernel(ConvParams
     constexpr int MI = BC / WC / 32;           // 32-cout tiles per wave
     constexpr int NI = (TH * TW) / WP / 32;    // 32-pixel tiles per wave
     constexpr int WT_BYTES = BC * 128;         // one weight tile (BC rows x 128 B)
-    constexpr int W_PER_T = BC * 8 / NT;       // 16-byte slots of a weight tile per thread
     constexpr int NTAP = KS * KS;
     // weight stage = TPS consecutive taps staged (and barrier-synchronised) together: the measured cost of a
     // work-group barrier is ~650 cycles of wave skew, so the big tile amortises it over 48 MFMAs instead of 16
@@ -517,10 +516,11 @@ int launch_v(const ConvParams& p0, hipStream_t s) {
     p.tiles_h = mas_cdiv(p.Ho, G::TH); p.tiles_w = mas_cdiv(p.Wo, TW);
     constexpr int TPS = (BIG == 1 && KS == 3) ? 3 : 1;
     size_t lds = (size_t)G::PATCH_BYTES + 2 * TPS * BC * 128;
-    if (const char* e = getenv("MAS_CONV_LDS_PAD")) lds += (size_t)atoi(e);   // experiment: lower residency
+    static const int lds_pad = mas_env_int("MAS_CONV_LDS_PAD", 0);            // experiment knob: lower residency
+    lds += (size_t)lds_pad;
     auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, BC, WC, VEC, BIG>;
     static bool attr_done = false;
-    if (!attr_done || getenv("MAS_CONV_LDS_PAD")) {
+    if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             MAS_FAIL(MAS_ELAUNCH, "conv_fwd: cannot set dynamic LDS size %zu", lds);
         attr_done = true;
@@ -530,7 +530,8 @@ int launch_v(const ConvParams& p0, hipStream_t s) {
     const long long tiles = (long long)p.N * p.tiles_h * p.tiles_w * q.n_ct;
     if (tiles <= 0 || tiles > 0x7fffffffLL) MAS_FAIL(MAS_EINVAL, "conv_fwd: bad tile count %lld", tiles);
     long long resident = (BIG ? 1LL : 2LL) * mas_num_cus();
-    if (const char* e = getenv("MAS_CONV_WGS_PER_CU")) resident = (long long)atoi(e) * mas_num_cus();   // work-groups per CU allowed by the LDS / VGPR budget
+    static const int wgs_per_cu = mas_env_int("MAS_CONV_WGS_PER_CU", 0);      // experiment knob: work-groups per CU
+    if (wgs_per_cu > 0) resident = (long long)wgs_per_cu * mas_num_cus();
     const unsigned blocks = (unsigned)(tiles < resident ? tiles : resident);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, s, q);
     MAS_CHECK_LAUNCH("conv_fwd");
@@ -544,10 +545,10 @@ int launch(const ConvParams& p, hipStream_t s) {
             // 16x16 tiles when they still fill the chip at one (8-wave) work-group per CU
             const long long big_tiles = (long long)p.N * mas_cdiv(p.Ho, 16) * mas_cdiv(p.Wo, TW) * mas_cdiv(p.Cout, BC);
             const long long huge_tiles = (long long)p.N * mas_cdiv(p.Ho, 32) * mas_cdiv(p.Wo, TW) * mas_cdiv(p.Cout, BC);
-            const char* force = getenv("MAS_CONV_TILE");   // experiments: 0 / 1 / 2
+            static const int force = mas_env_int("MAS_CONV_TILE", -1);   // experiment knob: 0 / 1 / 2
             (void)huge_tiles;   // level 2 spills today (acc 128 + prefetch 40 + fragments 48 VGPRs): experiment only
-            if (force && atoi(force) == 2) return launch_v<T, TO, KS, STRIDE, BC, WC, true, 2>(p, s);
-            if (force ? atoi(force) == 1 : (big_tiles >= 2LL * mas_num_cus())) return launch_v<T, TO, KS, STRIDE, BC, WC, true, 1>(p, s);
+            if (force == 2) return launch_v<T, TO, KS, STRIDE, BC, WC, true, 2>(p, s);
+            if (force >= 0 ? force == 1 : (big_tiles >= 2LL * mas_num_cus())) return launch_v<T, TO, KS, STRIDE, BC, WC, true, 1>(p, s);
         }
         return launch_v<T, TO, KS, STRIDE, BC, WC, true, 0>(p, s);
     }
@@ -582,7 +583,9 @@ extern "C" int mas_conv_fwd(const MasConvDesc* d, const void* x, const float* sc
     if ((long long)d->H * d->W * d->Cin > 0x7fffffffLL) MAS_FAIL(MAS_EUNSUPPORTED, "conv_fwd: one image exceeds 2^31 elements");
     ConvParams p;
     p.dbg = nullptr;
+#ifdef MAS_TIMELINE          // s_memtime timeline builds only (tools/build_variant.sh tl -DMAS_TIMELINE)
     if (const char* e = getenv("MAS_DBG_PTR")) p.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
+#endif
     p.x = x; p.ss = scale_shift; p.w = w_packed; p.bias = bias; p.res = residual; p.y = y;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
     p.Hl = d->upsample ? 2 * d->H : d->H; p.Wl = d->upsample ? 2 * d->W : d->W;

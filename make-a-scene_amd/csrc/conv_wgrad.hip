@@ -765,7 +765,8 @@ int launch(WgradParams p, hipStream_t s) {
 template <typename T>
 int launch_t(const WgradParams& p, int ks, int stride, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
-        if (stride == 1 && (p.Cout % 8) == 0 && (p.Cin % 8) == 0 && !getenv("MAS_WGRAD_NO_TR")) {
+        static const int no_tr = mas_env_int("MAS_WGRAD_NO_TR", 0);        // A/B knob: the transposed-staging kernel for every shape
+        if (stride == 1 && (p.Cout % 8) == 0 && (p.Cin % 8) == 0 && !no_tr) {
             if (ks == 3) return launch_tr<3>(p, s);
             if (ks == 1) return launch_tr<1>(p, s);
         }
@@ -786,7 +787,9 @@ extern "C" int mas_conv_wgrad(const MasConvDesc* d, const void* x, const float* 
     if (d->upsample && d->stride != 1) MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad: upsample fold needs stride 1");
     WgradParams p;
     p.dbg = nullptr;
+#ifdef MAS_TIMELINE          // s_memtime timeline builds only (tools/build_variant.sh tl -DMAS_TIMELINE)
     if (const char* e = getenv("MAS_DBG_PTR")) p.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
+#endif
     p.x = x; p.ss = scale_shift; p.dy = dy; p.dw = dw; p.dbias = dbias;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
     p.Hl = d->upsample ? 2 * d->H : d->H; p.Wl = d->upsample ? 2 * d->W : d->W;

@@ -1,6 +1,7 @@
 // Shared device/host helpers for libmas_hip.so (gfx950 only; wave = 64).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -27,6 +28,8 @@ void mas_set_error(const char* fmt, ...);
 int mas_num_cus();   // compute units of the current device (cached)
 static inline int mas_roundup(int a, int b) { return (a + b - 1) / b * b; }
 static inline int mas_cdiv(int a, int b) { return (a + b - 1) / b; }
+// tuning / A-B knobs are read from the environment ONCE per process (not on every launch)
+static inline int mas_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static inline size_t mas_esize(int dtype) { return dtype == MAS_BF16 ? 2 : 4; }
 
 // ---- bf16 <-> f32 (round-to-nearest-even, same as torch's .to(bfloat16)) ---------

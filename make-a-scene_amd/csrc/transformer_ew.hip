@@ -73,7 +73,7 @@ __global__ __launch_bounds__(NT) void gelu_fwd_kernel(const T* __restrict__ x, T
         }
         st_vec<T, N>(y + i * N, v);
     }
-    if (blockIdx.x == 0 && threadIdx.x < (int)(n - nv * N)) {        // ragged tail
+    if (blockIdx.x == 0 && (int)threadIdx.x < (int)(n - nv * N)) {   // ragged tail
         const long long i = nv * N + threadIdx.x;
         const float a = (float)x[i], t = tanh_f<EXACT>(GK * a * (1.0f + GC * a * a));
         y[i] = (T)(0.5f * a * (1.0f + t));
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NT) void gelu_bwd_kernel(const T* __restrict__ x, c
         for (int e = 0; e < N; ++e) v[e] = grad(v[e], g[e]);
         st_vec<T, N>(dx + i * N, v);
     }
-    if (blockIdx.x == 0 && threadIdx.x < (int)(n - nv * N)) {
+    if (blockIdx.x == 0 && (int)threadIdx.x < (int)(n - nv * N)) {
         const long long i = nv * N + threadIdx.x;
         dx[i] = (T)grad((float)x[i], (float)dy[i]);
     }

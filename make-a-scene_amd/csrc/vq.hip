@@ -135,7 +135,7 @@ __global__ __launch_bounds__(NT) void vq_loss_reduce(const float* __restrict__ b
     for (int i = threadIdx.x; i < n; i += NT) s += (double)blocksum[i];
     red[threadIdx.x] = s;
     __syncthreads();
-    for (int o = NT / 2; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    for (int o = NT / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) out[0] = (float)red[0];
 }
 

@@ -37,6 +37,14 @@ IMG = dict(ddconfig=dict(z_channels=256, in_channels=3, out_channels=3,
                          channels=[128, 128, 128, 256, 512, 512], num_res_blocks=2, resolution=512,
                          attn_resolutions=[32], dropout=0.0),
            n_embed=8192, embed_dim=256, init_steps=3000, reservoir_size=12500)
+# BASELINE config 1: the model block of conf/seg_config.yaml VERBATIM (ch / ch_mult / out_ch / double_z are swallowed by
+# **kwargs, modules.py:217,338, so the decoder emits 3 channels), n_embed 256 as BASELINE states, plus the two kwargs the
+# YAML lacks.  SEG_EFF = the constructor arguments that take effect (for the synthetic weights).
+SEG_YAML = dict(embed_dim=256, n_embed=256, init_steps=3000, reservoir_size=12500,
+                ddconfig=dict(double_z=False, z_channels=256, resolution=256, in_channels=159, out_ch=159, ch=128,
+                              ch_mult=[1, 1, 2, 2, 4], num_res_blocks=2, attn_resolutions=[16], dropout=0.0))
+SEG_EFF = dict(z_channels=256, in_channels=159, out_channels=3, channels=[128, 128, 128, 256, 512, 512], num_res_blocks=2,
+               resolution=256, attn_resolutions=[16], dropout=0.0)
 GRAD_KEYS_TINY = ["encoder.model.0.weight", "encoder.model.1.norm1.weight", "encoder.model.1.conv2.bias",
                   "encoder.model.3.nin_shortcut.weight", "encoder.model.6.q.weight", "encoder.model.8.norm.bias",
                   "quant_conv.0.weight", "quant_conv.1.weight", "quantize.embedding.weight",
@@ -44,9 +52,9 @@ GRAD_KEYS_TINY = ["encoder.model.0.weight", "encoder.model.1.norm1.weight", "enc
                   "decoder.model.16.weight"]
 
 
-def run_vq(cfg, x, seed, scale, train=True, grads=()):
+def run_vq(cfg, x, seed, scale, train=True, grads=(), eff=None, loss_fn=None):
     model = VQBASE(**cfg)
-    sd = synth_state_dict(cfg["ddconfig"], cfg["n_embed"], cfg["embed_dim"], seed=seed, codebook_scale=scale)
+    sd = synth_state_dict(eff or cfg["ddconfig"], cfg["n_embed"], cfg["embed_dim"], seed=seed, codebook_scale=scale)
     model.load_state_dict(sd, strict=True)
     model.train(train)
     model.quantize.q_counter = model.quantize.q_re_end  # steady state: VQ active, no k-means
@@ -57,7 +65,7 @@ def run_vq(cfg, x, seed, scale, train=True, grads=()):
     out = {}
     if train:
         rec, q_loss = model(x)
-        loss = (x - rec).abs().mean() + q_loss
+        loss = (loss_fn(x, rec) if loss_fn else (x - rec).abs().mean()) + q_loss
         loss.backward()
         out["loss"] = loss.detach().numpy()
         names = dict(model.named_parameters())
@@ -74,8 +82,22 @@ def run_vq(cfg, x, seed, scale, train=True, grads=()):
     return out
 
 
+def seg128():
+    """BASELINE configs[0]: VQ-SEG 128x128, codebook 256, batch 4, conf/seg_config.yaml, on the reference's CPU path."""
+    x = synth_image_batch(4, 159, 128, seed=4)
+    sg = run_vq(SEG_YAML, x, seed=4, scale=1.0, train=True, eff=SEG_EFF, loss_fn=lambda x, rec: rec.abs().mean(),
+                grads=["encoder.model.0.weight", "decoder.model.28.weight", "quantize.embedding.weight"])
+    np.savez_compressed(os.path.join(HERE, "vq_seg128.npz"), rec_sub=sg["rec"][:, :, ::4, ::4], q_loss=sg["q_loss"], loss=sg["loss"],
+                        idx=sg["idx"], z_sub=sg["z"][:, ::4], gradnorm_total=sg["gradnorm_total"],
+                        **{k: (v[:, ::8] if v.ndim == 4 and v.shape[1] > 64 else v) for k, v in sg.items() if k.startswith("grad:")})
+
+
 def main():
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "seg128":          # only the config-1 fixture
+        seg128()
+        return
+    seg128()
     # ---- tiny VQ: full tensors, train + eval, fwd + bwd ------------------------
     x = synth_image_batch(2, 3, 32, seed=0)
     tr = run_vq(TINY, x, seed=0, scale=1.0, train=True, grads=GRAD_KEYS_TINY)

@@ -148,6 +148,45 @@ def test_img256_fp32_vs_reference_golden(golden_dir):
     assert abs(tot - float(g["gradnorm_total"])) < 2e-2 * tot
 
 
+SEG_YAML = dict(embed_dim=256, n_embed=256, init_steps=3000, reservoir_size=12500,      # conf/seg_config.yaml:13-32 verbatim
+                ddconfig=dict(double_z=False, z_channels=256, resolution=256, in_channels=159, out_ch=159, ch=128,
+                              ch_mult=[1, 1, 2, 2, 4], num_res_blocks=2, attn_resolutions=[16], dropout=0.0))
+SEG_EFF = dict(z_channels=256, in_channels=159, out_channels=3, channels=[128, 128, 128, 256, 512, 512], num_res_blocks=2,
+               resolution=256, attn_resolutions=[16], dropout=0.0)
+
+
+def test_seg128_config1_fp32_vs_reference_golden(golden_dir):
+    """BASELINE configs[0]: the VQ-SEG model block of conf/seg_config.yaml passed VERBATIM (ch / ch_mult / out_ch / double_z
+    are swallowed by **kwargs exactly as the reference swallows them), 128x128, codebook 256, batch 4, fwd+bwd, against the
+    reference's own CPU output."""
+    from models import VQBASE
+    from mas_hip import ops
+    from oracle.vq_oracle import synth_image_batch, synth_state_dict
+    g = np.load(os.path.join(golden_dir, "vq_seg128.npz"))
+    ops.set_compute_dtype(torch.float32)
+    m = VQBASE(**SEG_YAML)
+    m.load_state_dict(synth_state_dict(SEG_EFF, 256, 256, seed=4), strict=True)
+    m = m.to(_dev()).train()
+    m.quantize.q_counter = m.quantize.q_re_end
+    x = synth_image_batch(4, 159, 128, seed=4).to(_dev())
+    taps = {}
+    m.quant_conv.register_forward_hook(lambda mod, i, o: taps.__setitem__("z", o.detach()))
+    m.quantize.register_forward_hook(lambda mod, i, o: taps.__setitem__("q", o))
+    rec, q_loss = m(x)
+    assert rec.shape == (4, 3, 128, 128)
+    loss = rec.abs().mean() + q_loss
+    loss.backward()
+    assert relerr(taps["z"][:, ::4], g["z_sub"]) < 2e-3
+    mism = (taps["q"][2].cpu().numpy() != g["idx"]).mean()
+    assert mism <= 2 / 256, mism
+    assert relerr(rec[:, :, ::4, ::4], g["rec_sub"]) < 5e-3
+    assert abs(float(loss) - float(g["loss"])) < 2e-3 * abs(float(g["loss"]))
+    params = dict(m.named_parameters())
+    assert relerr(params["decoder.model.28.weight"].grad[:, ::8], g["grad:decoder.model.28.weight"]) < 1e-2
+    tot = np.sqrt(sum(float((p.grad.double() ** 2).sum()) for p in m.parameters() if p.grad is not None))
+    assert abs(tot - float(g["gradnorm_total"])) < 2e-2 * tot
+
+
 def test_img256_bf16_batch_properties():
     """BASELINE config 2 shapes (bf16, 256x256): size-independent properties -- bitwise run-to-run
     determinism of the forward, per-sample independence of the conv/GN stack (eval mode: BN uses

@@ -81,6 +81,30 @@ def test_img256_matches_reference(golden_dir):
     assert abs(tot - float(g["gradnorm_total"])) < 1e-3 * tot
 
 
+SEG_EFF = dict(z_channels=256, in_channels=159, out_channels=3, channels=[128, 128, 128, 256, 512, 512], num_res_blocks=2,
+               resolution=256, attn_resolutions=[16], dropout=0.0)     # what conf/seg_config.yaml's model block resolves to
+
+
+def test_seg128_config1_matches_reference(golden_dir):
+    """BASELINE configs[0]: VQ-SEG 128x128, codebook 256, batch 4 (conf/seg_config.yaml on the reference's CPU path)."""
+    g = np.load(os.path.join(golden_dir, "vq_seg128.npz"))
+    x = O.synth_image_batch(4, 159, 128, seed=4)
+    sd = O.synth_state_dict(SEG_EFF, 256, 256, seed=4)
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    dec, q_loss, idx, z = O.vqbase_forward(sd, x, SEG_EFF, training=True)
+    loss = dec.abs().mean() + q_loss               # the YAML's decoder emits 3 channels (out_ch is swallowed): no x - rec here
+    loss.backward()
+    assert np.array_equal(idx.numpy(), g["idx"])
+    _close(dec[:, :, ::4, ::4], g["rec_sub"], rtol=1e-3, atol=1e-4)
+    _close(z[:, ::4], g["z_sub"], rtol=1e-3, atol=1e-4)
+    _close(loss, g["loss"])
+    _close(sd["decoder.model.28.weight"].grad[:, ::8], g["grad:decoder.model.28.weight"], rtol=5e-3, atol=1e-6)
+    tot = np.sqrt(sum(float((v.grad.double() ** 2).sum()) for v in sd.values() if v.grad is not None))
+    assert abs(tot - float(g["gradnorm_total"])) < 1e-3 * tot
+
+
 @pytest.mark.parametrize("tag", ["scaled", "default"])
 def test_codebook_matches_reference(golden_dir, tag):
     g = np.load(os.path.join(golden_dir, f"codebook_{tag}.npz"))
