@@ -204,3 +204,61 @@ def test_img256_bf16_batch_properties():
     assert torch.equal(h4[1:2], h1)
     assert torch.equal(rec4, rec4b)
     assert torch.isfinite(rec4).all()
+
+
+def test_kmeans_reinit_vs_oracle():
+    """the k-means behind the codebook re-initialisation (reference modules.py:487-499 ->
+    fast_pytorch_kmeans, absent and unpinned: parity is against oracle/kmeans_oracle.py's restatement of its published
+    algorithm, from identical initial centroids)."""
+    from models.kmeans import kmeans_fit
+    from oracle.kmeans_oracle import kmeans_lloyd
+    dev = _dev()
+    rs = np.random.RandomState(3)
+    k, d, per = 48, 32, 40
+    centers = 4.0 * rs.randn(k, d)
+    pts = (centers[:, None, :] + 0.3 * rs.randn(k, per, d)).reshape(-1, d).astype(np.float32)
+    rs.shuffle(pts)
+    init = rs.choice(len(pts), size=k, replace=False)
+    ref_c, ref_a, ref_it = kmeans_lloyd(pts, init)
+    cent, idx, it = kmeans_fit(torch.from_numpy(pts).to(dev), k, init_idx=torch.from_numpy(init).to(dev), return_info=True)
+    assert it == ref_it
+    assert np.array_equal(idx.cpu().numpy(), ref_a)
+    assert relerr(cent, ref_c) < 1e-5
+    # an empty cluster's centroid becomes the zero vector (library behaviour): duplicate initial centroid -> the higher index never wins a tie
+    init2 = init.copy(); init2[1] = init2[0]
+    ref_c2, ref_a2, _ = kmeans_lloyd(pts, init2, max_iter=1)
+    cent2, idx2, _ = kmeans_fit(torch.from_numpy(pts).to(dev), k, max_iter=1, init_idx=torch.from_numpy(init2).to(dev), return_info=True)
+    assert np.array_equal(idx2.cpu().numpy(), ref_a2) and float(cent2[1].abs().max()) == 0.0 and relerr(cent2, ref_c2) < 1e-5
+
+
+def test_codebook_warmup_schedule():
+    """Codebook.forward's training schedule (reference modules.py:474-499): unquantised pass-through with zero loss and no
+    indices before 3*init_steps, reservoir of 10 latents per image capped at reservoir_size, k-means re-init at 3*init_steps."""
+    import torch.distributed as dist
+    from models.modules import Codebook
+    from mas_hip import ops
+    dev = _dev()
+    ops.set_compute_dtype(torch.float32)
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        cb = Codebook(16, 32, beta=0.25, init_steps=2, reservoir_size=50).to(dev).train()      # collect > 2, quantise from 6
+        g = torch.Generator(device="cpu").manual_seed(0)
+        for step in range(1, 8):
+            z = torch.randn(4, 32, 6, 6, generator=g).to(dev)
+            before = cb.embedding.weight.detach().clone()
+            zq, loss, idx = cb(z)
+            assert cb.q_counter == step
+            if step < 6:
+                assert idx is None and float(loss) == 0.0 and torch.equal(zq, z)
+            else:
+                assert idx is not None and zq.shape == z.shape and float(loss) > 0.0
+            if step > 2:
+                assert cb.reservoir.shape == (min(50, 40 * (step - 2)), 32)
+            changed = not torch.equal(before, cb.embedding.weight.detach())
+            assert changed == (step in (6, 7))        # (q - q_init) % q_re_step == 0 with q_re_step = 1: every step from 6 on
+    finally:
+        if own_group:
+            dist.destroy_process_group()
