@@ -529,8 +529,13 @@ int launch_v(const ConvParams& p0, hipStream_t s) {
     q.n_ct = mas_cdiv(p.Cout, BC);
     const long long tiles = (long long)p.N * p.tiles_h * p.tiles_w * q.n_ct;
     if (tiles <= 0 || tiles > 0x7fffffffLL) MAS_FAIL(MAS_EINVAL, "conv_fwd: bad tile count %lld", tiles);
-    long long resident = (BIG ? 1LL : 2LL) * mas_num_cus();
-    static const int wgs_per_cu = mas_env_int("MAS_CONV_WGS_PER_CU", 0);      // experiment knob: work-groups per CU
+    // Persistent work-groups walk a static stride of tiles.  The grid is 4x what fits on the chip at once (1 or 2 work-groups
+    // per CU by LDS / VGPRs) so that the hardware dispatcher still balances at work-group granularity: when another kernel
+    // (an RCCL collective overlapping backward) holds some CUs, a grid of exactly one work-group per CU would run the
+    // displaced work-groups as a second full round (2x), this runs them as a fifth quarter-round (1.25x).  Measured cost
+    // of the 4x on an idle GPU: < 0.5 % (kbench / bench.py).
+    long long resident = 4LL * (BIG ? 1LL : 2LL) * mas_num_cus();
+    static const int wgs_per_cu = mas_env_int("MAS_CONV_WGS_PER_CU", 0);      // experiment knob: grid size in work-groups per CU
     if (wgs_per_cu > 0) resident = (long long)wgs_per_cu * mas_num_cus();
     const unsigned blocks = (unsigned)(tiles < resident ? tiles : resident);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, s, q);
