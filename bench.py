@@ -111,13 +111,21 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X (no CPU fallback for the product path)", file=sys.stderr)
         sys.exit(2)
+    # MAS_BENCH_SHARE_GPU=1 + MAS_BENCH_BACKEND=gloo: functional check of the N>1 code path (reducer, SyncBatchNorm
+    # exchange, max-over-ranks timing) with several ranks on ONE GPU -- RCCL refuses two ranks per device, gloo does not
+    if os.environ.get("MAS_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("MAS_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ddp = world > 1 or os.environ.get("MAS_BENCH_FORCE_DDP") == "1"     # the env knob exercises the N>1 code path on one GPU
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+        else:
+            dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
 
     from mas_hip import ops
     from models import VQBASE
@@ -190,6 +198,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss)
+    spread = None
+    if ddp:                                                 # replicas must still hold identical weights after the timed steps
+        with torch.no_grad():
+            cs = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        spread = float((hi - lo).item())
 
     if rank == 0:
         imgs = args.batch * world * args.steps
@@ -203,6 +219,7 @@ def main():
                        "parallelism": f"dp{world}" + ((" (DistributedDataParallel" if args.dp == "ddp" else " (mas_hip.dp.GradReducer: 128 MiB flat buckets,")
                                                        + " RCCL all-reduce overlapped with backward + SyncBatchNorm)" if ddp else "")},
             "final_loss": round(final_loss, 5),
+            "replica_weight_checksum_spread": spread,
             "model_tflops_per_gpu": round(value / world * FWD_BWD_GFLOP_PER_IMG / 1e3, 1),
         }
         if dom["events"]:
