@@ -1,0 +1,75 @@
+"""Row (e) on the real HIP path: two data-parallel ranks (gloo -- RCCL refuses two ranks on one device -- both on cuda:0),
+each running the tiny VQBASE on its half of the batch with torch's SyncBatchNorm exchange and mas_hip.dp.GradReducer,
+must reproduce the single-process full-batch loss and gradients."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TINY = dict(ddconfig=dict(z_channels=32, in_channels=3, out_channels=3, channels=[32, 32, 64, 64],
+                          num_res_blocks=1, resolution=32, attn_resolutions=[8], dropout=0.0),
+            n_embed=64, embed_dim=32, init_steps=3000, reservoir_size=12500)
+
+
+def _model():
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "make-a-scene_amd"))
+    from models import VQBASE
+    from mas_hip import ops
+    from oracle.vq_oracle import synth_state_dict, synth_image_batch
+    ops.set_compute_dtype(torch.float32)
+    m = VQBASE(**TINY)
+    m.load_state_dict(synth_state_dict(TINY["ddconfig"], TINY["n_embed"], TINY["embed_dim"], seed=0), strict=True)
+    m = m.to("cuda:0").train()
+    m.quantize.q_counter = m.quantize.q_re_end
+    return m, synth_image_batch(4, 3, 32, seed=0).to("cuda:0")
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, x = _model()
+    from mas_hip.dp import GradReducer
+    red = GradReducer(m.parameters(), bucket_bytes=256 << 10)
+    xs = x[rank * 2:(rank + 1) * 2]
+    rec, q = m(xs)
+    loss = (xs - rec).abs().mean() + q
+    loss.backward()
+    red.finish()
+    lsum = loss.detach().clone()
+    dist.all_reduce(lsum)
+    if rank == 0:
+        np.savez(out, loss=float(lsum) / world, nbuckets=len(red.buckets),
+                 **{k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_full_batch(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "dp_gpu.npz")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    assert int(got["nbuckets"]) >= 2
+    m, x = _model()
+    rec, q = m(x)                                    # no process group here: SyncBatchNorm == BatchNorm over the full batch
+    loss = (x - rec).abs().mean() + q
+    loss.backward()
+    assert abs(float(loss) - float(got["loss"])) < 1e-4 * abs(float(loss))
+    checked = 0
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            ref = p.grad.detach().cpu().numpy()
+            assert np.abs(got[k] - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-6, k
+            checked += 1
+    assert checked > 40
