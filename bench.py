@@ -44,8 +44,9 @@ FWD_BWD_GFLOP_PER_IMG = 1337.53   # SURVEY.md section 8(d), counted on the refer
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=15,
+                    help="untimed steps; the first ~1 s of load on a cold MI355X runs 5-8 %% slower (clock ramp), so the default covers it")
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE config: 32)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dp", default="mas", choices=["mas", "ddp"],
