@@ -10,8 +10,10 @@ by ONE asynchronous all-reduce (``ReduceOp.AVG`` on RCCL) that overlaps the rest
 parameters' ``.grad`` are re-pointed at views of the reduced flat buffer -- no per-parameter kernels.
 
 xGMI is point-to-point, so a ring all-reduce is per-link bound and wants few, large messages: the default
-bucket is 128 MiB (3 collectives for the 381 MB of VQ-IMG gradients), filled in reverse registration
-order so the first buckets close early in backward and only the last one is exposed.
+bucket is 128 MiB.  Gradients arrive in (roughly) reverse registration order, so every bucket but the one
+holding the model's FIRST parameters closes while backward still has work to overlap with; that one closes
+when backward ends and its collective is fully exposed -- it is therefore kept small (``first_bucket_bytes``,
+8 MiB: 4 collectives for the 381 MB of VQ-IMG gradients, ~0.05 ms exposed instead of ~0.8 ms).
 
 Semantics match DDP's: gradients are averaged over ranks; a parameter that received no gradient on this
 rank contributes zeros (all ranks must agree on which parameters are trainable in a step, as with
@@ -42,7 +44,8 @@ class _Bucket:
 
 class GradReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 128 << 20,
-                 process_group: Optional[dist.ProcessGroup] = None, broadcast: bool = True):
+                 process_group: Optional[dist.ProcessGroup] = None, broadcast: bool = True,
+                 first_bucket_bytes: int = 8 << 20):
         if not dist.is_initialized():
             raise RuntimeError("GradReducer needs an initialised torch.distributed process group")
         self.group = process_group
@@ -51,18 +54,20 @@ class GradReducer:
         plist = [p for p in params if p.requires_grad]
         if not plist:
             raise ValueError("GradReducer: no trainable parameters")
-        # buckets in reverse registration order (~ the order autograd produces gradients), split by dtype/device
-        self.buckets: List[_Bucket] = []
-        cur, cur_bytes = [], 0
-        for p in reversed(plist):
+        # contiguous runs of the registration order, split by size / dtype / device; the run holding the first parameters
+        # (last to receive gradients) is capped at first_bucket_bytes.  Listed in reverse (~ the order they will close).
+        groups, cur, cur_bytes = [], [], 0
+        for p in plist:
             nb = p.numel() * p.element_size()
-            if cur and (cur_bytes + nb > bucket_bytes or p.dtype != cur[0].dtype or p.device != cur[0].device):
-                self.buckets.append(_Bucket(cur))
+            cap = min(first_bucket_bytes, bucket_bytes) if not groups else bucket_bytes
+            if cur and (cur_bytes + nb > cap or p.dtype != cur[0].dtype or p.device != cur[0].device):
+                groups.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nb
         if cur:
-            self.buckets.append(_Bucket(cur))
+            groups.append(cur)
+        self.buckets: List[_Bucket] = [_Bucket(list(reversed(grp))) for grp in reversed(groups)]
         self._where = {}
         self._hooks = []
         for b in self.buckets:
