@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--co", type=int, default=0)
     ap.add_argument("--hw", type=int, default=256)
     ap.add_argument("--ks", type=int, default=3)
+    ap.add_argument("--stride", type=int, default=1, help="2 = the Downsample geometry (pad 0/1, conv_fwd only)")
     ap.add_argument("--act", type=int, default=0)
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--iters", type=int, default=20)
@@ -57,8 +58,13 @@ def main():
         else:
             wp = ops.pack_conv_weight(w, a.kind == "dgrad", dt)
             res = torch.randn(n, co, h, h, device=dev).to(dt).contiguous(memory_format=torch.channels_last) if a.res else None
-            fn = lambda: ops.conv_fwd_raw(x, ss, wp, b, res, n, h, h, c, h, h, co, a.ks, 1, p, p, a.act, False, dt)
-            byt = (x.numel() + n * co * h * h * (2 if a.res else 1)) * esz
+            ho = h if a.stride == 1 else h // 2
+            pt = p if a.stride == 1 else 0
+            if a.stride != 1:
+                flops /= 4.0
+                res = None
+            fn = lambda: ops.conv_fwd_raw(x, ss, wp, b, res, n, h, h, c, ho, ho, co, a.ks, a.stride, pt, pt, a.act, False, dt)
+            byt = (x.numel() + n * co * ho * ho * (2 if res is not None else 1)) * esz
         ms = timeit(fn, a.iters)
         print(f"{a.kind} n={n} c={c}->{co} hw={h} ks={a.ks} act={a.act} {a.dtype}: {ms:.4f} ms  {flops/ms/1e9:.1f} TFLOP/s  {byt/ms/1e6:.1f} GB/s(alg)")
     elif a.kind == "gn_stats":
