@@ -188,11 +188,20 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_fwd_kernel(ConvParams
             if (so[i] < 0 || cb >= p.Cin) v = u32x4{0u, 0u, 0u, 0u};   // zero padding / channels past Cin
             if (p.act != MAS_ACT_NONE && so[i] >= 0) {          // padding stays exactly zero
                 T* tv = reinterpret_cast<T*>(&v);
+                // vec_in: Cin is a multiple of the slot, so a slot is entirely inside or outside the tensor (handled above);
+                // the SiLU / plain-affine choice is wave-uniform: two straight-line bodies instead of per-element selects
+                if (p.act == MAS_ACT_AFFINE_SILU) {
 #pragma unroll
-                for (int e = 0; e < EPU; ++e) {
-                    float a = (float)tv[e] * sc[e] + sh[e];
-                    if (p.act == MAS_ACT_AFFINE_SILU) a = silu_f(a);
-                    tv[e] = (T)((cb + e < p.Cin) ? a : 0.0f);
+                    for (int e = 0; e < EPU; ++e) {
+                        const float a = silu_f((float)tv[e] * sc[e] + sh[e]);
+                        tv[e] = (T)((vec_in || cb + e < p.Cin) ? a : 0.0f);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPU; ++e) {
+                        const float a = (float)tv[e] * sc[e] + sh[e];
+                        tv[e] = (T)((vec_in || cb + e < p.Cin) ? a : 0.0f);
+                    }
                 }
             }
             *reinterpret_cast<u32x4*>(patch + dstoff[i]) = v;

@@ -626,13 +626,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgradParams p) {
             if (u >= X_UNITS) continue;
             u32x4 raw = rx[i];
             if (!okx[i]) raw = u32x4{0u, 0u, 0u, 0u};
-            else if (p.act != MAS_ACT_NONE) {
+            else if (p.act != MAS_ACT_NONE) {             // Cin % 8 == 0 on this path: the slot is entirely inside the tensor
                 T* tv = reinterpret_cast<T*>(&raw);
+                if (p.act == MAS_ACT_AFFINE_SILU) {       // wave-uniform: two straight-line bodies, no per-element selects
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float a = (float)tv[e] * rss[e >> 1][(e & 1) * 2] + rss[e >> 1][(e & 1) * 2 + 1];
-                    if (p.act == MAS_ACT_AFFINE_SILU) a = silu_f(a);
-                    tv[e] = (T)((cbx + e < p.Cin) ? a : 0.0f);
+                    for (int e = 0; e < 8; ++e) tv[e] = (T)silu_f((float)tv[e] * rss[e >> 1][(e & 1) * 2] + rss[e >> 1][(e & 1) * 2 + 1]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) tv[e] = (T)((float)tv[e] * rss[e >> 1][(e & 1) * 2] + rss[e >> 1][(e & 1) * 2 + 1]);
                 }
             }
             *reinterpret_cast<u32x4*>(xs + (u / X_UPP) * RSX + x_cu * 16) = raw;
