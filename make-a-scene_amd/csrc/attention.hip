@@ -358,11 +358,12 @@ template <int HD>
 int launch_fwd_fast(const AttnParams& p, hipStream_t s) {
     using G = FaGeo<HD>;
     auto kern = attn_causal_fwd_bf16_kernel<HD>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static mas_devmask_t attr_mask{0};
+    unsigned long long attr_bit;
+    if (mas_attr_needed(attr_mask, &attr_bit)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess)
             MAS_FAIL(MAS_ELAUNCH, "attn_causal_fwd: cannot set dynamic LDS size %zu", (size_t)G::LDS_BYTES);
-        attr_done = true;
+        mas_attr_done(attr_mask, attr_bit);
     }
     hipLaunchKernelGGL(kern, dim3(mas_cdiv(p.S, QT), p.B * p.H), dim3(NT), G::LDS_BYTES, s, p);
     MAS_CHECK_LAUNCH("attn_causal_fwd");

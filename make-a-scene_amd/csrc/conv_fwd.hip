@@ -528,11 +528,12 @@ int launch_v(const ConvParams& p0, hipStream_t s) {
     static const int lds_pad = mas_env_int("MAS_CONV_LDS_PAD", 0);            // experiment knob: lower residency
     lds += (size_t)lds_pad;
     auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, BC, WC, VEC, BIG>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static mas_devmask_t attr_mask{0};
+    unsigned long long attr_bit;
+    if (mas_attr_needed(attr_mask, &attr_bit)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             MAS_FAIL(MAS_ELAUNCH, "conv_fwd: cannot set dynamic LDS size %zu", lds);
-        attr_done = true;
+        mas_attr_done(attr_mask, attr_bit);
     }
     ConvParams q = p;
     q.n_ct = mas_cdiv(p.Cout, BC);

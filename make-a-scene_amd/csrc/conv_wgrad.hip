@@ -721,11 +721,12 @@ int launch_tr(WgradParams p, hipStream_t s) {
     constexpr int BCI_ = MAS_WGRAD_TR_BCI;
     using G = TrGeo<KS, BCI_>;
     auto kern = conv_wgrad_tr_kernel<KS, BCI_>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static mas_devmask_t attr_mask{0};
+    unsigned long long attr_bit;
+    if (mas_attr_needed(attr_mask, &attr_bit)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess)
             MAS_FAIL(MAS_ELAUNCH, "conv_wgrad_tr: cannot set dynamic LDS size %zu", (size_t)G::LDS_BYTES);
-        attr_done = true;
+        mas_attr_done(attr_mask, attr_bit);
     }
     p.tiles_h = mas_cdiv(p.Ho, G::THW); p.tiles_w = mas_cdiv(p.Wo, TWW);
     p.n_pt = p.N * p.tiles_h * p.tiles_w;
@@ -744,11 +745,12 @@ template <typename T, int KS, int STRIDE, int THW>
 int launch(WgradParams p, hipStream_t s) {
     using G = WGeo<T, KS, STRIDE, THW>;
     auto kern = conv_wgrad_kernel<T, KS, STRIDE, THW>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static mas_devmask_t attr_mask{0};
+    unsigned long long attr_bit;
+    if (mas_attr_needed(attr_mask, &attr_bit)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess)
             MAS_FAIL(MAS_ELAUNCH, "conv_wgrad: cannot set dynamic LDS size %zu", (size_t)G::LDS_BYTES);
-        attr_done = true;
+        mas_attr_done(attr_mask, attr_bit);
     }
     p.tiles_h = mas_cdiv(p.Ho, THW); p.tiles_w = mas_cdiv(p.Wo, TWW);
     p.n_pt = p.N * p.tiles_h * p.tiles_w;

@@ -25,7 +25,20 @@ void mas_set_error(const char* fmt, ...);
 // a stale error left in this thread by another library must not be blamed on our launch
 #define MAS_ENTER() do { (void)hipGetLastError(); } while (0)
 
-int mas_num_cus();   // compute units of the current device (cached)
+int mas_num_cus();   // compute units of the CURRENT device (cached per device)
+
+// One process per GPU is the contract (include/mas_hip.h), but a second device in the same process (nn.DataParallel,
+// reference train.py:177) must still launch correctly: per-function attributes such as the dynamic-LDS limit are set
+// once PER DEVICE.  `mask` holds one bit per device ordinal; the attribute call is idempotent, so a race only repeats it.
+#include <atomic>
+typedef std::atomic<unsigned long long> mas_devmask_t;
+static inline bool mas_attr_needed(mas_devmask_t& mask, unsigned long long* bit) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    *bit = 1ull << (dev & 63);
+    return (mask.load(std::memory_order_acquire) & *bit) == 0;
+}
+static inline void mas_attr_done(mas_devmask_t& mask, unsigned long long bit) { mask.fetch_or(bit, std::memory_order_release); }
 static inline int mas_roundup(int a, int b) { return (a + b - 1) / b * b; }
 static inline int mas_cdiv(int a, int b) { return (a + b - 1) / b; }
 // tuning / A-B knobs are read from the environment ONCE per process (not on every launch)

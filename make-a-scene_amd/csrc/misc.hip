@@ -12,13 +12,16 @@ void mas_set_error(const char* fmt, ...) {
 }
 
 int mas_num_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 256;   // MI355X
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;   // MI355X
+    int c = cus[dev & 63].load(std::memory_order_relaxed);
+    if (c == 0) {
+        int n = 0;
+        c = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        cus[dev & 63].store(c, std::memory_order_relaxed);
     }
-    return cus;
+    return c;
 }
 
 extern "C" const char* mas_last_error(void) { return g_err; }

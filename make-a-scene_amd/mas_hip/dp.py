@@ -17,7 +17,14 @@ when backward ends and its collective is fully exposed -- it is therefore kept s
 
 Semantics match DDP's: gradients are averaged over ranks; a parameter that received no gradient on this
 rank contributes zeros (all ranks must agree on which parameters are trainable in a step, as with
-``find_unused_parameters=False``); parameters are broadcast from rank 0 at construction."""
+``find_unused_parameters=False``); parameters are broadcast from rank 0 at construction.
+
+Contract: ``finish()`` follows EVERY synchronising ``backward()``.  Gradient accumulation (the reference's
+``accumulate_grad``, conf/img_config.yaml:13) runs the first k-1 micro-steps under ``with reducer.no_sync():``
+(hooks idle, ``.grad`` accumulates locally as usual) and the k-th outside it, exactly like DDP's ``no_sync``.  A
+second synchronising backward before ``finish()`` would add into a flat buffer whose all-reduce is in flight, so it
+raises instead of producing racy, unreduced gradients."""
+import contextlib
 from typing import Iterable, List, Optional
 
 import torch
@@ -27,7 +34,7 @@ __all__ = ["GradReducer"]
 
 
 class _Bucket:
-    __slots__ = ("params", "offsets", "flat", "pending", "work", "launched")
+    __slots__ = ("params", "offsets", "flat", "pending", "work", "launched", "seen")
 
     def __init__(self, params: List[torch.nn.Parameter]):
         self.params = params
@@ -40,6 +47,7 @@ class _Bucket:
         self.pending = len(params)
         self.work = None
         self.launched = False
+        self.seen = set()
 
 
 class GradReducer:
@@ -70,6 +78,7 @@ class GradReducer:
         self.buckets: List[_Bucket] = [_Bucket(list(reversed(grp))) for grp in reversed(groups)]
         self._where = {}
         self._hooks = []
+        self._sync = True
         for b in self.buckets:
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
@@ -87,8 +96,25 @@ class GradReducer:
                 for p, off in zip(b.params, b.offsets):
                     p.copy_(flat[off:off + p.numel()].view_as(p))
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Micro-steps of a gradient-accumulation window: backward passes inside the context only accumulate into
+        ``.grad``; the first backward outside it reduces the accumulated sum (then call ``finish()``)."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
+
     def _on_grad(self, p: torch.nn.Parameter):
-        b, _ = self._where[p]
+        if not self._sync:
+            return
+        b, i = self._where[p]
+        if b.launched or i in b.seen:
+            raise RuntimeError(
+                "GradReducer: a second backward() reached a bucket whose all-reduce is already in flight. Call finish() "
+                "after every synchronising backward(); run gradient-accumulation micro-steps under `with reducer.no_sync():`")
+        b.seen.add(i)
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
@@ -129,6 +155,7 @@ class GradReducer:
             b.work = None
             b.launched = False
             b.pending = len(b.params)
+            b.seen.clear()
 
     def remove(self):
         for h in self._hooks:

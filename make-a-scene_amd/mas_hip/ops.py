@@ -76,6 +76,9 @@ class _PackCache:
     def __init__(self):
         self.store = {}
 
+    def clear(self):
+        self.store.clear()
+
     def get(self, w: torch.Tensor, transpose: bool, dtype: torch.dtype) -> torch.Tensor:
         if not isinstance(w, torch.nn.Parameter):
             return pack_conv_weight(w.detach(), transpose, dtype)
@@ -90,6 +93,13 @@ class _PackCache:
 
 
 _pack_cache = _PackCache()
+
+
+def invalidate_weight_cache() -> None:
+    """Drops every cached packed weight.  The cache is validated by ``(Parameter._version, data_ptr)``, which an in-place
+    write THROUGH ``.data`` (``w.data.copy_(ema)``, ``w.data.normal_()``, weight clipping) does not change: call this after
+    such a write.  ``models.modules.Conv2d`` calls it from ``load_state_dict`` and on every train()/eval() switch."""
+    _pack_cache.clear()
 
 
 def pack_conv_weight(w: torch.Tensor, transpose: bool, dtype: torch.dtype) -> torch.Tensor:
@@ -162,6 +172,8 @@ def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ac
         _launch_hook("conv_wgrad", (n, h, w, cin, ho, wo, cout, ks, stride), launch)
     else:
         launch()
+    if ks == 1:                                     # [cout,1,1,cin] == OIHW memory; a permute would keep odd size-1 strides (DDP warns)
+        return dw.view(cout, cin, 1, 1), db
     return dw.permute(0, 3, 1, 2).contiguous(), db
 
 
@@ -407,9 +419,8 @@ class _CausalAttention(torch.autograd.Function):
     recomputes them tile by tile from the saved log-sum-exp and writes d(qkv) in place, no atomics)."""
 
     @staticmethod
-    def forward(ctx, qkv, n_heads):
+    def forward(ctx, qkv, n_heads, cd):
         _require_cuda(qkv, "causal_attention")
-        cd = compute_dtype()
         x = qkv.to(cd).contiguous()
         b, s, d3 = x.shape
         d = d3 // 3
@@ -437,11 +448,18 @@ class _CausalAttention(torch.autograd.Function):
         delta = torch.empty_like(lse)
         check(lib().mas_attn_causal_bwd(_ptr(x), _ptr(o), _ptr(g), _ptr(lse), _ptr(delta), _ptr(dx), _DT[x.dtype], b, h, s, hd,
                                         float(hd) ** -0.5, _stream()), "attn_causal_bwd")
-        return dx.to(ctx.in_dtype), None
+        return dx.to(ctx.in_dtype), None, None
 
 
-def causal_attention(qkv: torch.Tensor, n_heads: int) -> torch.Tensor:
-    return _CausalAttention.apply(qkv, n_heads)
+def causal_attention(qkv: torch.Tensor, n_heads: int, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """``dtype`` None: the arithmetic follows the INPUT -- bf16 kernels for a bf16 projection (what ``nn.Linear`` emits
+    under ``torch.autocast(bfloat16)``), exact-fp32 kernels for an fp32 one (the reference's un-autocast
+    ``train_transformer`` loop, train.py:150).  Pass ``dtype`` to force one."""
+    if dtype is None:
+        dtype = qkv.dtype
+    if dtype not in _DT:
+        raise RuntimeError(f"causal_attention: dtype {dtype} not supported (float32 / bfloat16)")
+    return _CausalAttention.apply(qkv, n_heads, dtype)
 
 
 # --------------------------------------------------------------------------- #

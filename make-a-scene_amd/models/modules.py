@@ -56,6 +56,18 @@ class Conv2d(nn.Conv2d):
         ph, pw = self.padding
         return (ph, ph, pw, pw)
 
+    # The packed bf16/NHWC weight images are cached on (Parameter._version, data_ptr); writes THROUGH ``.data`` change
+    # neither.  The two places such writes normally surround -- loading a checkpoint and switching train()/eval() (EMA
+    # swap-in) -- drop the cache; any other ``.data`` write needs ``mas_hip.ops.invalidate_weight_cache()``.
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        ops.invalidate_weight_cache()
+
+    def train(self, mode: bool = True):
+        if mode != self.training:
+            ops.invalidate_weight_cache()
+        return super().train(mode)
+
     def forward(self, x, residual=None, upsample=False):
         if self.kernel_size[0] != self.kernel_size[1] or self.kernel_size[0] not in (1, 3) or self.stride[0] not in (1, 2) \
                 or self.dilation != (1, 1) or self.groups != 1:
@@ -273,9 +285,14 @@ class Codebook(nn.Module):
         self.reservoir = self.reservoir[keep].detach()
 
     def _reinit_from_reservoir(self):
-        # reference modules.py:487-499 (needs an initialised process group there, too)
+        # reference modules.py:487-499.  Two departures, both fixing reference defects that would break training here:
+        # (i) no process group (single-GPU run) -> world size 1 instead of the reference's crash in dist.get_world_size();
+        # (ii) every rank clusters the same gathered pool, but from its OWN random initial centroids, so the replicas'
+        #      codebooks drift apart and nothing re-synchronises them (DDP broadcasts parameters only at construction):
+        #      rank 0's centroids are broadcast instead.
         from .kmeans import kmeans_fit
-        world_size = dist.get_world_size()
+        distributed = dist.is_available() and dist.is_initialized()
+        world_size = dist.get_world_size() if distributed else 1
         print("Updating codebook from reservoir.")
         if world_size > 1:
             gathered = [torch.zeros_like(self.reservoir) for _ in range(world_size)]
@@ -283,7 +300,10 @@ class Codebook(nn.Module):
             pool = torch.cat(gathered, dim=0)
         else:
             pool = self.reservoir
-        self.embedding.weight.data = kmeans_fit(pool, self.codebook_size).detach()
+        cent = kmeans_fit(pool, self.codebook_size).detach().contiguous()
+        if world_size > 1:
+            dist.broadcast(cent, 0)
+        self.embedding.weight.data = cent
 
     def forward(self, z):
         z = ops.nhwc(z, torch.float32)                    # b c h w logical, NHWC memory: the flatten is a view

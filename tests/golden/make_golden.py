@@ -92,10 +92,23 @@ def seg128():
                         **{k: (v[:, ::8] if v.ndim == 4 and v.shape[1] > 64 else v) for k, v in sg.items() if k.startswith("grad:")})
 
 
+def img256():
+    """full VQ-IMG 256^2 (conf/img_config.yaml model block), B=1, fwd+bwd: sub-sampled activations (fixture size) plus the
+    FULL latents z / z_q (the bf16 parity test feeds the reference's z_q to our decoder and compares latents end to end)."""
+    xi = synth_image_batch(1, 3, 256, seed=1)
+    im = run_vq(IMG, xi, seed=1, scale=1.0, train=True, grads=["decoder.model.28.weight", "encoder.model.0.weight"])
+    np.savez_compressed(os.path.join(HERE, "vq_img256.npz"), rec_sub=im["rec"][:, :, ::8, ::8], q_loss=im["q_loss"],
+                        loss=im["loss"], idx=im["idx"], z_sub=im["z"][:, ::8], h_sub=im["h"][:, ::8], z=im["z"], z_q=im["z_q"],
+                        gradnorm_total=im["gradnorm_total"], **{k: v for k, v in im.items() if k.startswith("grad:")})
+
+
 def main():
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "seg128":          # only the config-1 fixture
         seg128()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "img256":          # only the config-2 (B=1) fixture
+        img256()
         return
     seg128()
     # ---- tiny VQ: full tensors, train + eval, fwd + bwd ------------------------
@@ -109,12 +122,7 @@ def main():
     xs = synth_image_batch(2, 159, 16, seed=3)
     sg = run_vq(seg, xs, seed=3, scale=1.0, train=True, grads=["encoder.model.0.weight", "decoder.model.16.weight"])
     np.savez_compressed(os.path.join(HERE, "vq_seg_tiny.npz"), **{"train:" + k: v for k, v in sg.items()})
-    # ---- full VQ-IMG 256^2, B=1 : sub-sampled tensors (fixture size) -------------
-    xi = synth_image_batch(1, 3, 256, seed=1)
-    im = run_vq(IMG, xi, seed=1, scale=1.0, train=True, grads=["decoder.model.28.weight", "encoder.model.0.weight"])
-    np.savez_compressed(os.path.join(HERE, "vq_img256.npz"), rec_sub=im["rec"][:, :, ::8, ::8], q_loss=im["q_loss"],
-                        loss=im["loss"], idx=im["idx"], z_sub=im["z"][:, ::8], h_sub=im["h"][:, ::8],
-                        gradnorm_total=im["gradnorm_total"], **{k: v for k, v in im.items() if k.startswith("grad:")})
+    img256()
     # ---- codebook lookup alone (the bit-exact gate), default-init + scaled -------
     rs = np.random.RandomState(7)
     z = torch.from_numpy(rs.randn(4, 256, 16, 16).astype(np.float32))

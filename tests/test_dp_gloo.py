@@ -179,3 +179,69 @@ def test_grad_reducer_two_ranks_equals_full_batch(tmp_path):
             for p in net.parameters():
                 if p.grad is not None:
                     p.sub_(0.1 * p.grad)
+
+
+# --------------------------------------------------------------------------------------------------------
+# gradient accumulation (reference conf/img_config.yaml:13 accumulate_grad): k-1 micro-steps under no_sync(),
+# the k-th synchronising; a second synchronising backward before finish() must raise, not race
+# --------------------------------------------------------------------------------------------------------
+def _accum_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    sys.path.insert(0, os.path.join(ROOT, "make-a-scene_amd"))
+    from mas_hip.dp import GradReducer
+    net, x, y = _toy()
+    red = GradReducer(net.parameters(), bucket_bytes=1200)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    res = {}
+    for step, to_none in enumerate((True, False)):
+        with red.no_sync():
+            ((net(xs[:2]) - ys[:2]) ** 2).mean().backward()           # micro-step 1: local accumulation only
+        ((net(xs[2:]) - ys[2:]) ** 2).mean().backward()               # micro-step 2: reduces the accumulated sum
+        red.finish()
+        for k, p in net.named_parameters():
+            res[f"s{step}.{k}"] = p.grad.clone().numpy()
+        for p in net.parameters():
+            if to_none:
+                p.grad = None
+            else:
+                p.grad.zero_()
+    # misuse: two synchronising backward passes without finish() in between
+    raised = False
+    ((net(xs) - ys) ** 2).mean().backward()
+    try:
+        ((net(xs) - ys) ** 2).mean().backward()
+    except RuntimeError as e:
+        raised = "no_sync" in str(e)
+    red.finish()
+    res["raised"] = np.array(raised)
+    if rank == 0:
+        np.savez(out, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_accumulation_and_misuse(tmp_path):
+    if not dist.is_gloo_available():
+        pytest.skip("gloo unavailable")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "acc.npz")
+    mp.spawn(_accum_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    assert bool(got["raised"])
+    net, x, y = _toy()
+    exp = {k: np.zeros(tuple(p.shape), np.float32) for k, p in net.named_parameters()}
+    for rank in range(2):
+        for lo in (0, 2):
+            net.zero_grad(set_to_none=True)
+            sl = slice(rank * 4 + lo, rank * 4 + lo + 2)
+            ((net(x[sl]) - y[sl]) ** 2).mean().backward()
+            for k, p in net.named_parameters():
+                if p.grad is not None:
+                    exp[k] += p.grad.numpy() / 2.0                    # average over ranks of the per-rank accumulated sum
+    for step in range(2):
+        for k in exp:
+            assert np.allclose(got[f"s{step}.{k}"], exp[k], rtol=1e-5, atol=1e-6), (step, k)

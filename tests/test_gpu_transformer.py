@@ -33,7 +33,8 @@ def _restore_dtype():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 4, 24, 16), (1, 2, 200, 64), (2, 16, 1536, 64), (1, 3, 130, 32), (2, 2, 333, 64), (1, 1, 65, 64)])
+@pytest.mark.parametrize("shape", [(2, 4, 24, 16), (1, 2, 200, 64), (2, 16, 1536, 64), (1, 3, 130, 32), (2, 2, 333, 64), (1, 1, 65, 64),
+                                   (2, 2, 200, 128), (1, 8, 1536, 128), (1, 1, 65, 128)])    # head_dim 128: bf16 forward fast path + generic backward
 def test_causal_attention_vs_oracle(shape, dtype):
     from mas_hip import ops
     from oracle import transformer_oracle as TO
@@ -52,9 +53,8 @@ def test_causal_attention_vs_oracle(shape, dtype):
     ref = torch.matmul(probs, v).permute(0, 2, 1, 3).reshape(b, s, d)
     go = torch.from_numpy(rs.randn(b, s, d).astype(np.float32))
     ref.backward(go)
-    ops.set_compute_dtype(dtype)
     x = qkv.clone().to(dev).requires_grad_(True)
-    out = ops.causal_attention(x, h)
+    out = ops.causal_attention(x, h, dtype=dtype)          # fp32 leaf, arithmetic forced to `dtype`
     out.backward(go.to(dev))
     assert relerr(out, ref) < TOL[dtype]
     assert relerr(x.grad, ref_in.grad) < 2 * TOL[dtype]
@@ -85,23 +85,68 @@ def test_make_a_scene_fp32_vs_reference_golden(golden_dir):
             assert relerr(params[k[5:]].grad, g[k]) < 5e-3, k
 
 
-def test_make_a_scene_bf16_logits_close(golden_dir):
-    """production precision of the attention core (bf16 MFMA operands, fp32 softmax): logits within 3e-2 of max|logit|."""
-    from mas_hip import ops
+def test_make_a_scene_autocast_bf16_vs_reference_golden(golden_dir):
+    """The mode bench.py --workload transformer / tools/bench_transformer.py time: fp32 parameters and residual stream,
+    ``torch.autocast(bfloat16)`` around the forward (bf16 library GEMMs, bf16 attention kernels fed by the bf16 qkv
+    projection, fp32->bf16 / bf16->fp32 LayerNorm variants, bf16 GELU).  Logits AND gradients against the reference's own
+    fp32 output: logits within 3e-2 of max|logit|, loss within 1e-2, parameter gradients within 6e-2 of their max."""
     from models.transformer import MakeAScene
     from oracle import transformer_oracle as TO
     dev = _dev()
     g = np.load(os.path.join(golden_dir, "transformer_tiny.npz"))
     cfg = dict(num_layers=2, hidden_dim=64, num_attn_heads=4, image_vocab_size=96, seg_vocab_size=40, text_vocab_size=58,
                image_tokens_per_dim=4, seg_tokens_per_dim=2, text_length=8)
-    ops.set_compute_dtype(torch.bfloat16)
     m = MakeAScene(**cfg)
     m.load_state_dict(TO.synth_transformer_state_dict(cfg, seed=5), strict=True)
     m = m.to(dev)
     text, seg, img = (t.to(dev) for t in TO.synth_tokens(cfg, batch=2, seed=5))
-    with torch.no_grad():
-        logits = m(text, seg, img)
-    assert relerr(logits, g["logits"]) < 3e-2
+    seen = []
+    import mas_hip.ops as O
+    orig = O._CausalAttention.forward
+
+    def spy(ctx, qkv, n_heads, cd):
+        seen.append((qkv.dtype, cd))
+        return orig(ctx, qkv, n_heads, cd)
+    O._CausalAttention.forward = staticmethod(spy)
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits = m(text, seg, img)
+    finally:
+        O._CausalAttention.forward = staticmethod(orig)
+    assert seen and all(a == torch.bfloat16 and b == torch.bfloat16 for a, b in seen)      # the bf16 kernels really ran
+    loss = torch.nn.functional.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), img.reshape(-1))
+    loss.backward()
+    e_log = relerr(logits, g["logits"])
+    print("autocast bf16 MakeAScene: logits relerr %.3e, loss %.5f vs %.5f" % (e_log, float(loss), float(g["loss"])))
+    assert e_log < 3e-2
+    assert abs(float(loss) - float(g["loss"])) < 1e-2 * abs(float(g["loss"]))
+    params = dict(m.named_parameters())
+    for k in g.files:
+        if k.startswith("grad:"):
+            e = relerr(params[k[5:]].grad, g[k])
+            print("  grad", k[5:], "relerr %.3e" % e)
+            assert params[k[5:]].grad.dtype == torch.float32 and e < 6e-2, k
+
+
+def test_make_a_scene_fp32_input_runs_fp32_attention():
+    """No autocast, fp32 parameters (the reference's train_transformer loop, train.py:150): the attention core follows the
+    input dtype, i.e. exact-fp32 kernels -- not a silent bf16 downcast."""
+    import mas_hip.ops as O
+    dev = _dev()
+    seen = []
+    orig = O._CausalAttention.forward
+
+    def spy(ctx, qkv, n_heads, cd):
+        seen.append(cd)
+        return orig(ctx, qkv, n_heads, cd)
+    O._CausalAttention.forward = staticmethod(spy)
+    try:
+        O.set_compute_dtype(torch.bfloat16)                  # the conv stack's global default must not leak into the transformer
+        x = torch.randn(1, 40, 3 * 64, device=dev)
+        y = O.causal_attention(x, 2)
+    finally:
+        O._CausalAttention.forward = staticmethod(orig)
+    assert seen == [torch.float32] and y.dtype == torch.float32
 
 
 def _gelu_ref(x):
@@ -176,7 +221,6 @@ def test_causal_attention_full_size_properties():
     dev = _dev()
     b, h, s, hd = 2, 16, 1536, 64
     d = h * hd
-    ops.set_compute_dtype(torch.bfloat16)
     g = torch.Generator(device="cpu").manual_seed(3)
     qkv = torch.randn(b, s, 3 * d, generator=g).bfloat16().to(dev)
     ones = qkv.clone()

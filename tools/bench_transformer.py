@@ -17,7 +17,6 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = MakeAScene(a.layers, 1024, 16, 8192, 256, 49408 + 256, 32, 16, 256).to(dev)
-ops.set_compute_dtype(torch.bfloat16)
 text = torch.randint(1, 49408, (a.batch, 256), device=dev); text[:, 200:] = 0
 seg = torch.randint(0, 256, (a.batch, 256), device=dev)
 img = torch.randint(0, 8192, (a.batch, 1024), device=dev)

@@ -80,7 +80,6 @@ def main():
     elif a.kind == "attn":
         b, h, sq, hd = a.n, 16, a.hw if a.hw != 256 else 1536, 64
         qkv = torch.randn(b, sq, 3 * h * hd, device=dev).to(dt).requires_grad_(True)
-        ops.set_compute_dtype(dt)
         fl = 4.0 * b * h * sq * sq * hd / 2          # causal: half of the full S x S products
         ms = timeit(lambda: ops.causal_attention(qkv.detach(), h), a.iters)
         print(f"attn fwd B={b} H={h} S={sq} hd={hd} {a.dtype}: {ms:.4f} ms  {fl/ms/1e9:.1f} TFLOP/s (causal FLOPs)")
