@@ -15,7 +15,7 @@
 // are issued into registers before the MFMA phase of the current one, so their HBM latency hides
 // under 9 taps of MFMAs.  Pixel rows are exactly 128 B; bank conflicts are removed by XOR-swizzling the
 // 16-byte slot index with (patch_column>>1)&7 instead of padding.
-// Weights: mas_pack_conv_weight emits the swizzled LDS image of every [tap][chunk][cout] row, so a
+// Weights: mas_pack_conv_weight emits the swizzled LDS image of every [chunk][tap][cout] row, so a
 // weight tile is a linear, perfectly coalesced 16-byte copy (global -> registers one tap ahead ->
 // ds_write_b128) into a double buffer; one barrier per tap.  All global loads are ordinary loads, so
 // hipcc's counted s_waitcnt vmcnt(N) keeps the patch prefetch (issued one slot per tap, after that
@@ -214,15 +214,19 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_fwd_kernel(ConvParams
     // Double buffer: the DMA of stage s+1 is issued right after the barrier of stage s and is drained by the
     // vmcnt(0) hipcc puts in front of the next __syncthreads() -- it has the whole MFMA phase of stage s to land.
     constexpr int W_DMA = TPS * BC * 128 / 1024 / NWAVE;
+    // MUBUF form (`buffer_load ... lds`), not `global_load_lds`: hipcc counts the FLAT-encoded instruction as a possible LDS
+    // access ("pending flat") and then turns every lgkmcnt wait in front of an MFMA into lgkmcnt(0), which serialises the
+    // software-pipelined fragment reads.
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Wimg), 0,
+                                                                           (unsigned)(NTAP * p.n_chunks * p.Cout_pad * 128), 0x00020000);
     auto w_issue = [&](int stage, int ch, int c0, int buf) {
 #pragma unroll
         for (int k = 0; k < W_DMA; ++k) {
-            const int piece = wave * W_DMA + k;                 // 1-KiB piece of the TPS-tile stage
+            const int piece = __builtin_amdgcn_readfirstlane(wave) * W_DMA + k;   // 1-KiB piece of the TPS-tile stage
             const int tt = piece / (BC / 8), row8 = piece % (BC / 8);
-            const unsigned char* src = Wimg + ((size_t)((stage * TPS + tt) * p.n_chunks + ch) * p.Cout_pad + c0) * 128 + row8 * 1024 + lane * 16;
-            unsigned char* dst = wbuf + buf * (TPS * WT_BYTES) + piece * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            const int soff = ((ch * NTAP + stage * TPS + tt) * p.Cout_pad + c0) * 128 + row8 * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(wbuf + buf * (TPS * WT_BYTES) + piece * 1024),
+                                                     16, lane * 16, soff, 0, 0);
         }
     };
     auto w_commit = [&](int) {};
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_fwd_kernel(ConvParams
     auto w_issue = [&](int stage, int ch, int c0, int) {
 #pragma unroll
         for (int tt = 0; tt < TPS; ++tt) {
-            const unsigned char* src = Wimg + ((size_t)((stage * TPS + tt) * p.n_chunks + ch) * p.Cout_pad + c0) * 128 + tid * 16;
+            const unsigned char* src = Wimg + ((size_t)(ch * NTAP + stage * TPS + tt) * p.Cout_pad + c0) * 128 + tid * 16;
 #pragma unroll
             for (int k = 0; k < W_PER_T; ++k) wreg[tt * W_PER_T + k] = *reinterpret_cast<const u32x4*>(src + k * NT * 16);
         }
@@ -587,6 +591,9 @@ int launch_ks(const ConvParams& p, int ks, int stride, hipStream_t s) {
 
 }  // namespace
 
+int mas_conv3x3_stream_try(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed, const float* bias,
+                           const void* residual, void* y, hipStream_t s);   // conv3x3_stream.hip
+
 extern "C" int mas_conv_fwd(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed,
                             const float* bias, const void* residual, void* y, void* stream) {
     MAS_ENTER();
@@ -596,6 +603,10 @@ extern "C" int mas_conv_fwd(const MasConvDesc* d, const void* x, const float* sc
         MAS_FAIL(MAS_EINVAL, "conv_fwd: non-positive dimension");
     if (d->upsample && d->stride != 1) MAS_FAIL(MAS_EUNSUPPORTED, "conv_fwd: upsample fold needs stride 1");
     if ((long long)d->H * d->W * d->Cin > 0x7fffffffLL) MAS_FAIL(MAS_EUNSUPPORTED, "conv_fwd: one image exceeds 2^31 elements");
+    {   // the FLOP-carrying shapes (3x3, stride 1, bf16, Cin/Cout multiples of 128) take the stream-scheduled kernel
+        const int rc = mas_conv3x3_stream_try(d, x, scale_shift, w_packed, bias, residual, y, reinterpret_cast<hipStream_t>(stream));
+        if (rc != 0) return rc < 0 ? rc : MAS_OK;
+    }
     ConvParams p;
     p.dbg = nullptr;
 #ifdef MAS_TIMELINE          // s_memtime timeline builds only (tools/build_variant.sh tl -DMAS_TIMELINE)

@@ -31,7 +31,8 @@ extern "C" int mas_abi_version(void) {
 namespace {
 constexpr int NT = 256;
 
-// OIHW fp32 -> the LDS image the conv kernels copy linearly: [tap][chunk][row][128 B], where a 128-byte row
+// OIHW fp32 -> the LDS image the conv kernels copy linearly: [chunk][tap][row][128 B] (consecutive tap-steps of a tile's
+// K loop are consecutive in memory: the stream kernel addresses step t at t * rows_pad * 128), where a 128-byte row
 // holds CK = 128/sizeof(T) consecutive K elements as eight 16-byte slots and slot position sp stores logical
 // slot sp ^ ((row>>1)&7) (the bank-conflict swizzle of conv_fwd.hip).  See mas_hip.h for the two modes.
 template <typename T>
@@ -43,8 +44,8 @@ __global__ __launch_bounds__(NT) void pack_weight_kernel(const float* __restrict
     for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
         const int pos = (int)(i % CK);
         const int row = (int)((i / CK) % rows_pad);
-        const int ch = (int)((i / ((long long)CK * rows_pad)) % n_chunks);
-        const int t = (int)(i / ((long long)CK * rows_pad * n_chunks));
+        const int t = (int)((i / ((long long)CK * rows_pad)) % (ks * ks));
+        const int ch = (int)(i / ((long long)CK * rows_pad * ks * ks));
         const int sp = pos / EPU, e = pos % EPU;
         const int col = ch * CK + ((sp ^ ((row >> 1) & 7)) * EPU) + e;
         const int kh = t / ks, kw = t % ks;
