@@ -19,8 +19,8 @@ for mode in 0 1 3; do
 done
 } 2>&1 | tee $O/kbench.txt
 echo "== pytest"
-timeout 1200 python -m pytest tests -m gpu -q -x --timeout 900 2>&1 | tail -25 | tee $O/pytest.txt
-echo "== pytest -s parity prints"
-grep -h "img256 bf16\|fwd plain\|fwd GN\|dgrad:\|wgrad act\|autocast bf16\|grad " $O/pytest.txt | head
+timeout 1500 python -m pytest tests -m gpu -q -rP --timeout 900 > $O/pytest_full.txt 2>&1; tail -15 $O/pytest_full.txt
+echo "== parity prints"
+grep -h "img256 bf16\|fwd plain\|fwd GN\|^dgrad:\|wgrad act\|autocast bf16\|  grad \|FAILED\|Error" $O/pytest_full.txt | head -40
 echo "== bench"
 timeout 600 python bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err; cut -c1-1500 $O/bench.json; tail -3 $O/bench.err
