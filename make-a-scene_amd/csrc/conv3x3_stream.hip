@@ -251,6 +251,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
         p_activate(inb_cur, 0, 3, 3);
     }
     const int n_pairs = p.n_chunks >> 1;
+#ifdef S_DEBUG_DUMP      // debug build: dump weight stage 0 (32 KiB) + patch buffer 0 (41 KiB) of work-group 0's first tile into y
+    S_WAIT_BARRIER(0);
+    if (blockIdx.x == 0) {
+        for (int i = tid; i < S_WSTAGE / 16; i += 512) reinterpret_cast<u32x4*>(p.y)[i] = *reinterpret_cast<const u32x4*>(wbuf + i * 16);
+        for (int i = tid; i < S_PATCH / 16; i += 512) reinterpret_cast<u32x4*>(p.y + S_WSTAGE)[i] = *reinterpret_cast<const u32x4*>(patch + i * 16);
+    }
+    return;
+#endif
 
     for (;;) {
         const int next_tile = tile + (int)gridDim.x;
