@@ -294,6 +294,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
                     else if (s == 0 && imm_stores) { s_wait_barrier(8); imm_stores = false; }   // younger than stage 0's weight DMA
                     else s_wait_barrier(npatch);
                 }
+#ifdef S_DEBUG_DUMP_STAGE   // debug build: the weight stage + both patch buffers as stage S_DEBUG_DUMP_STAGE of work-group 0 sees them -> p.res
+                if (s == S_DEBUG_DUMP_STAGE && blockIdx.x == 0 && tile == 0 && pair == 0) {
+                    unsigned char* dd = const_cast<unsigned char*>(p.res);
+                    for (int i = tid; i < S_WSTAGE / 16; i += 512) reinterpret_cast<u32x4*>(dd)[i] = *reinterpret_cast<const u32x4*>(wbuf + wsel * S_WSTAGE + i * 16);
+                    for (int i = tid; i < 2 * S_PATCH / 16; i += 512) reinterpret_cast<u32x4*>(dd + S_WSTAGE)[i] = *reinterpret_cast<const u32x4*>(patch + i * 16);
+                }
+#endif
                 // ---- register path: commit what was loaded two stages ago (guaranteed landed by the wait above)
                 if constexpr (ACT) {
                     if (s == 2) p_activate(inb_cur, 1, 0, 3);
