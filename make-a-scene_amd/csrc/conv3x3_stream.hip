@@ -410,9 +410,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
                         float v[8];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, acc[i][j][(2 * qp) * 4 + e]),
-                                                                             __builtin_bit_cast(unsigned, acc[i][j][(2 * qp + 1) * 4 + e]), false, false);
-                            v[e] = __builtin_bit_cast(float, r[0]); v[4 + e] = __builtin_bit_cast(float, r[1]);
+                            // (copy the vector elements to scalars first: __builtin_bit_cast applied directly to an ext-vector
+                            //  element lvalue reads element 0 of the vector, whatever the index)
+                            const float qa = acc[i][j][(2 * qp) * 4 + e], qb = acc[i][j][(2 * qp + 1) * 4 + e];
+                            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(qa), __float_as_uint(qb), false, false);
+                            v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
                         }
                         const bf16_t* rb = reinterpret_cast<const bf16_t*>(&rv[i][qp]);
                         u32x4 o;
