@@ -7,8 +7,18 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_out
 timeout 200 rocprofv3 --pmc $CNT --kernel-trace -d /tmp/pmc_out -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/tools/kbench.py "$@" --iters 3 > /tmp/pmc.log 2>&1 || { tail -5 /tmp/pmc.log; exit 1; }
 f=$(find /tmp/pmc_out -name "*counter_collection.csv" | head -1)
-python3 - "$f" <<'PY'
+k=$(find /tmp/pmc_out -name "*kernel_trace.csv" | head -1)
+python3 - "$f" "$k" <<'PY'
 import csv, sys, collections
+try:      # per-kernel average duration of the SAME profiled run (clock = cycles / duration)
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(sys.argv[2])):
+        dur[r["Kernel_Name"][:60]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for k_, v in dur.items():
+        if "conv" in k_ or "gn_" in k_ or "attn" in k_ or "vq" in k_:
+            print(k_, "avg duration us under profiling", round(sum(v) / len(v) / 1e3, 1), "n", len(v))
+except Exception as e:
+    print("no kernel trace:", e)
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 seen = set()
 for r in csv.DictReader(open(sys.argv[1])):
