@@ -27,6 +27,7 @@ template <int... I, typename F>
 __device__ __forceinline__ void s_static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
 struct StreamParams {
+    unsigned long long* dbg;                   // -DS_TIMELINE builds only (tools/timeline_stream.py): s_memtime stamps of one work-group
     const unsigned char* x; const float* ss; const unsigned char* w; const float* bias; const unsigned char* res; unsigned char* y;
     int N, H, W, Cin, Ho, Wo, Cout;
     int Hl, Wl, pad_top, pad_left, upsample, act;
@@ -48,6 +49,13 @@ constexpr int S_OOB = (int)0x80000000;         // voffset beyond any descriptor'
                                asm volatile("" ::: "memory"); } while (0)
 #else   // timing experiment only (races): what do the 9 work-group barriers per pair cost?
 #define S_WAIT_BARRIER(N) do { asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory"); asm volatile("" ::: "memory"); } while (0)
+#endif
+
+#ifdef S_TIMELINE      // stamps only where no ds_read is in flight (s_memtime returns through lgkmcnt)
+#define STS(id) do { if (lane == 0 && blockIdx.x == 100 && tl_iter >= 1 && tl_iter < 3 && p.dbg) \
+                         p.dbg[((tl_iter - 1) * 8 + wave) * 64 + (id)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STS(id) do {} while (0)
 #endif
 
 __device__ __forceinline__ void s_wait_barrier(int n) {   // n is compile-time after unrolling, or selected by a uniform branch
@@ -260,10 +268,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
     return;
 #endif
 
+#ifdef S_TIMELINE
+    int tl_iter = 0;
+#endif
     for (;;) {
         const int next_tile = tile + (int)gridDim.x;
         const bool has_next = next_tile < total_tiles;
         const Tile nxt = has_next ? decode(next_tile) : cur;
+        STS(0);
 
         f32x16 acc[2][2];
 #pragma unroll
@@ -286,6 +298,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
                 constexpr int s = decltype(s_c)::value;
                 // ---- barrier(s): stage s's weights, and every patch chunk it reads, are visible; stage s-1's buffers are free.
                 //      vmcnt allowance = the VMEM operations issued AFTER the weight DMA in stage s-1 (they may stay in flight)
+                if (pair == 0) STS(1 + 3 * s);
                 {
                     constexpr int sp = (s + 8) % 9;           // previous stage (of this or the previous pair)
                     constexpr int npatch = ACT ? ((sp == 0 || sp == 5) ? 7 : ((sp == 1 || sp == 6) ? 3 : 0))
@@ -294,6 +307,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
                     else if (s == 0 && imm_stores) { s_wait_barrier(8); imm_stores = false; }   // younger than stage 0's weight DMA
                     else s_wait_barrier(npatch);
                 }
+                if (pair == 0) STS(2 + 3 * s);
 #ifdef S_DEBUG_DUMP_STAGE   // debug build: the weight stage + both patch buffers as stage S_DEBUG_DUMP_STAGE of work-group 0 sees them -> p.res
                 if (s == S_DEBUG_DUMP_STAGE && blockIdx.x == 0 && tile == 0 && pair == 0) {
                     unsigned char* dd = const_cast<unsigned char*>(p.res);
@@ -343,6 +357,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
                     if (s < 8 && do_store) store_one(s);
                 }
                 asm volatile("" ::: "memory");
+                if (pair == 0) STS(3 + 3 * s);
                 // ---- 2 tap-steps = 8 k-steps of 4 MFMAs; fragment reads software-pipelined one k-step ahead
                 {
                     const unsigned char* wb = wbuf + wsel * S_WSTAGE;
@@ -378,6 +393,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
             });
         }
 
+        STS(40);
+#ifdef S_ABL_NOEPIALL   // timing experiment only: no epilogue at all (the accumulators are consumed by an impossible store)
+        if (p.N != -12345) {
+            float t = 0.0f;
+            for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+            if (t == 123.456f) reinterpret_cast<float*>(p.y)[0] = t;
+        } else
+#endif
         // ---- epilogue: lanes l / l+32 exchange accumulator quads (fp32) so each lane owns 8 consecutive couts of its pixel;
         //      bias and residual arrive by UNCONDITIONAL buffer loads (a null pointer is a zero-length descriptor that returns
         //      zeros): no per-load branches, so hipcc batches the 24 loads instead of waiting for each one
@@ -430,6 +453,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
             pending_out = DEFER;
             imm_stores = !DEFER;
         }
+        STS(41);
+#ifdef S_TIMELINE
+        ++tl_iter;
+#endif
         if (!has_next) break;
         tile = next_tile; cur = nxt; rs_cur = rs_nxt; inb_cur = inb_nxt;
 #pragma unroll
@@ -477,6 +504,10 @@ int mas_conv3x3_stream_try(const MasConvDesc* d, const void* x, const float* sca
     const long long out_bytes = (long long)d->N * d->Ho * d->Wo * d->Cout * 2;
     if (img_bytes >= 0x7fffffffLL || out_bytes >= 0x7fffffffLL) return 0;
     StreamParams p;
+    p.dbg = nullptr;
+#ifdef S_TIMELINE
+    if (const char* e = getenv("MAS_DBG_PTR")) p.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
+#endif
     p.x = (const unsigned char*)x; p.ss = scale_shift; p.w = (const unsigned char*)w_packed; p.bias = bias;
     p.res = (const unsigned char*)residual; p.y = (unsigned char*)y;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
