@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAS_ABI_VERSION 1
+#define MAS_ABI_VERSION 2
 
 enum { MAS_OK = 0, MAS_EINVAL = -1, MAS_EUNSUPPORTED = -2, MAS_ELAUNCH = -3, MAS_EWORKSPACE = -4 };
 enum { MAS_F32 = 0, MAS_BF16 = 1 };
@@ -48,6 +48,8 @@ typedef struct MasConvDesc {
     int32_t act;                /* MAS_ACT_* prologue applied to x on load (padding stays exactly 0) */
     int32_t upsample;           /* 1: logical input is nearest-x2 of x (F.interpolate, modules.py:56): pixel (h,w) reads x[h>>1][w>>1];
                                    H,W above are then the PHYSICAL (pre-upsample) size */
+    int32_t w_layout;           /* MAS_WLAYOUT_*: how w_packed was packed; mas_conv_fwd requires mas_conv_weight_layout(d)
+                                   or MAS_WLAYOUT_K64 (always accepted); ignored by mas_conv_wgrad */
 } MasConvDesc;
 
 int         mas_abi_version(void);
@@ -64,6 +66,15 @@ const char* mas_last_error(void);
 size_t mas_packed_weight_elems(int Cout, int Cin, int ks);
 int    mas_pack_conv_weight(const float* w_oihw, void* packed, int Cout, int Cin, int ks,
                             int transpose, int dtype, void* stream);
+/* Two LDS images exist.  MAS_WLAYOUT_K64 (what mas_pack_conv_weight emits; every kernel but one reads it):
+ * [Cin/64 chunks][tap][Cout_pad][128 B], 16-byte slots XOR-swizzled with (row>>1)&7.  MAS_WLAYOUT_K32 (bf16 only; the
+ * wide 3x3 kernel, conv3x3_wide.hip): [Cin/32 chunks][tap][Cout_pad][64 B], slots XOR-swizzled with (row>>2)&3.
+ * mas_conv_weight_layout(d) tells which image mas_conv_fwd prefers for a convolution; a K64 image is always accepted
+ * (the call then takes the kernels that read it).  Same buffer size for both (mas_packed_weight_elems).            */
+enum { MAS_WLAYOUT_K64 = 0, MAS_WLAYOUT_K32 = 1 };
+int    mas_conv_weight_layout(const MasConvDesc* d);
+int    mas_pack_conv_weight_layout(const float* w_oihw, void* packed, int Cout, int Cin, int ks,
+                                   int transpose, int dtype, int layout, void* stream);
 
 /* ---- GroupNorm statistics (replaces the reduction half of torch.nn.GroupNorm,
  * modules.py:40-41).  x: [N,HW,C] NHWC.  Outputs:

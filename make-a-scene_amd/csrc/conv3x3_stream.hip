@@ -259,6 +259,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
         p_activate(inb_cur, 0, 3, 3);
     }
     const int n_pairs = p.n_chunks >> 1;
+#ifdef S_PRIO_HALF   // MI355X_MICROARCH.md "Two waves per SIMD" item 4: static priority for the second-dispatched half
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 #ifdef S_DEBUG_DUMP      // debug build: dump weight stage 0 (32 KiB) + patch buffer 0 (41 KiB) of work-group 0's first tile into y
     S_WAIT_BARRIER(0);
     if (blockIdx.x == 0) {
@@ -330,6 +333,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
                     w_issue(tn, c0n, wsel ^ 1);
                 }
                 asm volatile("" ::: "memory");                // VMEM order = source order: the counted waits depend on it
+                auto late_ops = [&]() {
                 // ---- patch operations for later chunks
                 // (ACT: 3 pieces in each of two stages + the chunk's scale/shift, then the in-place activation two stages later;
                 //  plain: 2 pieces in each of three stages)
@@ -357,6 +361,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
                     if (s < 8 && do_store) store_one(s);
                 }
                 asm volatile("" ::: "memory");
+                };
+#ifndef S_LATE_ISSUE
+                late_ops();
+#endif
                 if (pair == 0) STS(3 + 3 * s);
                 // ---- 2 tap-steps = 8 k-steps of 4 MFMAs; fragment reads software-pipelined one k-step ahead
                 {
@@ -389,6 +397,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 }
+#ifdef S_LATE_ISSUE   // HBM-facing operations of this stage issued at its END, where the early half of the waves would wait at the barrier anyway
+                asm volatile("" ::: "memory");
+                late_ops();
+#endif
                 wsel ^= 1;
             });
         }

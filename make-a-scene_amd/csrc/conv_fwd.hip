@@ -593,6 +593,14 @@ int launch_ks(const ConvParams& p, int ks, int stride, hipStream_t s) {
 
 int mas_conv3x3_stream_try(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed, const float* bias,
                            const void* residual, void* y, hipStream_t s);   // conv3x3_stream.hip
+bool mas_conv3x3_wide_eligible(const MasConvDesc* d);                        // conv3x3_wide.hip
+int mas_conv3x3_wide_launch(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed, const float* bias,
+                            const void* residual, void* y, hipStream_t s);
+
+extern "C" int mas_conv_weight_layout(const MasConvDesc* d) {
+    if (!d) return MAS_WLAYOUT_K64;
+    return mas_conv3x3_wide_eligible(d) ? MAS_WLAYOUT_K32 : MAS_WLAYOUT_K64;
+}
 
 extern "C" int mas_conv_fwd(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed,
                             const float* bias, const void* residual, void* y, void* stream) {
@@ -603,6 +611,11 @@ extern "C" int mas_conv_fwd(const MasConvDesc* d, const void* x, const float* sc
         MAS_FAIL(MAS_EINVAL, "conv_fwd: non-positive dimension");
     if (d->upsample && d->stride != 1) MAS_FAIL(MAS_EUNSUPPORTED, "conv_fwd: upsample fold needs stride 1");
     if ((long long)d->H * d->W * d->Cin > 0x7fffffffLL) MAS_FAIL(MAS_EUNSUPPORTED, "conv_fwd: one image exceeds 2^31 elements");
+    if (d->w_layout == MAS_WLAYOUT_K32) {   // the caller packed for the wide 3x3 kernel (mas_conv_weight_layout said so)
+        if (!mas_conv3x3_wide_eligible(d)) MAS_FAIL(MAS_EINVAL, "conv_fwd: w_layout K32 but this convolution does not take the wide kernel");
+        return mas_conv3x3_wide_launch(d, x, scale_shift, w_packed, bias, residual, y, reinterpret_cast<hipStream_t>(stream));
+    }
+    if (d->w_layout != MAS_WLAYOUT_K64) MAS_FAIL(MAS_EINVAL, "conv_fwd: bad w_layout %d", d->w_layout);
     {   // the FLOP-carrying shapes (3x3, stride 1, bf16, Cin/Cout multiples of 128) take the stream-scheduled kernel
         const int rc = mas_conv3x3_stream_try(d, x, scale_shift, w_packed, bias, residual, y, reinterpret_cast<hipStream_t>(stream));
         if (rc != 0) return rc < 0 ? rc : MAS_OK;

@@ -59,6 +59,28 @@ __global__ __launch_bounds__(NT) void pack_weight_kernel(const float* __restrict
     }
 }
 
+// MAS_WLAYOUT_K32 (bf16): [chunk32][tap][row][64 B]; slot position sp stores logical slot sp ^ ((row>>2)&3) (conv3x3_wide.hip)
+__global__ __launch_bounds__(NT) void pack_weight_k32_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin,
+                                                             int ks, int transpose, int rows_pad, int n_chunks) {
+    const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
+    const long long total = (long long)ks * ks * n_chunks * rows_pad * 32;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+        const int pos = (int)(i % 32);
+        const int row = (int)((i / 32) % rows_pad);
+        const int t = (int)((i / (32LL * rows_pad)) % (ks * ks));
+        const int ch = (int)(i / (32LL * rows_pad * ks * ks));
+        const int sp = pos / 8, e = pos % 8;
+        const int col = ch * 32 + ((sp ^ ((row >> 2) & 3)) * 8) + e;
+        const int kh = t / ks, kw = t % ks;
+        float v = 0.0f;
+        if (row < rows && col < cols) {
+            if (!transpose) v = w[(((size_t)row * Cin + col) * ks + kh) * ks + kw];
+            else v = w[(((size_t)col * Cin + row) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)];
+        }
+        out[i] = (bf16_t)v;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT) void upsample2x_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C) {
     // one thread per 16-byte unit of the OUTPUT
@@ -152,6 +174,22 @@ extern "C" int mas_pack_conv_weight(const float* w_oihw, void* packed, int Cout,
         hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, s, w_oihw, (float*)packed, Cout, Cin, ks, transpose, rows_pad, n_chunks);
     else MAS_FAIL(MAS_EUNSUPPORTED, "pack_conv_weight: dtype %d", dtype);
     MAS_CHECK_LAUNCH("pack_conv_weight");
+    return MAS_OK;
+}
+
+extern "C" int mas_pack_conv_weight_layout(const float* w_oihw, void* packed, int Cout, int Cin, int ks, int transpose, int dtype,
+                                           int layout, void* stream) {
+    if (layout == MAS_WLAYOUT_K64) return mas_pack_conv_weight(w_oihw, packed, Cout, Cin, ks, transpose, dtype, stream);
+    MAS_ENTER();
+    if (!w_oihw || !packed) MAS_FAIL(MAS_EINVAL, "pack_conv_weight: null argument");
+    if (layout != MAS_WLAYOUT_K32) MAS_FAIL(MAS_EINVAL, "pack_conv_weight: bad layout %d", layout);
+    if (dtype != MAS_BF16 || ks != 3 || Cout <= 0 || Cin <= 0) MAS_FAIL(MAS_EUNSUPPORTED, "pack_conv_weight: the K32 image is bf16 / 3x3 only");
+    const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
+    const int rows_pad = mas_roundup(rows, 128), n_chunks = mas_cdiv(cols, 32);
+    const long long total = 9LL * n_chunks * rows_pad * 32;
+    hipLaunchKernelGGL(pack_weight_k32_kernel, dim3(grid_for(total)), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), w_oihw,
+                       (bf16_t*)packed, Cout, Cin, ks, transpose, rows_pad, n_chunks);
+    MAS_CHECK_LAUNCH("pack_conv_weight_k32");
     return MAS_OK;
 }
 

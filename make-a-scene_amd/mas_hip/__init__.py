@@ -17,14 +17,15 @@ LIB_PATH = os.environ.get("MAS_HIP_LIB") or os.path.join(_HERE, "libmas_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_AFFINE, ACT_AFFINE_SILU = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
+WLAYOUT_K64, WLAYOUT_K32 = 0, 1
 
 
 class ConvDesc(C.Structure):
     """Mirror of ``MasConvDesc`` (include/mas_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in (
         "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "ks", "stride", "pad_top", "pad_left",
-        "in_dtype", "out_dtype", "act", "upsample")]
+        "in_dtype", "out_dtype", "act", "upsample", "w_layout")]
 
 
 _p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -33,6 +34,8 @@ _SIGNATURES = {
     "mas_last_error": (C.c_char_p, []),
     "mas_packed_weight_elems": (_sz, [_i, _i, _i]),
     "mas_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "mas_conv_weight_layout": (_i, [C.POINTER(ConvDesc)]),
+    "mas_pack_conv_weight_layout": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mas_gn_stats_workspace": (_sz, [_i, _i]),
     "mas_gn_stats": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _sz, _p]),
     "mas_gn_bwd_workspace": (_sz, [_i, _i]),

@@ -14,7 +14,7 @@ from typing import Optional
 
 import torch
 
-from . import ACT_AFFINE, ACT_AFFINE_SILU, ACT_NONE, BF16, F32, ConvDesc, check, lib
+from . import ACT_AFFINE, ACT_AFFINE_SILU, ACT_NONE, BF16, F32, WLAYOUT_K64, ConvDesc, check, lib
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 _state = {"compute_dtype": torch.bfloat16 if os.environ.get("MAS_COMPUTE_DTYPE", "bf16") == "bf16" else torch.float32}
@@ -79,15 +79,15 @@ class _PackCache:
     def clear(self):
         self.store.clear()
 
-    def get(self, w: torch.Tensor, transpose: bool, dtype: torch.dtype) -> torch.Tensor:
+    def get(self, w: torch.Tensor, transpose: bool, dtype: torch.dtype, layout: int = WLAYOUT_K64) -> torch.Tensor:
         if not isinstance(w, torch.nn.Parameter):
-            return pack_conv_weight(w.detach(), transpose, dtype)
-        key = (id(w), transpose, dtype)
+            return pack_conv_weight(w.detach(), transpose, dtype, layout)
+        key = (id(w), transpose, dtype, layout)
         ver = (w._version, w.data_ptr())
         hit = self.store.get(key)
         if hit is not None and hit[0]() is w and hit[1] == ver:
             return hit[2]
-        packed = pack_conv_weight(w.detach(), transpose, dtype)
+        packed = pack_conv_weight(w.detach(), transpose, dtype, layout)
         self.store[key] = (weakref.ref(w, lambda _r, k=key: self.store.pop(k, None)), ver, packed)
         return packed
 
@@ -102,15 +102,26 @@ def invalidate_weight_cache() -> None:
     _pack_cache.clear()
 
 
-def pack_conv_weight(w: torch.Tensor, transpose: bool, dtype: torch.dtype) -> torch.Tensor:
+def pack_conv_weight(w: torch.Tensor, transpose: bool, dtype: torch.dtype, layout: int = WLAYOUT_K64) -> torch.Tensor:
+    """OIHW fp32 -> the LDS image of ``layout`` (include/mas_hip.h: K64 = every kernel but the wide 3x3 one, K32 = that one)."""
     _require_cuda(w, "pack_conv_weight")
     cout, cin, ks, ks2 = w.shape
     assert ks == ks2
     w = w.contiguous().float()
     n = lib().mas_packed_weight_elems(cout, cin, ks)
     out = torch.empty(n, dtype=dtype, device=w.device)
-    check(lib().mas_pack_conv_weight(_ptr(w), _ptr(out), cout, cin, ks, int(transpose), _DT[dtype], _stream()), "pack_conv_weight")
+    check(lib().mas_pack_conv_weight_layout(_ptr(w), _ptr(out), cout, cin, ks, int(transpose), _DT[dtype], int(layout), _stream()),
+          "pack_conv_weight")
     return out
+
+
+class ConvWeight:
+    """An UNPACKED conv weight handed to ``conv_fwd_raw``: packed there (through the cache when it is an nn.Parameter) in the
+    layout the library prefers for that convolution (``mas_conv_weight_layout``)."""
+    __slots__ = ("w", "transpose")
+
+    def __init__(self, w: torch.Tensor, transpose: bool = False):
+        self.w, self.transpose = w, bool(transpose)
 
 
 # --------------------------------------------------------------------------- #
@@ -140,13 +151,29 @@ def gn_bwd(x, da, dres, groups, act, gamma, mr, ss):
     return dx, dgamma, dbeta
 
 
-def _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, in_dt, out_dt, act, upsample):
-    return ConvDesc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, _DT[in_dt], _DT[out_dt], act, int(upsample))
+def _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, in_dt, out_dt, act, upsample, w_layout=WLAYOUT_K64):
+    return ConvDesc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, _DT[in_dt], _DT[out_dt], act, int(upsample), int(w_layout))
+
+
+_layout_memo = {}
+
+
+def _preferred_layout(d: ConvDesc) -> int:
+    key = tuple(getattr(d, f) for f, _ in ConvDesc._fields_[:-1])
+    lay = _layout_memo.get(key)
+    if lay is None:
+        lay = _layout_memo[key] = int(lib().mas_conv_weight_layout(C.byref(d)))
+    return lay
 
 
 def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, upsample, out_dtype):
+    """``wp``: a ``ConvWeight`` (packed here in the layout the library prefers for this convolution) or an already packed
+    K64 image from ``pack_conv_weight`` (always accepted; the call then stays on the kernels that read K64)."""
     y = _empty_nhwc(n, cout, ho, wo, out_dtype, x.device)
     d = _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, x.dtype, out_dtype, act, upsample)
+    if isinstance(wp, ConvWeight):
+        d.w_layout = _preferred_layout(d)
+        wp = _pack_cache.get(wp.w, wp.transpose, x.dtype, d.w_layout)
 
     def launch():
         check(lib().mas_conv_fwd(C.byref(d), _ptr(x), _ptr(ss), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), _stream()), "conv_fwd")
@@ -226,7 +253,7 @@ class _NormActConv(torch.autograd.Function):
         mr = ss = None
         if act != ACT_NONE:
             mr, ss = gn_stats(x, gn_w.detach().float(), gn_b.detach().float(), cfg["groups"], cfg["eps"])
-        wp = _pack_cache.get(weight, False, cd)
+        wp = ConvWeight(weight, False)
         b32 = bias.detach().float() if bias is not None else None
         res = nhwc(residual, cd) if residual is not None else None
         y = conv_fwd_raw(x, ss, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, cfg["out_dtype"])
@@ -252,7 +279,7 @@ class _NormActConv(torch.autograd.Function):
             dw, db = conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, need_b)
             dw = dw.to(weight.dtype) if need_w else None
         if need_x or need_gn:
-            wt = _pack_cache.get(weight, True, cd)
+            wt = ConvWeight(weight, True)
             hl, wl = (2 * h, 2 * w) if ups else (h, w)
             if stride == 1:
                 d_in, hd, wd = dy, ho, wo
@@ -310,9 +337,9 @@ class _ResBlock(torch.autograd.Function):
         n, c, h, w = x.shape
         f32 = lambda t: t.detach().float()
         mr1, ss1 = gn_stats(x, f32(n1w), f32(n1b), groups, eps)
-        hh = conv_fwd_raw(x, ss1, _pack_cache.get(c1w, False, cd), f32(c1b), None, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU, False, cd)
+        hh = conv_fwd_raw(x, ss1, ConvWeight(c1w, False), f32(c1b), None, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU, False, cd)
         mr2, ss2 = gn_stats(hh, f32(n2w), f32(n2b), groups, eps)
-        y = conv_fwd_raw(hh, ss2, _pack_cache.get(c2w, False, cd), f32(c2b), x, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU, False, cd)
+        y = conv_fwd_raw(hh, ss2, ConvWeight(c2w, False), f32(c2b), x, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU, False, cd)
         ctx.groups, ctx.cd = groups, cd
         ctx.save_for_backward(x, hh, mr1, ss1, mr2, ss2, n1w, c1w, n2w, c2w)
         return y
@@ -329,14 +356,14 @@ class _ResBlock(torch.autograd.Function):
         dw2 = db2 = dw1 = db1 = None
         if ng[7] or ng[8]:
             dw2, db2 = conv_wgrad_raw(hh, ss2, dy, *geo, ACT_AFFINE_SILU, False, True)
-        da2 = conv_fwd_raw(dy, None, _pack_cache.get(c2w, True, cd), None, None, *geo, ACT_NONE, False, cd)
+        da2 = conv_fwd_raw(dy, None, ConvWeight(c2w, True), None, None, *geo, ACT_NONE, False, cd)
         dh, dg2w, dg2b = gn_bwd(hh, da2, None, groups, ACT_AFFINE_SILU, n2w.detach().float(), mr2, ss2)
         # conv1 / norm1 (+ the skip connection's gradient, fused into the GroupNorm-backward apply pass)
         if ng[3] or ng[4]:
             dw1, db1 = conv_wgrad_raw(x, ss1, dh, *geo, ACT_AFFINE_SILU, False, True)
         dx = dg1w = dg1b = None
         if ng[0] or ng[1] or ng[2]:
-            da1 = conv_fwd_raw(dh, None, _pack_cache.get(c1w, True, cd), None, None, *geo, ACT_NONE, False, cd)
+            da1 = conv_fwd_raw(dh, None, ConvWeight(c1w, True), None, None, *geo, ACT_NONE, False, cd)
             dx, dg1w, dg1b = gn_bwd(x, da1, dy, groups, ACT_AFFINE_SILU, n1w.detach().float(), mr1, ss1)
         cast = lambda g, ref: g.to(ref.dtype) if g is not None else None
         return (dx, cast(dg1w, n1w), cast(dg1b, n1w), cast(dw1, c1w), cast(db1, c1w), cast(dg2w, n2w), cast(dg2b, n2w),

@@ -1,0 +1,48 @@
+"""conv3x3_wide.hip (16x32-pixel tiles, 32-channel chunks, wave tile 128 couts x 64 pixels, K32 weight image) against a CPU fp32
+convolution at SMALL shapes: ragged tiles, several pairs / cout tiles, upsample fold, pad 2, residual, GroupNorm(+SiLU) prologue,
+many tiles per work-group, data-gradient packing.  The real-shape check of the same kernel is
+tests/test_gpu_parity_r2.py::test_dominant_conv_real_shape_vs_cpu_fp32 (the dispatch picks it there)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_wide_kernel_small_shapes_vs_cpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, MAS_CONV_WIDE_MIN_TILES_PER_CU="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "wide_check.py")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    print(r.stdout[-4000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok   ") >= 13
+
+
+def test_weight_layout_query_and_k64_is_always_accepted():
+    """mas_conv_weight_layout picks K32 exactly for the shapes the wide kernel takes; a K64 image passed for such a shape still
+    computes the same convolution (on the kernels that read K64)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, os.path.join(ROOT, "make-a-scene_amd"))
+    import mas_hip
+    from mas_hip import ops
+    bf = torch.bfloat16
+    big = ops._desc(32, 256, 256, 128, 256, 256, 128, 3, 1, 1, 1, bf, bf, 0, False)
+    assert ops._preferred_layout(big) == mas_hip.WLAYOUT_K32
+    for d in (ops._desc(32, 16, 16, 512, 16, 16, 512, 3, 1, 1, 1, bf, bf, 0, False),         # 16-wide map
+              ops._desc(32, 256, 256, 128, 256, 256, 128, 1, 1, 0, 0, bf, bf, 0, False),      # 1x1
+              ops._desc(32, 257, 257, 128, 128, 128, 128, 3, 2, 0, 0, bf, bf, 0, False),      # stride 2
+              ops._desc(32, 256, 256, 128, 256, 256, 128, 3, 1, 1, 1, torch.float32, torch.float32, 0, False)):
+        assert ops._preferred_layout(d) == mas_hip.WLAYOUT_K64
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(8, 128, 64, 64, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(128, 128, 3, 3, generator=g) * 0.03).cuda()
+    y32 = ops.conv_fwd_raw(x, None, ops.ConvWeight(w, False), None, None, 8, 64, 64, 128, 64, 64, 128, 3, 1, 1, 1, 0, False, bf)
+    y64 = ops.conv_fwd_raw(x, None, ops.pack_conv_weight(w, False, bf), None, None, 8, 64, 64, 128, 64, 64, 128, 3, 1, 1, 1, 0, False, bf)
+    assert float((y32.float() - y64.float()).abs().max() / y64.float().abs().max()) < 1e-2

@@ -56,7 +56,7 @@ def main():
             fn = lambda: ops.conv_wgrad_raw(x, ss, dy, n, h, h, c, h, h, co, a.ks, 1, p, p, a.act, False, True)
             byt = (x.numel() + dy.numel()) * esz
         else:
-            wp = ops.pack_conv_weight(w, a.kind == "dgrad", dt)
+            wp = ops.ConvWeight(torch.nn.Parameter(w), a.kind == "dgrad")   # packed (once: the Parameter is cached) in the layout the library prefers
             res = torch.randn(n, co, h, h, device=dev).to(dt).contiguous(memory_format=torch.channels_last) if a.res else None
             ho = h if a.stride == 1 else h // 2
             pt = p if a.stride == 1 else 0

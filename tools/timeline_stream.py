@@ -15,7 +15,7 @@ res = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 n, c, h = 32, 128, 256
 x = torch.randn(n, c, h, h, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
 w = torch.randn(c, c, 3, 3, device=dev) / (c * 9) ** 0.5
-wp = ops.pack_conv_weight(w, False, torch.bfloat16)
+wp = ops.pack_conv_weight(w, False, torch.bfloat16) if os.environ.get('TL_KERNEL', 'stream') == 'stream' else ops.ConvWeight(torch.nn.Parameter(w), False)
 ss = torch.randn(n, c, 2, device=dev) if act else None
 r = torch.randn_like(x) if res else None
 b = torch.randn(c, device=dev)
@@ -30,7 +30,8 @@ for it in range(2):
     print("tile start      ", rel(0))
     prev_issue = None
     tot = {"wait": 0, "issue": 0, "mfma": 0}
-    for s in range(9):
+    nst = 9 if os.environ.get('TL_KERNEL', 'stream') == 'stream' else 6
+    for s in range(nst):
         a, bb, cc = rel(1 + 3 * s), rel(2 + 3 * s), rel(3 + 3 * s)
         mean = lambda v: sum(v) / len(v)
         line = f"stage {s}: arrive {int(mean(a)):6d} (spread {max(a) - min(a):5d})  barrier+wait {int(mean(bb) - mean(a)):5d}  issue {int(mean(cc) - mean(bb)):5d}"
@@ -41,5 +42,5 @@ for it in range(2):
         prev_issue = mean(cc)
         print(line)
     e0, e1 = rel(40), rel(41)
-    print(f"mfma block of stage 8: {int(sum(e0) / 8 - prev_issue)}   epilogue {int(sum(e1) / 8 - sum(e0) / 8)}  tile total {int(sum(e1) / 8 - sum(rel(0)) / 8)}")
+    print(f"mfma block of the last stage: {int(sum(e0) / 8 - prev_issue)}   epilogue {int(sum(e1) / 8 - sum(e0) / 8)}  tile total {int(sum(e1) / 8 - sum(rel(0)) / 8)}")
     print({k: int(v) for k, v in tot.items()})
