@@ -34,6 +34,7 @@ struct WideParams {
     int N, H, W, Cin, Ho, Wo, Cout;
     int Hl, Wl, pad_top, pad_left, upsample, act;
     int n_chunks, Cout_pad, tiles_h, tiles_w, n_ct;
+    int stagger;                               // experiment: work-group b sleeps (b * 5 % 8) * stagger * 8128 cycles before its first tile
     unsigned m_ct, m_tw, m_th;                 // ceil(2^32 / d) for d = n_ct, tiles_w, tiles_h: t / d == umulhi(t, m) (host checks t * d < 2^32)
 };
 
@@ -45,7 +46,9 @@ constexpr int W_WT = 128 * 64;                 // one tap-step weight tile: 128 
 constexpr int W_WSTAGE = 3 * W_WT;             // one filter row of one chunk
 constexpr int W_WBUF = 0;                      // LDS map: [2][W_WSTAGE] weights, then [2][W_PATCH] patch
 constexpr int W_PBUF = 2 * W_WSTAGE;
-constexpr int W_LDS = W_PBUF + 2 * W_PATCH;
+constexpr int W_BIAS = W_PBUF + 2 * W_PATCH;   // [Cout] fp32 bias (zeros without one), staged once per work-group
+constexpr int W_MAXCOUT = 2048;
+constexpr int W_LDS = W_BIAS + W_MAXCOUT * 4;
 constexpr int W_NSLOT = 5;                     // patch DMA pieces (and 16-byte activation slots) per wave (thread) per chunk
 constexpr int W_OOB = (int)0x80000000;
 
@@ -53,8 +56,8 @@ constexpr int W_OOB = (int)0x80000000;
                                asm volatile("" ::: "memory"); } while (0)
 
 #ifdef W_TIMELINE
-#define WTS(id) do { if (lane == 0 && blockIdx.x == 100 && tl_iter >= 1 && tl_iter < 3 && p.dbg) \
-                         p.dbg[((tl_iter - 1) * 8 + wave) * 64 + (id)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define WTS(id) do { __builtin_amdgcn_sched_barrier(0); if (lane == 0 && blockIdx.x == 100 && tl_iter >= 1 && tl_iter < 3 && p.dbg) \
+                         p.dbg[((tl_iter - 1) * 8 + wave) * 64 + (id)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define WTS(id) do {} while (0)
 #endif
@@ -65,7 +68,7 @@ __device__ __forceinline__ void w_wait_barrier(int n) {   // n is a compile-time
         case 2: W_WAIT_BARRIER(2); break;
         case 3: W_WAIT_BARRIER(3); break;
         case 7: W_WAIT_BARRIER(7); break;
-        case 16: W_WAIT_BARRIER(16); break;
+        case 32: W_WAIT_BARRIER(32); break;
         default: W_WAIT_BARRIER(0); break;
     }
 }
@@ -120,14 +123,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
         pc = q - pr * W_PWL;
         return q < W_NPIX;
     };
-    auto make_plan = [&](const Tile& tc, int (&vo)[W_NSLOT], unsigned& inb_mask, int (&ob)[2]) {
+    auto make_plan = [&](const Tile& tc, int (&vo)[W_NSLOT], unsigned& inb_mask, int (&ob)[3]) {
         inb_mask = 0;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {           // byte offset of (n, ho, wo, c0 + 8 g) -- the epilogue's stores add (32 i + 16 qp) * 2
-            const int ho = tc.h0 + 2 * wave + j, wo = tc.w0 + l31;
-            const bool pix_ok = (ho < p.Ho) && (wo < p.Wo);
-            ob[j] = pix_ok ? (int)((((size_t)(tc.n * p.Ho + ho) * p.Wo + wo) * p.Cout + tc.c0 + 8 * g) * 2) : W_OOB;
+        for (int j = 0; j < 2; ++j) {           // byte offset of (n, ho, w0 + 4 g, c0 + 4 l31); the epilogue adds the pixel column
+            const int ho = tc.h0 + 2 * wave + j;
+            ob[j] = (ho < p.Ho) ? (int)((((size_t)(tc.n * p.Ho + ho) * p.Wo + tc.w0 + 4 * g) * p.Cout + tc.c0 + 4 * l31) * 2) : W_OOB;
         }
+        ob[2] = p.Wo - tc.w0 - 4 * g;           // pixel columns (relative to this lane's first) that exist
 #pragma unroll
         for (int k = 0; k < W_NSLOT; ++k) {
             int q, pr, pc;
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
 
     // ---- prologue ----------------------------------------------------------------------------------------------------------------
     int tile = blockIdx.x;                      // grid <= total_tiles
-    int c0_cur, c0_nxt, ob_cur[2], ob_nxt[2];
+    int c0_cur, c0_nxt, ob_cur[3], ob_nxt[3];
     // ONE plan / image descriptor: the current tile's until its last chunk-B patch has been issued (stage 1 of the last pair),
     // the next tile's from stage 2 of the last pair on (only the in-bounds masks of both tiles are live at the same time)
     int vo[W_NSLOT];
@@ -218,10 +221,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
         const Tile t0 = decode(tile);
         make_plan(t0, vo, inb_cur, ob_cur);
         c0_cur = c0_nxt = t0.c0; n_cur = n_nxt = t0.n;
-        ob_nxt[0] = ob_cur[0]; ob_nxt[1] = ob_cur[1];
+        ob_nxt[0] = ob_cur[0]; ob_nxt[1] = ob_cur[1]; ob_nxt[2] = ob_cur[2];
         rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.x) + (size_t)t0.n * img_bytes, 0, (unsigned)img_bytes, 0x00020000);
     }
     inb_nxt = inb_cur;
+    {   // bias -> LDS (read back in the epilogue through lgkmcnt: a VMEM load there would wait behind the tile's own stores)
+        float* bl = reinterpret_cast<float*>(smem + W_BIAS);
+        for (int c = tid; c < p.Cout; c += 512) bl[c] = p.bias ? p.bias[c] : 0.0f;
+    }
     w_issue(0, c0_cur, 0);
     p_dma(rs_x, vo, 0, 0, 0, W_NSLOT);
     if constexpr (ACT) {
@@ -229,7 +236,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
         W_WAIT_BARRIER(0);                       // the raw patch of chunk 0 has landed for every wave
         p_activate(inb_cur, 0);
     }
-    bool stores_in_flight = false;               // the previous tile's 16 epilogue stores may still be in flight at the first wait
+    if (p.stagger > 0) {
+        const int n = (int)((blockIdx.x * 5u) % 8u) * p.stagger;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    bool stores_in_flight = false;               // the previous tile's 32 epilogue stores may still be in flight at the first wait
     const int n_pairs = p.n_chunks >> 1;
 #ifdef W_TIMELINE
     int tl_iter = 0;
@@ -255,16 +266,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                 constexpr int s = decltype(s_c)::value;
                 constexpr int cb = s / 3, kh = s % 3;         // chunk A / B of the pair (= patch buffer), filter row
                 constexpr int wsel = s & 1;
-                if (pair == 0) WTS(1 + 3 * s);
+                if (pair < 2) WTS(1 + 3 * (pair * 6 + s));
                 // ---- barrier: this stage's weights, and the patch chunk it reads, are visible; the previous stage's buffers are free.
                 //      vmcnt allowance = VMEM operations issued AFTER the weight DMA in the previous stage
                 {
                     constexpr int khp = (kh + 2) % 3;         // filter row of the previous stage
                     constexpr int allow = khp == 0 ? 3 : (khp == 1 ? (ACT ? 0 : 2) : 0);
-                    if (s == 0 && pair == 0 && stores_in_flight) { w_wait_barrier(16); stores_in_flight = false; }
+                    if (s == 0 && pair == 0 && stores_in_flight) { w_wait_barrier(32); stores_in_flight = false; }
                     else w_wait_barrier(allow);
                 }
-                if (pair == 0) WTS(2 + 3 * s);
+                if (pair < 2) WTS(2 + 3 * (pair * 6 + s));
                 if (s == 2 && last_pair && has_next) {        // the next tile's plan (used by the chunk-B stages 3, 4); without a next
                     const Tile nt = decode(next_tile);        // tile the current one is re-fetched, harmlessly
                     make_plan(nt, vo, inb_nxt, ob_nxt);
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                     }
                 }
                 asm volatile("" ::: "memory");
-                if (pair == 0) WTS(3 + 3 * s);
+                if (pair < 2) WTS(3 + 3 * (pair * 6 + s));
                 // ---- 3 taps x 2 k-steps of 8 MFMAs; fragment reads software-pipelined one k-step ahead
                 {
                     const unsigned char* wb = wbuf + wsel * W_WSTAGE;
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) mma16(acc[i][j], afr[n & 1][i], bfr[n & 1][j]);
+                            for (int j = 0; j < 2; ++j) mma16(acc[i][j], bfr[n & 1][j], afr[n & 1][i]);   // D[pixel][cout]: rows (registers) = pixels, column (lane) = cout
                     }
                     __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);          // DS reads of k-step 0
 #pragma unroll
@@ -339,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
             });
         }
 
-        WTS(40);
+        WTS(60);
 #ifdef W_ABL_NOEPI     // timing experiment only
         if (p.N != -12345) {
             float t = 0.0f;
@@ -347,57 +358,67 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
             if (t == 123.456f) reinterpret_cast<float*>(p.y)[0] = t;
         } else
 #endif
-        // ---- epilogue: lanes l / l+32 exchange accumulator quads (fp32) so each lane owns 8 consecutive couts of its pixel;
-        //      bias (+ residual) added in fp32, bf16 pack, one 16-byte store per 8 couts
+        // ---- epilogue.  The weight rows of a cout tile are stored PERMUTED (LDS row 32 i + l holds cout 4 l + i, see
+        //      mas_pack_conv_weight_layout), so a lane owns 4 CONSECUTIVE couts (one of each of its 4 accumulator tiles) of the
+        //      16 pixels of each register block: one 8-byte store per pixel and lane, and the 32 lanes of a half-wave write one
+        //      whole 256-byte NHWC pixel row (8 lanes per 64-byte... every store instruction = two complete rows, perfectly coalesced).
+        //      (The MFMA-natural alternative -- lane = pixel, 8 couts = 16 B per lane -- touches 32 different 128-byte lines per
+        //      store instruction: measured 0.08 ms of 0.64 on the 128->128 @256^2 launch, profiles/r02_wide_store_ablation.txt.)
         {
-            const int (&obase)[2] = ob_cur;
+            const int row_bytes = p.Cout * 2;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem + W_BIAS) + c0_cur + 4 * l31);
+            // order: residual loads of row 0 | pack row 0 | residual loads of row 1 | stores of row 0 | pack + stores of row 1 --
+            // no load is waited for behind a store (in-order vmcnt would add the store's round trip), 32 packed + 32 residual
+            // registers at most beside the 64 accumulators of the other row
+            u32x2 rv[16], o0[16];
+            auto res_load = [&](int j) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int qp = 0; qp < 2; ++qp) {
-                    f32x4 b0 = {0.0f, 0.0f, 0.0f, 0.0f}, b1 = b0;
-                    if (p.bias) {                                                  // uniform branch
-                        const f32x4* bp = reinterpret_cast<const f32x4*>(p.bias + c0_cur + i * 32 + 16 * qp + 8 * g);
-                        b0 = bp[0]; b1 = bp[1];
-                    }
-                    u32x4 rv[2];
-                    if constexpr (RES) {
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) rv[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, obase[j] + (i * 32 + qp * 16) * 2, 0, 0);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        float v[8];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            // (copy the vector elements to scalars first: __builtin_bit_cast applied directly to an ext-vector
-                            //  element lvalue reads element 0 of the vector, whatever the index)
-                            const float qa = acc[i][j][(2 * qp) * 4 + e], qb = acc[i][j][(2 * qp + 1) * 4 + e];
-                            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(qa), __float_as_uint(qb), false, false);
-                            v[e] = __uint_as_float(r[0]) + b0[e]; v[4 + e] = __uint_as_float(r[1]) + b1[e];
-                        }
-                        u32x4 o;
-                        bf16_t* ob = reinterpret_cast<bf16_t*>(&o);
-                        if constexpr (RES) {
-                            const bf16_t* rb = reinterpret_cast<const bf16_t*>(&rv[j]);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) ob[e] = (bf16_t)(v[e] + (float)rb[e]);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) ob[e] = (bf16_t)v[e];
-                        }
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, obase[j] + (i * 32 + qp * 16) * 2, 0, 0);
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int pc = (r & 3) + 8 * (r >> 2);           // pixel column (+ 4 g, folded into ob_cur)
+                    rv[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, pc < ob_cur[2] ? ob_cur[j] : W_OOB, pc * row_bytes, 0);
                 }
-            }
+            };
+            auto pack = [&](int j, int r) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[i][j][r] + bv[i];
+                if constexpr (RES) {
+                    const bf16_t* rb = reinterpret_cast<const bf16_t*>(&rv[r]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += (float)rb[i];
+                }
+                u32x2 o;
+                bf16_t* ob = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ob[i] = (bf16_t)v[i];
+                return o;
+            };
+#ifndef W_ST_AUX
+#define W_ST_AUX 0
+#endif
+            auto store = [&](int j, int r, u32x2 o) {
+                const int pc = (r & 3) + 8 * (r >> 2);
+                __builtin_amdgcn_raw_buffer_store_b64(o, rs_y, pc < ob_cur[2] ? ob_cur[j] : W_OOB, pc * row_bytes, W_ST_AUX);
+            };
+            if constexpr (RES) res_load(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o0[r] = pack(0, r);
+            asm volatile("" ::: "memory");
+            if constexpr (RES) res_load(1);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 16; ++r) store(0, r, o0[r]);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 16; ++r) store(1, r, pack(1, r));
             stores_in_flight = true;
         }
-        WTS(41);
+        WTS(61);
 #ifdef W_TIMELINE
         ++tl_iter;
 #endif
         if (!has_next) break;
-        tile = next_tile; c0_cur = c0_nxt; n_cur = n_nxt; inb_cur = inb_nxt; ob_cur[0] = ob_nxt[0]; ob_cur[1] = ob_nxt[1];
+        tile = next_tile; c0_cur = c0_nxt; n_cur = n_nxt; inb_cur = inb_nxt; ob_cur[0] = ob_nxt[0]; ob_cur[1] = ob_nxt[1]; ob_cur[2] = ob_nxt[2];
     }
 }
 
@@ -429,7 +450,9 @@ bool mas_conv3x3_wide_eligible(const MasConvDesc* d) {
     if (!mode) return false;
     if (d->ks != 3 || d->stride != 1 || d->in_dtype != MAS_BF16 || d->out_dtype != MAS_BF16) return false;
     if (d->Cin % 64 != 0 || d->Cout % 128 != 0) return false;
-    if (d->Wo < 32 || (d->Wo % 32 != 0 && d->Wo < 96)) return false;     // narrow maps: half-empty 32-pixel tile rows
+    static const int any_width = mas_env_int("MAS_CONV_WIDE_ANY_WIDTH", 0);   // tests: ragged tile columns at small sizes
+    if (d->Cout > W_MAXCOUT) return false;
+    if (!any_width && (d->Wo < 32 || 4 * d->Wo < 3 * 32 * mas_cdiv(d->Wo, 32))) return false;   // < 75 % of the 32-pixel tile rows used
     const long long img_bytes = (long long)d->H * d->W * d->Cin * 2;
     const long long out_bytes = (long long)d->N * d->Ho * d->Wo * d->Cout * 2;
     if (img_bytes >= 0x7fffffffLL || out_bytes >= 0x7fffffffLL) return false;
@@ -455,6 +478,8 @@ int mas_conv3x3_wide_launch(const MasConvDesc* d, const void* x, const float* sc
     p.pad_top = d->pad_top; p.pad_left = d->pad_left; p.upsample = d->upsample; p.act = d->act;
     p.n_chunks = d->Cin / 32; p.Cout_pad = mas_roundup(d->Cout, 128);
     p.tiles_h = mas_cdiv(d->Ho, 16); p.tiles_w = mas_cdiv(d->Wo, 32); p.n_ct = d->Cout / 128;
+    static const int stagger = mas_env_int("MAS_CONV_WIDE_STAGGER", 0);
+    p.stagger = stagger;
     auto magic = [](int dv) { return (unsigned)((0x100000000ULL + (unsigned)dv - 1) / (unsigned)dv); };   // (d = 1 handled in the kernel)
     p.m_ct = magic(p.n_ct); p.m_tw = magic(p.tiles_w); p.m_th = magic(p.tiles_h);
     if (d->act != MAS_ACT_NONE) return residual ? launch_wide<true, true>(p, s) : launch_wide<true, false>(p, s);

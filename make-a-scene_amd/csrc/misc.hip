@@ -59,7 +59,9 @@ __global__ __launch_bounds__(NT) void pack_weight_kernel(const float* __restrict
     }
 }
 
-// MAS_WLAYOUT_K32 (bf16): [chunk32][tap][row][64 B]; slot position sp stores logical slot sp ^ ((row>>2)&3) (conv3x3_wide.hip)
+// MAS_WLAYOUT_K32 (bf16): [chunk32][tap][row][64 B]; slot position sp stores logical slot sp ^ ((row>>2)&3); inside every
+// 128-row tile the rows are PERMUTED: LDS row 32 i + l holds filter row 4 l + i (conv3x3_wide.hip: a lane then owns 4 consecutive
+// output channels, one per accumulator tile, and stores them with one 8-byte store)
 __global__ __launch_bounds__(NT) void pack_weight_k32_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin,
                                                              int ks, int transpose, int rows_pad, int n_chunks) {
     const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
@@ -71,11 +73,12 @@ __global__ __launch_bounds__(NT) void pack_weight_k32_kernel(const float* __rest
         const int ch = (int)(i / (32LL * rows_pad * ks * ks));
         const int sp = pos / 8, e = pos % 8;
         const int col = ch * 32 + ((sp ^ ((row >> 2) & 3)) * 8) + e;
+        const int frow = (row & ~127) + 4 * (row & 31) + ((row & 127) >> 5);      // filter row stored at LDS row `row`
         const int kh = t / ks, kw = t % ks;
         float v = 0.0f;
-        if (row < rows && col < cols) {
-            if (!transpose) v = w[(((size_t)row * Cin + col) * ks + kh) * ks + kw];
-            else v = w[(((size_t)col * Cin + row) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)];
+        if (frow < rows && col < cols) {
+            if (!transpose) v = w[(((size_t)frow * Cin + col) * ks + kh) * ks + kw];
+            else v = w[(((size_t)col * Cin + frow) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)];
         }
         out[i] = (bf16_t)v;
     }

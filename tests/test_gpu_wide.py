@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_wide_kernel_small_shapes_vs_cpu():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    env = dict(os.environ, MAS_CONV_WIDE_MIN_TILES_PER_CU="0")
+    env = dict(os.environ, MAS_CONV_WIDE_MIN_TILES_PER_CU="0", MAS_CONV_WIDE_ANY_WIDTH="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "wide_check.py")], env=env,
                        capture_output=True, text=True, timeout=600)
     print(r.stdout[-4000:])

@@ -30,7 +30,8 @@ for it in range(2):
     print("tile start      ", rel(0))
     prev_issue = None
     tot = {"wait": 0, "issue": 0, "mfma": 0}
-    nst = 9 if os.environ.get('TL_KERNEL', 'stream') == 'stream' else 6
+    wide = os.environ.get('TL_KERNEL', 'stream') != 'stream'
+    nst = 12 if wide else 9
     for s in range(nst):
         a, bb, cc = rel(1 + 3 * s), rel(2 + 3 * s), rel(3 + 3 * s)
         mean = lambda v: sum(v) / len(v)
@@ -41,6 +42,6 @@ for it in range(2):
         tot["wait"] += mean(bb) - mean(a); tot["issue"] += mean(cc) - mean(bb)
         prev_issue = mean(cc)
         print(line)
-    e0, e1 = rel(40), rel(41)
+    e0, e1 = (rel(60), rel(61)) if wide else (rel(40), rel(41))
     print(f"mfma block of the last stage: {int(sum(e0) / 8 - prev_issue)}   epilogue {int(sum(e1) / 8 - sum(e0) / 8)}  tile total {int(sum(e1) / 8 - sum(rel(0)) / 8)}")
     print({k: int(v) for k, v in tot.items()})
