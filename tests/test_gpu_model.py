@@ -201,7 +201,10 @@ def test_img256_bf16_batch_properties():
         rec4, _ = m(x)
         rec4b, _ = m(x)
     assert torch.equal(h4, h4b)
-    assert torch.equal(h4[1:2], h1)
+    # batch 4 and batch 1 do not take the same kernels any more (the dispatch picks the tile geometry that fills the chip:
+    # 16x32-pixel tiles / 32-channel chunks at batch 4, 8x16 / 64-channel at batch 1 -- different fp32 accumulation orders),
+    # so per-sample independence is checked to bf16 rounding, not bitwise
+    assert float((h4[1:2].float() - h1.float()).abs().max() / h1.float().abs().max()) < 2e-2
     assert torch.equal(rec4, rec4b)
     assert torch.isfinite(rec4).all()
 
