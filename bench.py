@@ -5,19 +5,23 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one per-GPU batch of synthetic images:
-``rec, q = VQBASE(x); (|x-rec|.mean() + q).backward(); Adam.step()`` on the model block of the
-reference's conf/img_config.yaml (BASELINE.json configs[1]: VQ-IMG 256x256, codebook 8192, per-GPU
-batch 32, bf16 activations, fp32 accumulate).  Inputs are resident in HBM before the timed region.
-N > 1: one process per GPU, the reference's own data-parallel scheme (train.py:24,32: NCCL==RCCL process
-group + DistributedDataParallel bucketed gradient all-reduce overlapped with backward; SyncBatchNorm's
-statistics all-gather), weak scaling (per-GPU batch fixed).
+--workload vq (default, BASELINE.json's metric): one "step" = one pass of the hot path over one per-GPU batch of synthetic
+images: ``rec, q = VQBASE(x); (|x-rec|.mean() + q).backward(); Adam.step()`` on the model block of the reference's
+conf/img_config.yaml (BASELINE configs[1]: VQ-IMG 256x256, codebook 8192, per-GPU batch 32, bf16 activations, fp32 accumulate).
+Inputs are resident in HBM before the timed region.  N > 1: one process per GPU, the reference's own data-parallel scheme
+(train.py:24,32: NCCL==RCCL process group + bucketed gradient all-reduce overlapped with backward; SyncBatchNorm's statistics
+all-gather), weak scaling (per-GPU batch fixed).
+
+--workload transformer (BASELINE configs[3]): MakeAScene 24L / 1024d / 16 heads over 256 text + 256 seg + 1024 image tokens,
+fwd + bwd of the cross-entropy on the image tokens (train.py:150-152) + Adam, bf16 autocast for the library GEMMs, tokens/s.
+--workload e2e (BASELINE configs[4]): frozen VQ-SEG + VQ-IMG encode -> tokens -> the same transformer step, samples/s.
 
 Rank 0 prints ONE JSON line; besides the driver's contract it carries
-  "roofline":     the dominant kernel (3x3 128->128 conv at 256^2, fwd/dgrad implicit GEMM) timed live with
-                  HIP events on the launch stream inside the timed steps, against the bf16 MFMA peak;
-  "cpu_baseline": the CPU oracle (oracle/vq_oracle.py, a port of the reference's arithmetic) timed on this
-                  host's cores on a bounded sample (rank 0, N=1 only).
+  "roofline":     the dominant kernel timed live with HIP events on the launch stream inside the timed steps, against the bf16
+                  MFMA peak (vq: the 3x3 128->128 conv at 256^2, fwd + dgrad launches, the two loader populations separately
+                  and launch-weighted; transformer / e2e: the causal-attention forward kernel);
+  "cpu_baseline": the CPU oracle (oracle/vq_oracle.py, a port of the reference's arithmetic -- /root/reference does not exist
+                  on the GPU box) timed on this host's cores on a bounded sample (rank 0, N=1, vq workload only).
 """
 import argparse
 import json
@@ -36,9 +40,15 @@ import torch.distributed as dist  # noqa: E402
 IMG_CFG = dict(ddconfig=dict(z_channels=256, in_channels=3, out_channels=3, channels=[128, 128, 128, 256, 512, 512],
                              num_res_blocks=2, resolution=512, attn_resolutions=[32], dropout=0.0),
                n_embed=8192, embed_dim=256, init_steps=3000, reservoir_size=12500)   # reference conf/img_config.yaml:19-34
+SEG_CFG = dict(ddconfig=dict(z_channels=256, in_channels=159, out_channels=159, channels=[128, 128, 128, 256, 512, 512],
+                             num_res_blocks=2, resolution=512, attn_resolutions=[32], dropout=0.0),
+               n_embed=256, embed_dim=256, init_steps=3000, reservoir_size=12500)    # conf/seg_config.yaml:13-32
+TR_CFG = dict(num_layers=24, hidden_dim=1024, num_attn_heads=16, image_vocab_size=8192, seg_vocab_size=256,
+              text_vocab_size=49408 + 256, image_tokens_per_dim=32, seg_tokens_per_dim=16, text_length=256)
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-FWD_BWD_GFLOP_PER_IMG = 1337.53   # SURVEY.md section 8(d), counted on the reference with torch flop_counter
+FWD_BWD_GFLOP_PER_IMG = 1337.53     # SURVEY.md section 8(d), counted on the reference with torch flop_counter
+TR_FWD_GFLOP_PER_SAMPLE = 1185.4    # full S x S attention count
 
 
 def parse():
@@ -47,17 +57,22 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=15,
                     help="untimed steps; the first ~1 s of load on a cold MI355X runs 5-8 %% slower (clock ramp), so the default covers it")
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE config: 32)")
+    ap.add_argument("--workload", default="vq", choices=["vq", "transformer", "e2e"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the BASELINE config: vq 32, transformer 8, e2e 64)")
+    ap.add_argument("--micro-batch", type=int, default=16, help="e2e: gradient-accumulation micro-batch (the reference accumulates too)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dp", default="mas", choices=["mas", "ddp"],
                     help="N>1 gradient averaging: mas_hip.dp.GradReducer (default) or torch DistributedDataParallel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-batch", type=int, default=1)
+    ap.add_argument("--cpu-baseline-batch", type=int, default=2)
     return ap.parse_args()
 
 
-def _cpu_baseline_worker(batch, threads):
-    """child process: prints the seconds of one timed CPU-oracle fwd+bwd step"""
+# --------------------------------------------------------------------------------------------------------------------
+# CPU baseline (vq workload)
+# --------------------------------------------------------------------------------------------------------------------
+def _cpu_baseline_worker(batch, threads, timed):
+    """child process: prints the seconds of each timed CPU-oracle fwd+bwd step"""
     from oracle import vq_oracle as O
     torch.set_num_threads(threads)
     sd = O.synth_state_dict(IMG_CFG["ddconfig"], IMG_CFG["n_embed"], IMG_CFG["embed_dim"], seed=0)
@@ -73,177 +88,55 @@ def _cpu_baseline_worker(batch, threads):
         O.recon_vq_loss(x, dec, qq).backward()
 
     step()                                      # warm-up (allocator, oneDNN primitive cache)
-    t0 = time.perf_counter()
-    step()
-    print("CPU_BASELINE_SECONDS", time.perf_counter() - t0, flush=True)
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        step()
+        print("CPU_BASELINE_SECONDS", time.perf_counter() - t0, flush=True)
 
 
-def cpu_baseline(batch, budget_s=90):
-    """Times the CPU oracle (fp32 port of the reference's arithmetic) on a BOUNDED sample: `batch` images, 1 warm-up +
-    1 timed fwd+bwd step, in a child process that is killed after `budget_s` seconds (the host of a GPU box can have
-    hundreds of slow hardware threads: round 1 measured 277 s/step with all 256).  A reported baseline, not the target."""
+def cpu_baseline(batch, budget_s=150):
+    """Times the CPU oracle (fp32 port of the reference's arithmetic; BASELINE.md section 3's recipe: B=2, 1 warm-up + 3 timed
+    fwd+bwd steps of rec,q = model(x); (|x-rec|.mean()+q).backward()) in a child process that is killed after `budget_s`
+    seconds -- whatever steps finished by then are reported.  Threads are capped at 32: the host of a GPU box has hundreds of
+    slow hardware threads and torch-CPU convolutions get SLOWER beyond a few dozen (round 1: 277 s/step with all 256).
+    A reported baseline, not the target."""
     import subprocess
-    threads = min(os.cpu_count() or 1, 32)
-    sample = f"oracle/vq_oracle.py fp32 fwd+bwd, B={batch} x 256x256, 1 warm-up + 1 timed step, {threads} threads, torch CPU {torch.__version__}"
-    out = {"value": None, "unit": "images/s", "cores": threads, "kind": "port", "sample": sample}
+    host = os.cpu_count() or 1
+    threads = min(host, 32)
+    timed = 3
+    out = {"value": None, "unit": "images/s", "cores": threads, "host_cpus": host, "kind": "port",
+           "sample": f"oracle/vq_oracle.py fp32 fwd+bwd, B={batch} x 256x256, 1 warm-up + {timed} timed steps, {threads} threads of "
+                     f"{host} host CPUs, torch CPU {torch.__version__}"}
+    secs = []
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(batch), str(threads)],
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(batch), str(threads), str(timed)],
                            capture_output=True, text=True, timeout=budget_s)
-        for line in r.stdout.splitlines():
-            if line.startswith("CPU_BASELINE_SECONDS"):
-                out["value"] = round(batch / float(line.split()[1]), 4)
-        if out["value"] is None:
-            out["sample"] += " -- worker failed: " + r.stderr[-200:]
-    except subprocess.TimeoutExpired:
-        out["sample"] += f" -- exceeded the {budget_s}s budget"
+        txt, err = r.stdout, r.stderr
+    except subprocess.TimeoutExpired as e:
+        txt = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        err = ""
+        out["sample"] += f" -- stopped at the {budget_s}s budget"
+    for line in txt.splitlines():
+        if line.startswith("CPU_BASELINE_SECONDS"):
+            secs.append(float(line.split()[1]))
+    if secs:
+        out["value"] = round(batch * len(secs) / sum(secs), 4)
+        out["timed_steps"] = len(secs)
+    else:
+        out["sample"] += " -- no step finished" + (": " + err[-200:] if err else "")
     return out
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
-    if not torch.cuda.is_available():
-        print("bench.py needs an MI355X (no CPU fallback for the product path)", file=sys.stderr)
-        sys.exit(2)
-    # MAS_BENCH_SHARE_GPU=1 + MAS_BENCH_BACKEND=gloo: functional check of the N>1 code path (reducer, SyncBatchNorm
-    # exchange, max-over-ranks timing) with several ranks on ONE GPU -- RCCL refuses two ranks per device, gloo does not
-    if os.environ.get("MAS_BENCH_SHARE_GPU") == "1":
-        local_rank = 0
-    backend = os.environ.get("MAS_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    ddp = world > 1 or os.environ.get("MAS_BENCH_FORCE_DDP") == "1"     # the env knob exercises the N>1 code path on one GPU
-    if ddp:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        if backend == "nccl":
-            dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
-        else:
-            dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
-
-    from mas_hip import ops
-    from models import VQBASE
-    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    ops.set_compute_dtype(cdt)
-
-    torch.manual_seed(0)                                   # identical replicas (DDP would broadcast anyway)
-    model = VQBASE(**IMG_CFG)
-    with torch.no_grad():                                  # post-k-means-like codebook scale (SURVEY section 8(d) config 2)
-        model.quantize.embedding.weight.normal_(0.0, 1.0)
-    model = model.to(dev).train()
-    model.quantize.q_counter = model.quantize.q_re_end      # steady state: VQ lookup on the path, no warm-up bypass
-    net, reducer = model, None
-    if ddp and args.dp == "ddp":                            # the reference's wrapper (train.py:31-34)
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True)
-    elif ddp:                                               # same semantics, 3 flat buckets instead of 345 per-parameter copies
-        from mas_hip.dp import GradReducer
-        reducer = GradReducer(model.parameters())
-    opt = torch.optim.Adam(model.parameters(), lr=5e-6, betas=(0.5, 0.9), fused=True)   # conf/img_config.yaml:36-41
-
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)          # distinct data per rank
-    x = torch.rand(args.batch, 3, 256, 256, generator=g).to(dev)
-
-    # ---- live timing of the dominant kernel (HIP events on the launch stream) -------------
-    dom = {"events": [], "on": False}
-
-    def hook(kind, shape, launch):
-        # shape = (n,h,w,cin,ho,wo,cout,ks,stride)
-        if dom["on"] and kind == "conv_fwd" and shape[3] == 128 and shape[6] == 128 and shape[7] == 3 and shape[8] == 1 \
-                and shape[4] == 256 and shape[5] == 256 and shape[1] == 256:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            launch()
-            e1.record()
-            dom["events"].append((e0, e1))
-        else:
-            launch()
-
-    ops.set_launch_hook(hook)
-
-    def step():
-        rec, q = net(x)
-        loss = (x - rec).abs().mean() + q
-        loss.backward()
-        if reducer is not None:
-            reducer.finish()
-        opt.step()
-        opt.zero_grad(set_to_none=True)
-        return loss
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if ddp:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dom["on"] = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if ddp:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dom["on"] = False
-    ops.set_launch_hook(None)
-    if ddp:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    final_loss = float(loss)
-    spread = None
-    if ddp:                                                 # replicas must still hold identical weights after the timed steps
-        with torch.no_grad():
-            cs = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
-        lo, hi = cs.clone(), cs.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        spread = float((hi - lo).item())
-
-    if rank == 0:
-        imgs = args.batch * world * args.steps
-        value = imgs / dt
-        out = {
-            "metric": "VQ-IMG 256x256 images/sec/node (recon+VQ fwd+bwd)", "value": round(value, 2), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "VQ-IMG 256x256, codebook 8192x256, conf/img_config.yaml model block (95.2 M params), "
-                                   "fwd+bwd of L1+q_loss + Adam step", "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}" + ((" (DistributedDataParallel" if args.dp == "ddp" else " (mas_hip.dp.GradReducer: 128 MiB flat buckets,")
-                                                       + " RCCL all-reduce overlapped with backward + SyncBatchNorm)" if ddp else "")},
-            "final_loss": round(final_loss, 5),
-            "replica_weight_checksum_spread": spread,
-            "model_tflops_per_gpu": round(value / world * FWD_BWD_GFLOP_PER_IMG / 1e3, 1),
-        }
-        if dom["events"]:
-            ms = [a.elapsed_time(b) for a, b in dom["events"]]
-            avg_ms = sum(ms) / len(ms)
-            px = args.batch * 256 * 256
-            flops = 2.0 * 9 * 128 * 128 * px                 # algorithmic FLOPs of one launch (SURVEY Appendix A)
-            esz = 2 if args.dtype == "bf16" else 4
-            bytes_ = 2.0 * px * 128 * esz                    # one read of the input, one write of the output
-            ach = flops / (avg_ms * 1e-3) / 1e12
-            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-            out["roofline"] = {"kernel": "conv_fwd_kernel<3x3,s1,128->128> @256x256 (fwd + dgrad launches)", "bound": "mfma",
-                               "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "traffic": _pmc_traffic(), "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
-                               "algorithmic_gflop_per_launch": round(flops / 1e9, 1),
-                               "algorithmic_hbm_gbs": round(bytes_ / (avg_ms * 1e-3) / 1e9, 1),
-                               "hbm_frac": round(bytes_ / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-        out["encoder_stack"] = _encoder_stack(model, x, args.batch, args.dtype)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch)
-        print(json.dumps(out), flush=True)
-    if ddp:
-        dist.destroy_process_group()
+# --------------------------------------------------------------------------------------------------------------------
+def _pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC summary (a separate profiled run of the
+    same kernel and shape, tools/pmc_kernel.sh), not measured by this run."""
+    p = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
 
 
 def _encoder_stack(model, x, batch, dtype):
@@ -271,18 +164,310 @@ def _encoder_stack(model, x, batch, dtype):
             "north_star_target_hbm_frac": 0.40}
 
 
-def _pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary, if any."""
-    p = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
-    try:
-        with open(p) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
-    except Exception:
+def _setup_dist(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs an MI355X (no CPU fallback for the product path)", file=sys.stderr)
+        sys.exit(2)
+    # MAS_BENCH_SHARE_GPU=1 + MAS_BENCH_BACKEND=gloo: functional check of the N>1 code path (reducer, SyncBatchNorm
+    # exchange, max-over-ranks timing) with several ranks on ONE GPU -- RCCL refuses two ranks per device, gloo does not
+    if os.environ.get("MAS_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("MAS_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ddp = world > 1 or os.environ.get("MAS_BENCH_FORCE_DDP") == "1"     # the env knob exercises the N>1 code path on one GPU
+    if ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl":
+            dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+        else:
+            dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
+    return world, rank, local_rank, dev, ddp
+
+
+def _wrap_dp(model, args, ddp, local_rank):
+    net, reducer = model, None
+    if ddp and args.dp == "ddp":                            # the reference's wrapper (train.py:31-34)
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True)
+    elif ddp:                                               # same semantics, a few flat buckets instead of per-parameter copies
+        from mas_hip.dp import GradReducer
+        reducer = GradReducer(model.parameters())
+    return net, reducer
+
+
+def _timed(step, args, ddp, dev, on_start=None):
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if ddp:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if on_start:
+        on_start(True)
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if ddp:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if on_start:
+        on_start(False)
+    if ddp:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, float(loss.detach())
+
+
+def _replica_spread(model, ddp):
+    if not ddp:                                             # replicas must still hold identical weights after the timed steps
         return None
+    with torch.no_grad():
+        cs = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+    lo, hi = cs.clone(), cs.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return float((hi - lo).item())
+
+
+def _par(world, args, ddp):
+    return f"dp{world}" + ((" (DistributedDataParallel" if args.dp == "ddp" else " (mas_hip.dp.GradReducer: 128 MiB flat buckets,")
+                           + " RCCL all-reduce overlapped with backward)" if ddp else "")
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# workload: vq (the headline metric)
+# --------------------------------------------------------------------------------------------------------------------
+def run_vq(args):
+    world, rank, local_rank, dev, ddp = _setup_dist(args)
+    from mas_hip import ops
+    from models import VQBASE
+    batch = args.batch or 32
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    ops.set_compute_dtype(cdt)
+
+    torch.manual_seed(0)                                   # identical replicas (DDP would broadcast anyway)
+    model = VQBASE(**IMG_CFG)
+    with torch.no_grad():                                  # post-k-means-like codebook scale
+        model.quantize.embedding.weight.normal_(0.0, 1.0)
+    model = model.to(dev).train()
+    model.quantize.q_counter = model.quantize.q_re_end      # steady state: VQ lookup on the path, no warm-up bypass
+    net, reducer = _wrap_dp(model, args, ddp, local_rank)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-6, betas=(0.5, 0.9), fused=True)   # conf/img_config.yaml:36-41
+
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)          # distinct data per rank
+    x = torch.rand(batch, 3, 256, 256, generator=g).to(dev)
+
+    # ---- live timing of the dominant kernel (HIP events on the launch stream) -------------
+    dom = {"plain": [], "gn_silu": [], "on": False}
+
+    def hook(kind, shape, launch):
+        # shape = (n,h,w,cin,ho,wo,cout,ks,stride,act,has_residual)
+        if dom["on"] and kind == "conv_fwd" and shape[3] == 128 and shape[6] == 128 and shape[7] == 3 and shape[8] == 1 \
+                and shape[4] == 256 and shape[5] == 256 and shape[1] == 256:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch()
+            e1.record()
+            dom["gn_silu" if shape[9] else "plain"].append((e0, e1))
+        else:
+            launch()
+
+    ops.set_launch_hook(hook)
+
+    def step():
+        rec, q = net(x)
+        loss = (x - rec).abs().mean() + q
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    dt, final_loss = _timed(step, args, ddp, dev, on_start=lambda on: dom.__setitem__("on", on))
+    ops.set_launch_hook(None)
+    spread = _replica_spread(model, ddp)
+
+    if rank == 0:
+        value = batch * world * args.steps / dt
+        out = {
+            "metric": "VQ-IMG 256x256 images/sec/node (recon+VQ fwd+bwd)", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "VQ-IMG 256x256, codebook 8192x256, conf/img_config.yaml model block (95.2 M params), "
+                                   "fwd+bwd of L1+q_loss + Adam step", "per_gpu_batch": batch, "global_batch": batch * world,
+                       "parallelism": _par(world, args, ddp) + (" + SyncBatchNorm" if ddp else "")},
+            "final_loss": round(final_loss, 5),
+            "replica_weight_checksum_spread": spread,
+            "model_tflops_per_gpu": round(value / world * FWD_BWD_GFLOP_PER_IMG / 1e3, 1),
+        }
+        n_ev = len(dom["plain"]) + len(dom["gn_silu"])
+        if n_ev:
+            px = batch * 256 * 256
+            flops = 2.0 * 9 * 128 * 128 * px                 # algorithmic FLOPs of one launch
+            esz = 2 if args.dtype == "bf16" else 4
+            bytes_ = 2.0 * px * 128 * esz                    # one read of the input, one write of the output
+            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+            pops = {}
+            tot_ms = 0.0
+            for k in ("plain", "gn_silu"):
+                ms = [a.elapsed_time(b) for a, b in dom[k]]
+                if ms:
+                    tot_ms += sum(ms)
+                    avg = sum(ms) / len(ms)
+                    pops[k] = {"launches": len(ms), "avg_launch_ms": round(avg, 4), "tflops": round(flops / (avg * 1e-3) / 1e12, 1),
+                               "frac": round(flops / (avg * 1e-3) / 1e12 / peak, 4)}
+            avg_ms = tot_ms / n_ev                           # launch-weighted over both populations
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "3x3 stride-1 128->128 conv @256x256: conv3x3_wide_kernel (fwd + dgrad launches of the step; "
+                                         "'plain' = data gradients and prologue-free forwards, 'gn_silu' = forwards with the GroupNorm+SiLU loader)",
+                               "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                               "traffic": _pmc_traffic(),
+                               "traffic_source": "committed rocprofv3 PMC pass on the same kernel and shape (profiles/pmc_dominant_kernel.json), not measured by this run",
+                               "avg_launch_ms": round(avg_ms, 4), "launches_timed": n_ev, "populations": pops,
+                               "algorithmic_gflop_per_launch": round(flops / 1e9, 1),
+                               "algorithmic_hbm_gbs": round(bytes_ / (avg_ms * 1e-3) / 1e9, 1),
+                               "hbm_frac": round(bytes_ / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        out["encoder_stack"] = _encoder_stack(model, x, batch, args.dtype)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch)
+        print(json.dumps(out), flush=True)
+    if ddp:
+        dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# workloads: transformer (config 4) and e2e (config 5)
+# --------------------------------------------------------------------------------------------------------------------
+def run_transformer(args, e2e):
+    world, rank, local_rank, dev, ddp = _setup_dist(args)
+    from mas_hip import ops
+    from models import VQBASE
+    from models.transformer import MakeAScene
+    batch = args.batch or (64 if e2e else 8)
+    micro = min(args.micro_batch, batch) if e2e else batch
+    if batch % micro:
+        raise SystemExit("--batch must be a multiple of --micro-batch")
+    cfg = TR_CFG
+    S = cfg["text_length"] + cfg["seg_tokens_per_dim"] ** 2 + cfg["image_tokens_per_dim"] ** 2
+    torch.manual_seed(0)
+    model = MakeAScene(**cfg).to(dev).train()
+    net, reducer = _wrap_dp(model, args, ddp, local_rank)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+    g = torch.Generator(device="cpu").manual_seed(4321 + rank)
+    text = torch.randint(1, 49408, (batch, 256), generator=g)
+    text[:, 200:] = 0                                                    # zero-padded tail (transformer.py:350-353)
+    text = text.to(dev)
+    vq_img = vq_seg = images = segs = None
+    if e2e:                                                              # frozen stage-1 models produce the tokens inside the step
+        ops.set_compute_dtype(torch.bfloat16)
+        vq_img = VQBASE(**IMG_CFG).to(dev).eval().requires_grad_(False)
+        vq_seg = VQBASE(**SEG_CFG).to(dev).eval().requires_grad_(False)
+        with torch.no_grad():
+            vq_img.quantize.embedding.weight.normal_(0.0, 1.0)
+            vq_seg.quantize.embedding.weight.normal_(0.0, 1.0)
+        images = torch.rand(batch, 3, 256, 256, generator=g).to(dev)
+        segs = torch.rand(batch, 159, 256, 256, generator=g).to(dev)      # soft one-hot-like maps of the 159 classes
+    else:
+        seg_tok = torch.randint(0, 256, (batch, 256), generator=g).to(dev)
+        img_tok = torch.randint(0, 8192, (batch, 1024), generator=g).to(dev)
+
+    att = {"ev": [], "on": False}
+    orig = ops._CausalAttention.forward
+
+    def timed_fwd(ctx, qkv, n_heads, cd):
+        if not att["on"]:
+            return orig(ctx, qkv, n_heads, cd)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(ctx, qkv, n_heads, cd)
+        e1.record()
+        att["ev"].append((e0, e1, qkv.shape[0]))
+        return r
+
+    ops._CausalAttention.forward = staticmethod(timed_fwd)
+
+    def step():
+        from token_data import tokenize_batch
+        loss = None
+        for m0 in range(0, batch, micro):
+            sl = slice(m0, m0 + micro)
+            if e2e:
+                it, st = tokenize_batch(vq_img, vq_seg, images[sl], segs[sl])
+            else:
+                it, st = img_tok[sl], seg_tok[sl]
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
+                logits = net(text[sl], st, it)
+            loss = torch.nn.functional.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), it.reshape(-1)) * (micro / batch)
+            if reducer is not None and m0 + micro < batch:
+                with reducer.no_sync():
+                    loss.backward()
+            else:
+                loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    dt, final_loss = _timed(step, args, ddp, dev, on_start=lambda on: att.__setitem__("on", on))
+    ops._CausalAttention.forward = staticmethod(orig)
+    spread = _replica_spread(model, ddp)
+    if rank == 0:
+        samples = batch * world * args.steps
+        gf = TR_FWD_GFLOP_PER_SAMPLE * 3
+        if e2e:
+            out = {"metric": "end-to-end stage-2 samples/sec/node (frozen VQ-SEG + VQ-IMG encode -> AR transformer fwd+bwd+Adam)",
+                   "value": round(samples / dt, 2), "unit": "samples/s"}
+            wl = (f"BASELINE configs[4]: frozen VQ-IMG (256x256x3) + VQ-SEG (256x256x159) encode -> 1024 + 256 tokens -> MakeAScene 24L/1024d/16h "
+                  f"(S={S}) cross-entropy fwd+bwd + Adam, micro-batch {micro} x {batch // micro} accumulation")
+        else:
+            out = {"metric": "MakeAScene 24L/1024d transformer tokens/sec/node (fwd+bwd+Adam, S=1536)",
+                   "value": round(samples * S / dt, 1), "unit": "tokens/s"}
+            wl = f"BASELINE configs[3]: MakeAScene 24L/1024d/16 heads (head_dim 64, assumed: SURVEY 8(d)), 256 text + 256 seg + 1024 image tokens"
+        out.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                    "config": {"workload": wl, "per_gpu_batch": batch, "global_batch": batch * world, "parallelism": _par(world, args, ddp)},
+                    "final_loss": round(final_loss, 5), "replica_weight_checksum_spread": spread,
+                    "model_tflops_per_gpu": round(samples / world / dt * gf / 1e3, 1)})
+        if att["ev"]:
+            ms = [a.elapsed_time(b) for a, b, _ in att["ev"]]
+            nb = att["ev"][0][2]
+            avg = sum(ms) / len(ms)
+            fl = 4.0 * nb * 16 * S * S * 64 / 2              # causal half of the two S x S x hd products
+            ach = fl / (avg * 1e-3) / 1e12
+            out["roofline"] = {"kernel": f"attn_causal_fwd_bf16 (B={nb}, H=16, S={S}, hd=64), forward launches of the step (incl. the dtype glue of the autograd wrapper)",
+                               "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg, 4),
+                               "launches_timed": len(ms), "algorithmic_gflop_per_launch": round(fl / 1e9, 1)}
+        print(json.dumps(out), flush=True)
+    if ddp:
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.workload == "vq":
+        run_vq(args)
+    else:
+        run_transformer(args, e2e=args.workload == "e2e")
 
 
 if __name__ == "__main__":
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
-        _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]))
+        _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 1)
     else:
         main()

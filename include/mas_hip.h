@@ -146,6 +146,16 @@ int mas_attn_causal_fwd(const void* q, const void* k, const void* v, void* o, fl
 int mas_attn_causal_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv,
                         int dtype, int B, int H, int S, int hd, float scale, void* stream);
 
+/* ---- decode-time (KV-cached) attention  (replaces the cached branch of SelfAttention.forward, models/transformer.py:73-115,
+ * for token-by-token sampling: SURVEY 8(f) rank 3).  nq new queries of every (batch, head) against a cache of past + nq keys /
+ * values: query i (0 <= i < nq) attends to keys 0 .. past + i (causal inside the block).  q: element (b, i, h, d) at
+ * q[b*q_bs + i*ld_q + h*hd + d]; k_cache / v_cache: element (b, s, h, d) at ptr[b*bs + s*ld + h*hd + d], rows 0 .. past+nq-1
+ * valid (the caller appends the new rows BEFORE the call); o likewise with (o_bs, ld_o).  HBM-bound: each key / value row is
+ * read once per query; no [nq, S] score tensor exists.  hd in {16,32,64,128}; rows 16-byte aligned.                        */
+int mas_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* o, int dtype, int B, int H, int nq,
+                    int past, int hd, int ld_q, int ld_k, int ld_v, int ld_o, long long q_bs, long long k_bs,
+                    long long v_bs, long long o_bs, float scale, void* stream);
+
 /* ---- small NHWC helpers on the path -------------------------------------------------
  * nearest x2 upsample (F.interpolate, modules.py:56) and its adjoint (2x2 sum);
  * zero-stuffing used by the stride-2 data gradient (adjoint of modules.py:76-78).      */

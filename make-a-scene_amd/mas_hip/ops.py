@@ -36,7 +36,7 @@ _launch_hook = None
 
 def set_launch_hook(fn) -> None:
     """fn(kind, shape, launch) wraps every conv launch (bench.py times the dominant kernel with HIP events
-    recorded on the launch stream); None disables it."""
+    recorded on the launch stream); shape = (n, h, w, cin, ho, wo, cout, ks, stride, act, has_residual); None disables it."""
     global _launch_hook
     _launch_hook = fn
 
@@ -179,7 +179,7 @@ def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stri
         check(lib().mas_conv_fwd(C.byref(d), _ptr(x), _ptr(ss), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), _stream()), "conv_fwd")
 
     if _launch_hook is not None:
-        _launch_hook("conv_fwd", (n, h, w, cin, ho, wo, cout, ks, stride), launch)
+        _launch_hook("conv_fwd", (n, h, w, cin, ho, wo, cout, ks, stride, act, int(residual is not None)), launch)
     else:
         launch()
     return y
@@ -196,7 +196,7 @@ def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ac
         check(lib().mas_conv_wgrad(C.byref(d), _ptr(x), _ptr(ss), _ptr(dy), _ptr(dw), _ptr(db), _stream()), "conv_wgrad")
 
     if _launch_hook is not None:
-        _launch_hook("conv_wgrad", (n, h, w, cin, ho, wo, cout, ks, stride), launch)
+        _launch_hook("conv_wgrad", (n, h, w, cin, ho, wo, cout, ks, stride, act, 0), launch)
     else:
         launch()
     if ks == 1:                                     # [cout,1,1,cin] == OIHW memory; a permute would keep odd size-1 strides (DDP warns)
@@ -487,6 +487,26 @@ def causal_attention(qkv: torch.Tensor, n_heads: int, dtype: Optional[torch.dtyp
     if dtype not in _DT:
         raise RuntimeError(f"causal_attention: dtype {dtype} not supported (float32 / bfloat16)")
     return _CausalAttention.apply(qkv, n_heads, dtype)
+
+
+def attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, past: int, n_heads: int) -> torch.Tensor:
+    """Inference-only cached attention (``mas_attn_decode``): q [B,nq,H*hd] (the new positions), k_cache / v_cache [B,S_max,H*hd]
+    whose rows 0 .. past+nq-1 are valid (the new keys / values already appended).  Query i attends to keys 0 .. past+i.
+    Returns the context [B,nq,H*hd]."""
+    _require_cuda(q, "attention_decode")
+    if q.dtype not in _DT or k_cache.dtype != q.dtype or v_cache.dtype != q.dtype:
+        raise RuntimeError("attention_decode: q / k / v must share a dtype in {float32, bfloat16}")
+    b, nq, d = q.shape
+    hd = d // n_heads
+    if k_cache.shape[0] != b or k_cache.shape[2] != d or v_cache.shape != k_cache.shape or past + nq > k_cache.shape[1]:
+        raise RuntimeError(f"attention_decode: cache {tuple(k_cache.shape)} does not hold past={past} + nq={nq} rows of width {d}")
+    if q.stride(2) != 1 or k_cache.stride(2) != 1 or v_cache.stride(2) != 1:
+        raise RuntimeError("attention_decode: the last dimension must be contiguous")
+    o = torch.empty((b, nq, d), dtype=q.dtype, device=q.device)
+    check(lib().mas_attn_decode(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(o), _DT[q.dtype], b, n_heads, nq, int(past), hd,
+                                q.stride(1), k_cache.stride(1), v_cache.stride(1), o.stride(1), q.stride(0), k_cache.stride(0),
+                                v_cache.stride(0), o.stride(0), float(hd) ** -0.5, _stream()), "attn_decode")
+    return o
 
 
 # --------------------------------------------------------------------------- #

@@ -2,11 +2,21 @@
 ``SelfAttention`` :17, ``MLP`` :118, ``TransformerLayer`` :142, ``Transformer`` :213, ``MakeAScene`` :275 --
 same constructor arguments, submodule names and ``state_dict`` keys (incl. the ``transformer.mask`` buffer).
 
-Training configuration only (no KV cache; pb-relax on, rudalle-relax off, sandwich layer-norm on -- the reference's
-defaults): the attention core is the flash-style HIP kernel (``mas_attn_causal_fwd``); the PB-relax shift
+Training configuration (pb-relax on, rudalle-relax off, sandwich layer-norm on -- the reference's defaults): the
+attention core is the flash-style HIP kernel (``mas_attn_causal_fwd``); the PB-relax shift
 (:64-70) subtracts a per-(batch, head) constant before the softmax and the per-layer ``mask * tril`` product (:260-263)
 is pure causal, so an online-softmax causal kernel computes the same function.  Linear / LayerNorm /
-embeddings are plain library calls (hipBLASLt GEMMs), as SURVEY 2.1 K11 allows."""
+embeddings are plain library calls (hipBLASLt GEMMs), as SURVEY 2.1 K11 allows.
+
+Sampling configuration (reference transformer.py:73-115,170-210 ``use_cache`` / ``cache``): KV-cached
+token-by-token decoding on ``mas_attn_decode`` (HBM-bound, one pass over the cached keys / values per new token).  The
+reference's cached branch cannot run as committed (``TransformerLayer`` passes ``cache`` / ``use_cache`` to
+``SelfAttention.forward`` in swapped positions, :181, and feeds the MLP the CACHED rows instead of the new ones, :199-200;
+SURVEY Appendix B) and nothing in the reference ever calls it with ``use_cache=True``; what is kept is its calling
+convention -- the layer receives the FULL sequence and a per-layer cache tuple whose first entry has the cached length on
+axis -2, computes only the new positions and returns full-length outputs -- and what is pinned is the only behaviour a
+cache can have: the logits of cached decoding equal those of the uncached forward (tests/test_gpu_sampling.py, and through
+it the reference's golden logits)."""
 import math
 
 import torch
@@ -45,14 +55,53 @@ class SelfAttention(nn.Module):
         self.rudalle_relax = rudalle_relax
 
     def forward(self, x, mask, use_cache=False, cache=None):
-        if use_cache or cache:
-            raise NotImplementedError("KV-cached sampling is SURVEY section 8(f) rank 3 (not built yet)")
         if self.rudalle_relax or (self.training and self.attn_drop.p > 0):
             raise NotImplementedError("rudalle_relax / attention dropout are off the measured path (reference defaults: off)")
-        qkv = self.qkv(x)
-        context = ops.causal_attention(qkv, self.num_attn_heads)     # `mask` is causal by construction (transformer.py:260-263)
-        out = self.out_proj(context)
-        return self.out_drop(out), cache
+        if not use_cache:
+            qkv = self.qkv(x)
+            context = ops.causal_attention(qkv, self.num_attn_heads)     # `mask` is causal by construction (transformer.py:260-263)
+            return self.out_drop(self.out_proj(context)), cache
+        return self._forward_cached(x, cache)
+
+    # ---- KV-cached inference (reference transformer.py:74-84,106-111) ------------------------------------------------------
+    # cache = (k, v, out): k, v are [B, H, L, hd] VIEWS (the reference's shapes: cached length on axis -2) of preallocated
+    # [B, S_max, H*hd] buffers in the layout nn.Linear emits, `out` is a [B, L, D] view of the projected outputs so far.
+    # x is the FULL sequence (reference convention); only x[:, L:] is computed.
+    def _forward_cached(self, x, cache):
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise RuntimeError("KV-cached attention is an inference path: call it under torch.no_grad()")
+        b, s_tot, d = x.shape
+        h = self.num_attn_heads
+        past = 0 if cache is None else cache[0].shape[-2]
+        nq = s_tot - past
+        if nq <= 0:
+            raise RuntimeError(f"SelfAttention: the cache already holds {past} positions, the input has {s_tot}")
+        qkv = self.qkv(x[:, past:, :])
+        dt = qkv.dtype
+        if cache is None:
+            cap = max(getattr(self, "cache_capacity", 0), s_tot)
+            kbuf = torch.empty((b, cap, d), dtype=dt, device=x.device)
+            vbuf = torch.empty_like(kbuf)
+            obuf = torch.empty_like(kbuf)
+        else:
+            kbuf, vbuf, obuf = (t._base if t._base is not None else t for t in cache)   # the buffers behind the views
+            kbuf, vbuf = kbuf.view(b, -1, d), vbuf.view(b, -1, d)
+            if kbuf.shape[1] < s_tot:                                                  # grow geometrically, copy once
+                cap = max(2 * kbuf.shape[1], s_tot)
+                grow = lambda t: torch.cat([t[:, :past], torch.empty((b, cap - past, d), dtype=t.dtype, device=t.device)], dim=1)
+                kbuf, vbuf, obuf = grow(kbuf), grow(vbuf), grow(obuf.view(b, -1, d))
+            obuf = obuf.view(b, -1, d)
+        kbuf[:, past:s_tot] = qkv[..., d:2 * d]
+        vbuf[:, past:s_tot] = qkv[..., 2 * d:]
+        q = qkv[..., :d]
+        if cache is None and nq > 1:
+            context = ops.causal_attention(qkv, h)                  # prefill: the training kernel on the whole prompt
+        else:
+            context = ops.attention_decode(q, kbuf, vbuf, past, h)  # decode: one pass over the cached rows
+        obuf[:, past:s_tot] = self.out_proj(context)
+        hd = d // h
+        view = lambda t: t[:, :s_tot].view(b, s_tot, h, hd).permute(0, 2, 1, 3)
+        return self.out_drop(obuf[:, :s_tot]), (view(kbuf), view(vbuf), obuf[:, :s_tot])
 
 
 class MLP(nn.Module):
@@ -90,7 +139,9 @@ class TransformerLayer(nn.Module):
         return t / t.detach().max(dim=-1)[0].unsqueeze(-1) if self.cogview_layernorm_prescale else t
 
     def forward(self, x, mask, cache=None, use_cache=False, mlp_cache=False):
-        attn_out, new_cache = self.attn(self.ln_in(self._prescale(x)), mask, use_cache, cache)
+        if use_cache:
+            return self._forward_cached(x, cache)
+        attn_out, new_cache = self.attn(self.ln_in(self._prescale(x)), mask, False, cache)
         if self.cogview_sandwich_layernorm:
             x = self.first_ln_sandwich(self._prescale(attn_out), residual=x)        # x + LN(attn_out), one pass
         else:
@@ -99,6 +150,37 @@ class TransformerLayer(nn.Module):
         if self.cogview_sandwich_layernorm:
             return self.second_ln_sandwich(mlp_out, residual=x), new_cache
         return x + mlp_out, new_cache
+
+    def _forward_cached(self, x, cache):
+        """Full sequence in, full sequence out, only the positions past the cache computed (reference transformer.py:170-210
+        with its two defects fixed, see the module docstring).  cache = (k, v, attn_out, layer_out): the attention's tuple plus
+        this layer's own outputs so far (the reference keeps those for the last layer only, ``mlp_cache``)."""
+        past = 0 if cache is None else cache[0].shape[-2]
+        x_new = x[:, past:, :]
+        ln = self.ln_in(self._prescale(x_new))
+        if cache is not None:      # the attention slices its input at the cached length: hand it a full-length tensor whose
+            ln_full = x.new_empty(x.shape[:-1] + (ln.shape[-1],), dtype=ln.dtype)   # cached rows are never read
+            ln_full[:, past:] = ln
+        else:
+            ln_full = ln
+        attn_full, kv = self.attn(ln_full, None, True, None if cache is None else cache[:3])
+        attn_new = attn_full[:, past:, :]
+        if self.cogview_sandwich_layernorm:
+            h = self.first_ln_sandwich(self._prescale(attn_new), residual=x_new)
+        else:
+            h = x_new + attn_new
+        mlp_out = self.mlp(self.ln_out(self._prescale(h)))
+        y_new = self.second_ln_sandwich(mlp_out, residual=h) if self.cogview_sandwich_layernorm else h + mlp_out
+        if cache is None:
+            ybuf = torch.empty((x.shape[0], kv[0]._base.view(x.shape[0], -1, x.shape[-1]).shape[1], x.shape[-1]), dtype=y_new.dtype,
+                               device=x.device)
+        else:
+            ybuf = cache[3]._base if cache[3]._base is not None else cache[3]
+            if ybuf.shape[1] < x.shape[1]:
+                ybuf = torch.cat([ybuf[:, :past], torch.empty((x.shape[0], 2 * ybuf.shape[1] - past, x.shape[-1]), dtype=ybuf.dtype,
+                                                              device=x.device)], dim=1)
+        ybuf[:, past:x.shape[1]] = y_new
+        return ybuf[:, :x.shape[1]], kv + (ybuf[:, :x.shape[1]],)
 
 
 class Transformer(nn.Module):
@@ -122,11 +204,16 @@ class Transformer(nn.Module):
     def forward(self, x, attn_mask, cache=None, use_cache=None):
         if cache is None:
             cache = {}
+        past = 0
+        if use_cache and cache.get(0) is not None:
+            past = cache[0][0].shape[-2]
         for i, layer in enumerate(self.layers):
             # attn_mask * self.mask is pure causal: nothing to materialise for the kernel
             x, layer_cache = layer(x, None, cache.get(i), mlp_cache=i == len(self.layers) - 1, use_cache=use_cache)
             cache[i] = layer_cache
-        return self.final_ln(x), cache
+        # cached decoding: the final LayerNorm of the positions computed by THIS call only (everything the caller can need:
+        # rows are independent, and the earlier ones were returned by the earlier calls)
+        return self.final_ln(x[:, past:] if past else x), cache
 
 
 class MakeAScene(nn.Module):
@@ -183,13 +270,70 @@ class MakeAScene(nn.Module):
         ids = torch.arange(past_length, n + past_length, dtype=torch.long, device=self.device)
         return self.image_row_embeddings((ids // self.image_tokens_per_dim)[None]) + self.image_col_embeddings((ids % self.image_tokens_per_dim)[None])
 
-    def forward(self, text_tokens, seg_tokens, img_tokens):
+    def _prompt_embeddings(self, text_tokens, seg_tokens):
         # zero padding -> unique per-position ids from the vocabulary tail (transformer.py:350-353)
         text_range = (torch.arange(self.text_length) + (self.text_vocab_size - self.text_length)).to(self.device)
         text_tokens = torch.where(text_tokens == 0, text_range, text_tokens)
         text_pos = self.text_pos_embeddings(torch.arange(text_tokens.shape[1], device=self.device))
-        embeddings = torch.cat((self.text_token_embedding(text_tokens) + text_pos,
-                                self.seg_token_embedding(seg_tokens) + self.get_seg_pos_embeddings(seg_tokens)), dim=1)
+        return torch.cat((self.text_token_embedding(text_tokens) + text_pos,
+                          self.seg_token_embedding(seg_tokens) + self.get_seg_pos_embeddings(seg_tokens)), dim=1)
+
+    @torch.no_grad()
+    def generate(self, text_tokens, seg_tokens, temperature=1.0, top_k=None, cond_scale=None, generator=None, img_tokens=None,
+                 return_logits=False):
+        """Autoregressive sampling of the ``image_length`` image tokens given text + segmentation tokens, KV-cached: one prefill
+        over the prompt (the training attention kernel), then one ``mas_attn_decode`` pass per layer and token.
+        ``temperature`` 0 -> greedy; ``top_k`` keeps the k most likely tokens; ``cond_scale`` s -> classifier-free guidance
+        against the text-free stream the reference trains for (train.py:147-148 zeroes the text with probability ``uncond_p``):
+        logits = l_uncond + s * (l_cond - l_uncond).  ``img_tokens`` [B, image_length]: teacher forcing (the given tokens are fed
+        instead of the sampled ones -- used by the tests to compare every step's logits with the uncached forward).
+        Returns the tokens [B, image_length] (int64) -- ``VQBASE.decode_code`` turns them into an image -- and, with
+        ``return_logits``, the logits [B, image_length, vocab] they were drawn from."""
+        b = text_tokens.shape[0]
+        guided = cond_scale is not None
+        if guided:
+            text_tokens = torch.cat([text_tokens, torch.zeros_like(text_tokens)], dim=0)
+            seg_tokens = torch.cat([seg_tokens, seg_tokens], dim=0)
+        prompt = self._prompt_embeddings(text_tokens, seg_tokens)
+        bb, plen, d = prompt.shape
+        for layer in self.transformer.layers:
+            layer.attn.cache_capacity = self.total_length
+        buf = prompt.new_empty((bb, self.total_length, d))
+        buf[:, :plen] = prompt
+        cur = plen
+        hidden, cache = self.transformer(buf[:, :cur], None, cache={}, use_cache=True)
+        tokens = torch.empty((b, self.image_length), dtype=torch.long, device=prompt.device)
+        all_logits = [] if return_logits else None
+        for i in range(self.image_length):
+            logits = self.to_logits(hidden[:, -1:, :])[:, 0, :].float()
+            if guided:
+                logits = logits[b:] + float(cond_scale) * (logits[:b] - logits[b:])
+            if return_logits:
+                all_logits.append(logits)
+            if img_tokens is not None:
+                tok = img_tokens[:, i]
+            elif temperature == 0:
+                tok = logits.argmax(dim=-1)
+            else:
+                lg = logits / float(temperature)
+                if top_k is not None:
+                    kth = torch.topk(lg, int(top_k), dim=-1).values[:, -1:]
+                    lg = lg.masked_fill(lg < kth, float("-inf"))
+                tok = torch.multinomial(torch.softmax(lg, dim=-1), 1, generator=generator)[:, 0]
+            tokens[:, i] = tok
+            if i + 1 == self.image_length:
+                break
+            t_in = torch.cat([tok, tok], dim=0) if guided else tok
+            emb = self.image_token_embedding(t_in[:, None]) + self.get_image_pos_embeddings(t_in[:, None], past_length=i)
+            buf[:, cur] = emb[:, 0]
+            cur += 1
+            hidden, cache = self.transformer(buf[:, :cur], None, cache=cache, use_cache=True)
+        if return_logits:
+            return tokens, torch.stack(all_logits, dim=1)
+        return tokens
+
+    def forward(self, text_tokens, seg_tokens, img_tokens):
+        embeddings = self._prompt_embeddings(text_tokens, seg_tokens)
         if img_tokens is not None:
             embeddings = torch.cat((embeddings, self.image_token_embedding(img_tokens) + self.get_image_pos_embeddings(img_tokens)), dim=1)
         # transformer.py:366-370 builds tril-with-bidirectional-prefix, which the layers multiply by tril again: causal

@@ -28,6 +28,18 @@ class VQBASE(nn.Module):
         quant, emb_loss, info = self.quantize(h)
         return quant, emb_loss
 
+    @torch.no_grad()
+    def encode_to_indices(self, x):
+        """Frozen-VQ tokenisation for stage 2: images -> codebook indices [B, h*w] (int64), row-major over
+        the latent grid -- what ``train.py:141-145`` consumes as ``img_token`` / ``seg_token``.  The reference's ``encode``
+        drops the indices (vqvae.py:23-24); this is the same encoder -> quant_conv -> Codebook lookup, keeping them.  Call in
+        ``eval()`` mode (SyncBatchNorm running statistics; the codebook warm-up schedule untouched)."""
+        if self.training:
+            raise RuntimeError("encode_to_indices: tokenise with the frozen model in eval() mode")
+        h = self.quant_conv(self.encoder(x))
+        _, _, idx = self.quantize(h)
+        return idx.view(x.shape[0], -1)
+
     def decode(self, quant):
         quant = self.post_quant_conv(quant)
         dec = self.decoder(quant)

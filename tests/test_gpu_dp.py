@@ -133,3 +133,32 @@ def test_ddp_wrapper_two_ranks_equal_full_batch(tmp_path):
             assert np.abs(got[k] - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-6, k
             checked += 1
     assert checked > 40
+
+
+def test_bench_py_multi_rank_branch_end_to_end():
+    """bench.py's N > 1 branch (process group, GradReducer, SyncBatchNorm exchange, barrier + max-over-ranks timing, replica
+    checksum) run end to end by pytest: two ranks share the one GPU over gloo (RCCL refuses two ranks per device; the 8-GPU RCCL
+    run is the driver's).  Small batch, 1 + 1 steps."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MAS_BENCH_SHARE_GPU="1", MAS_BENCH_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                                       "--batch", "2", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][1][-1500:] + outs[1][1][-1500:]
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 4 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["replica_weight_checksum_spread"] == 0.0                  # both replicas applied the same averaged gradients
+    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]   # only rank 0 prints
