@@ -379,7 +379,7 @@ def run_transformer(args, e2e):
         with torch.no_grad():
             vq_img.quantize.embedding.weight.normal_(0.0, 1.0)
             vq_seg.quantize.embedding.weight.normal_(0.0, 1.0)
-        images = torch.rand(batch, 3, 256, 256, generator=g).to(dev)
+        images = torch.rand(batch, 3, 512, 512, generator=g).to(dev)      # 512x512 -> 32x32 = 1024 image tokens (img_config.yaml: resolution 512)
         segs = torch.rand(batch, 159, 256, 256, generator=g).to(dev)      # soft one-hot-like maps of the 159 classes
     else:
         seg_tok = torch.randint(0, 256, (batch, 256), generator=g).to(dev)
@@ -432,7 +432,7 @@ def run_transformer(args, e2e):
         if e2e:
             out = {"metric": "end-to-end stage-2 samples/sec/node (frozen VQ-SEG + VQ-IMG encode -> AR transformer fwd+bwd+Adam)",
                    "value": round(samples / dt, 2), "unit": "samples/s"}
-            wl = (f"BASELINE configs[4]: frozen VQ-IMG (256x256x3) + VQ-SEG (256x256x159) encode -> 1024 + 256 tokens -> MakeAScene 24L/1024d/16h "
+            wl = (f"BASELINE configs[4]: frozen VQ-IMG (512x512x3) + VQ-SEG (256x256x159) encode -> 1024 + 256 tokens -> MakeAScene 24L/1024d/16h "
                   f"(S={S}) cross-entropy fwd+bwd + Adam, micro-batch {micro} x {batch // micro} accumulation")
         else:
             out = {"metric": "MakeAScene 24L/1024d transformer tokens/sec/node (fwd+bwd+Adam, S=1536)",

@@ -154,10 +154,10 @@ def test_frozen_vq_tokenisation_roundtrip(tmp_path):
             rec, _ = m(x)
         h.remove()
         tok = m.encode_to_indices(x)
-        assert tok.shape == (3, 16) and tok.dtype == torch.int64
+        assert tok.shape == (3, 64) and tok.dtype == torch.int64      # 32x32 input, two Downsamples -> 8x8 latent grid
         assert torch.equal(tok.reshape(-1), got["idx"].reshape(-1))
         with torch.no_grad():
-            rec2 = m.decode_code(tok.view(3, 4, 4))
+            rec2 = m.decode_code(tok.view(3, 8, 8))
         assert relerr(rec2, rec.cpu()) < 1e-5
         it, st = TD.tokenize_batch(m, m, x, x)
         paths = TD.write_token_shards(str(tmp_path), [(it, st, torch.zeros(3, 8, dtype=torch.long))], 64, 64, 100)
