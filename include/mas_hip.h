@@ -39,7 +39,8 @@ enum { MAS_ACT_NONE = 0,      /* a = x                                   */
 typedef struct MasConvDesc {
     int32_t N, H, W, Cin;       /* input  [N,H,W,Cin]  (the tensor in memory; before any upsample fold) */
     int32_t Ho, Wo, Cout;       /* output [N,Ho,Wo,Cout] */
-    int32_t ks;                 /* 1 or 3 (square)  */
+    int32_t ks;                 /* 1 or 3 (square); bf16 also 4 (forward / data gradient, stride 1 or 2) and 2 / 4 stride 1 (weight gradient):
+                                   the PatchGAN discriminator of the loss stack, losses/discriminator.py:20-36 */
     int32_t stride;             /* 1 or 2           */
     int32_t pad_top, pad_left;  /* input row = ho*stride + kh - pad_top ; rows/cols outside [0,H)x[0,W) read 0
                                    (covers padding=1, and the right/bottom-only pad of Downsample, modules.py:76-78) */
@@ -162,6 +163,10 @@ int mas_attn_decode(const void* q, const void* k_cache, const void* v_cache, voi
 int mas_upsample2x(const void* x, void* y, int dtype, int N, int H, int W, int C, void* stream);
 int mas_sumpool2x(const void* x, void* y, int dtype, int N, int Ho, int Wo, int C, void* stream);
 int mas_zero_stuff2x(const void* x, void* y, int dtype, int N, int H, int W, int C, int Hout, int Wout, void* stream);
+/* y[n][h'][w'][(dy*2+dx)*C + c] = x[n][2h'+dy-pad][2w'+dx-pad][c] (0 outside), y is [N,Ho,Wo,4C]: a stride-2 K x K convolution of x
+ * equals the stride-1 (K/2) x (K/2) convolution of y -- the weight gradient of the discriminator's 4x4 stride-2 convolutions
+ * (losses/discriminator.py:20,27) runs as mas_conv_wgrad with ks = 2 on y.                                                       */
+int mas_space_to_depth2x(const void* x, void* y, int dtype, int N, int H, int W, int C, int Ho, int Wo, int pad, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Transformer row operators (streaming, HBM-bound).

@@ -586,6 +586,12 @@ int launch_ks(const ConvParams& p, int ks, int stride, hipStream_t s) {
     if (ks == 1 && stride == 1) return launch_bc<T, TO, 1, 1>(p, s);
     if (ks == 3 && stride == 1) return launch_bc<T, TO, 3, 1>(p, s);
     if (ks == 3 && stride == 2) return launch_bc<T, TO, 3, 2>(p, s);
+    if constexpr (sizeof(T) == 2) {
+        // the 4x4 / pad-1 geometries of the PatchGAN discriminator (reference losses/discriminator.py:20-36: stride 2 and stride 1),
+        // and the 4x4 stride-1 / pad-2 convolutions that are their data gradients -- bf16 input only, bf16 or fp32 output
+        if (ks == 4 && stride == 1) return launch_bc<T, TO, 4, 1>(p, s);
+        if (ks == 4 && stride == 2) return launch_bc<T, TO, 4, 2>(p, s);
+    }
     MAS_FAIL(MAS_EUNSUPPORTED, "conv_fwd: unsupported ks=%d stride=%d", ks, stride);
 }
 

@@ -716,9 +716,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgradParams p) {
 #ifndef MAS_WGRAD_TR_BCI
 #define MAS_WGRAD_TR_BCI 64
 #endif
-template <int KS>
+template <int KS, int BCI_ = MAS_WGRAD_TR_BCI>
 int launch_tr(WgradParams p, hipStream_t s) {
-    constexpr int BCI_ = MAS_WGRAD_TR_BCI;
     using G = TrGeo<KS, BCI_>;
     auto kern = conv_wgrad_tr_kernel<KS, BCI_>;
     static mas_devmask_t attr_mask{0};
@@ -772,6 +771,11 @@ int launch_t(const WgradParams& p, int ks, int stride, hipStream_t s) {
         if (stride == 1 && (p.Cout % 8) == 0 && (p.Cin % 8) == 0 && !no_tr) {
             if (ks == 3) return launch_tr<3>(p, s);
             if (ks == 1) return launch_tr<1>(p, s);
+            // discriminator geometries (reference losses/discriminator.py:20-36): 4x4 stride 1 directly (32-channel input
+            // slices: two waves share a 32x32 tile and split the 16 taps 8 / 8); 4x4 stride 2 as the 2x2 stride-1
+            // convolution of the space-to-depth input (mas_space_to_depth2x; the host wrapper un-permutes dW)
+            if (ks == 4) return launch_tr<4, 32>(p, s);
+            if (ks == 2) return launch_tr<2, 64>(p, s);
         }
     }
     if (ks == 1 && stride == 1) return launch<T, 1, 1, 8>(p, s);

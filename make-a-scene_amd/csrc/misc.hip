@@ -146,6 +146,27 @@ __global__ __launch_bounds__(NT) void zero_stuff2x_kernel(const T* __restrict__ 
     }
 }
 
+// y[n][h'][w'][(dy*2+dx)*C + c] = x[n][2h'+dy-pad][2w'+dx-pad][c]  (0 outside): a stride-2 KxK convolution of x is the stride-1
+// (K/2)x(K/2) convolution of y -- used for the WEIGHT gradient of the discriminator's 4x4 stride-2 convolutions
+// (reference losses/discriminator.py:20,27), which then runs on the stride-1 transpose-read wgrad kernel with ks = 2
+template <typename T>
+__global__ __launch_bounds__(NT) void space_to_depth2x_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C,
+                                                              int Ho, int Wo, int pad) {
+    constexpr int EPU = 16 / (int)sizeof(T);
+    const int upp = C / EPU;
+    const long long total = (long long)N * Ho * Wo * 4 * upp;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+        const int cu = (int)(i % upp); long long r = i / upp;
+        const int q = (int)(r % 4); r /= 4;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho); const int n = (int)(r / Ho);
+        const int ih = 2 * ho + (q >> 1) - pad, iw = 2 * wo + (q & 1) - pad;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = *reinterpret_cast<const u32x4*>(x + (((size_t)n * H + ih) * W + iw) * C + cu * EPU);
+        *reinterpret_cast<u32x4*>(y + (size_t)i * EPU) = v;
+    }
+}
+
 int grid_for(long long total) {
     long long b = (total + NT - 1) / NT;
     if (b > 8192) b = 8192;
@@ -164,7 +185,7 @@ extern "C" int mas_pack_conv_weight(const float* w_oihw, void* packed, int Cout,
                                     void* stream) {
     MAS_ENTER();
     if (!w_oihw || !packed) MAS_FAIL(MAS_EINVAL, "pack_conv_weight: null argument");
-    if (Cout <= 0 || Cin <= 0 || (ks != 1 && ks != 3)) MAS_FAIL(MAS_EINVAL, "pack_conv_weight: bad shape");
+    if (Cout <= 0 || Cin <= 0 || (ks < 1 || ks > 4)) MAS_FAIL(MAS_EINVAL, "pack_conv_weight: bad shape");
     const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
     const int rows_pad = mas_roundup(rows, 128);
     const int ck = dtype == MAS_BF16 ? 64 : 32;
@@ -218,6 +239,11 @@ extern "C" int mas_sumpool2x(const void* x, void* y, int dtype, int N, int Ho, i
     MAS_ENTER();
     if (!x || !y) MAS_FAIL(MAS_EINVAL, "sumpool2x: null argument");
     MAS_DISPATCH_NHWC("sumpool2x", sumpool2x_kernel, (long long)N * Ho * Wo * C, N, Ho, Wo, C);
+}
+extern "C" int mas_space_to_depth2x(const void* x, void* y, int dtype, int N, int H, int W, int C, int Ho, int Wo, int pad, void* stream) {
+    MAS_ENTER();
+    if (!x || !y) MAS_FAIL(MAS_EINVAL, "space_to_depth2x: null argument");
+    MAS_DISPATCH_NHWC("space_to_depth2x", space_to_depth2x_kernel, (long long)N * Ho * Wo * 4 * C, N, H, W, C, Ho, Wo, pad);
 }
 extern "C" int mas_zero_stuff2x(const void* x, void* y, int dtype, int N, int H, int W, int C, int Hout, int Wout, void* stream) {
     MAS_ENTER();

@@ -1,0 +1,4 @@
+"""The VQGAN loss stack behind the reference's surface (reference losses/__init__.py:1-2): same import paths and class names, so
+``conf/*.yaml`` (``_target_: losses.loss_img.VQLPIPSWithDiscriminator``, ``losses.VQVAEWithBCELoss``) resolve unchanged."""
+from .loss_seg import BCELossWithQuant, VQVAEWithBCELoss
+from .loss_img import VQLPIPSWithDiscriminator

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "mas_upsample2x": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "mas_sumpool2x": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "mas_zero_stuff2x": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mas_space_to_depth2x": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "mas_gelu_tanh_fwd": (_i, [_p, _p, _i, C.c_longlong, _p]),
     "mas_gelu_tanh_bwd": (_i, [_p, _p, _p, _i, C.c_longlong, _p]),
     "mas_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),

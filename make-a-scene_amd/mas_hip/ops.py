@@ -186,6 +186,16 @@ def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stri
 
 
 def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, upsample, want_bias):
+    if ks == 4 and stride == 2:
+        # the discriminator's 4x4 / stride-2 convolutions (reference losses/discriminator.py:20,27): the stride-2 4x4 correlation of x
+        # is the stride-1 2x2 correlation of its (padded) space-to-depth image, so the weight gradient runs on the stride-1
+        # transpose-read kernel with ks = 2 and 4 Cin channels; dW' [co][(dy,dx,c)][kh'][kw'] -> dW [co][c][2kh'+dy][2kw'+dx]
+        if act != ACT_NONE or upsample or pt != pl:
+            raise RuntimeError("conv_wgrad: the 4x4 stride-2 geometry takes no prologue / upsample fold and needs pad_top == pad_left")
+        xs = space_to_depth2x(x, ho + 1, wo + 1, pt)
+        dws, db = conv_wgrad_raw(xs, None, dy, n, ho + 1, wo + 1, 4 * cin, ho, wo, cout, 2, 1, 0, 0, ACT_NONE, False, want_bias)
+        dw = dws.view(cout, 2, 2, cin, 2, 2).permute(0, 3, 4, 1, 5, 2).reshape(cout, cin, 4, 4)
+        return dw, db
     nw = cout * ks * ks * cin                       # dw and db share one zero-filled allocation (one fill launch)
     acc = torch.zeros(nw + (cout if want_bias else 0), dtype=torch.float32, device=x.device)
     dw = acc[:nw].view(cout, ks, ks, cin)
@@ -215,6 +225,14 @@ def sumpool2x(x):
     n, c, h2, w2 = x.shape
     y = _empty_nhwc(n, c, h2 // 2, w2 // 2, x.dtype, x.device)
     check(lib().mas_sumpool2x(_ptr(x), _ptr(y), _DT[x.dtype], n, h2 // 2, w2 // 2, c, _stream()), "sumpool2x")
+    return y
+
+
+def space_to_depth2x(x, ho, wo, pad):
+    """[N,C,H,W] -> [N,4C,ho,wo]: channel (dy*2+dx)*C + c of output pixel (h',w') = x[c, 2h'+dy-pad, 2w'+dx-pad] (0 outside)."""
+    n, c, h, w = x.shape
+    y = _empty_nhwc(n, 4 * c, ho, wo, x.dtype, x.device)
+    check(lib().mas_space_to_depth2x(_ptr(x), _ptr(y), _DT[x.dtype], n, h, w, c, ho, wo, int(pad), _stream()), "space_to_depth2x")
     return y
 
 

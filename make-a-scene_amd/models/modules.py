@@ -69,9 +69,9 @@ class Conv2d(nn.Conv2d):
         return super().train(mode)
 
     def forward(self, x, residual=None, upsample=False):
-        if self.kernel_size[0] != self.kernel_size[1] or self.kernel_size[0] not in (1, 3) or self.stride[0] not in (1, 2) \
+        if self.kernel_size[0] != self.kernel_size[1] or self.kernel_size[0] not in (1, 3, 4) or self.stride[0] not in (1, 2) \
                 or self.dilation != (1, 1) or self.groups != 1:
-            raise NotImplementedError("libmas_hip conv supports 1x1 / 3x3, stride 1 / 2, dense, undilated")
+            raise NotImplementedError("libmas_hip conv supports 1x1 / 3x3 (and, bf16, 4x4), stride 1 / 2, dense, undilated")
         return ops.norm_act_conv(x, self.weight, self.bias, None, None, residual, stride=self.stride[0], padding=self._pad4(),
                                  act=ACT_NONE, upsample=upsample, in_dtype=self.in_dtype, out_dtype=self.out_dtype)
 

@@ -1,0 +1,171 @@
+"""SURVEY 8(f) rank 1 on the MI355X: the 4x4 convolution geometries of the PatchGAN discriminator (forward, data gradient, weight
+gradient; stride 2 and 1) against torch fp32 on CPU; ``losses.discriminator.Discriminator`` against the REFERENCE's own
+discriminator (tests/golden/disc_tiny.npz: logits train / eval, hinge + generator losses, parameter and input gradients, the
+BatchNorm running statistics); ``VQLPIPSWithDiscriminator`` (adaptive weight through the decoder's HIP autograd nodes with
+``retain_graph``, the ``change_requires_grad`` dance of reference train.py:86-98) against oracle/loss_oracle.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def relerr(got, ref):
+    got = got.detach().float().cpu()
+    ref = torch.as_tensor(np.asarray(ref)).float() if not isinstance(ref, torch.Tensor) else ref.detach().float().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("case", [
+    # n, cin, h, w, cout, stride, bias
+    (2, 3, 64, 64, 64, 2, True),         # layer 0: RGB in (channel axis padded to one 16-byte slot)
+    (2, 64, 32, 32, 128, 2, False),      # layer 2
+    (3, 128, 20, 28, 256, 2, False),     # layer 5, a non-square map
+    (2, 256, 9, 9, 512, 1, False),       # layer 8: stride 1 (9 -> 8)
+    (2, 512, 8, 8, 1, 1, True),          # layer 11: one output channel (padded to a slot), fp32 logits
+    (1, 64, 33, 31, 64, 2, True),        # odd sizes: the last stride-2 window hangs over the border
+])
+def test_conv4x4_fwd_dgrad_wgrad_vs_torch(case):
+    from models.modules import Conv2d
+    n, cin, h, w, cout, stride, bias = case
+    dev = _dev()
+    g = torch.Generator().manual_seed(h * 100 + cin)
+    x = torch.randn(n, cin, h, w, generator=g)
+    conv = Conv2d(cin, cout, 4, stride, 1, bias=bias)
+    conv.in_dtype = torch.bfloat16
+    conv.out_dtype = torch.float32 if cout == 1 else torch.bfloat16
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(cout, cin, 4, 4, generator=g) / (16 * cin) ** 0.5)
+    xr = x.bfloat16().float().requires_grad_(True)
+    wr = conv.weight.detach().bfloat16().float().requires_grad_(True)
+    br = conv.bias.detach().clone().requires_grad_(True) if bias else None
+    ref = F.conv2d(xr, wr, br, stride=stride, padding=1)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go.bfloat16().float() if cout != 1 else go)
+    conv = conv.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    y = conv(xd)
+    assert y.shape == ref.shape and y.dtype == conv.out_dtype
+    y.backward(go.to(dev).to(y.dtype))
+    assert relerr(y, ref) < 1.5e-2
+    assert relerr(xd.grad, xr.grad) < 2e-2
+    assert relerr(conv.weight.grad, wr.grad) < 2e-2
+    if bias:
+        assert relerr(conv.bias.grad, br.grad) < 2e-2
+
+
+def _disc(dev, train=True):
+    from losses.discriminator import Discriminator
+    from oracle import loss_oracle as LO
+    d = Discriminator()
+    d.load_state_dict(LO.synth_disc_state_dict(seed=7), strict=True)
+    return d.to(dev).train(train)
+
+
+def test_discriminator_vs_reference_golden(golden_dir):
+    dev = _dev()
+    g = np.load(os.path.join(golden_dir, "disc_tiny.npz"))
+    real, fake = torch.from_numpy(g["real"]).to(dev), torch.from_numpy(g["fake"]).to(dev).requires_grad_(True)
+    from losses.loss_img import hinge_d_loss, vanilla_d_loss, adopt_weight
+    d = _disc(dev, train=False)
+    with torch.no_grad():
+        assert relerr(d(real), g["logits_real_eval"]) < 3e-2
+    d.train()
+    lr, lf = d(real), d(fake)
+    assert lr.dtype == torch.float32 and lr.shape == (2, 1, 6, 6)
+    print(f"disc logits real {relerr(lr, g['logits_real']):.2e} fake {relerr(lf, g['logits_fake']):.2e}")
+    assert relerr(lr, g["logits_real"]) < 3e-2 and relerr(lf, g["logits_fake"]) < 3e-2
+    d_loss = hinge_d_loss(lr, lf)
+    assert abs(float(d_loss) - float(g["hinge"])) < 3e-2 * abs(float(g["hinge"])) + 1e-3
+    assert abs(float(vanilla_d_loss(lr, lf)) - float(g["vanilla"])) < 3e-2 * abs(float(g["vanilla"])) + 1e-3
+    g_loss = -lf.mean()
+    (gin,) = torch.autograd.grad(g_loss, fake, retain_graph=True)
+    assert relerr(gin, g["grad_fake:g_loss"]) < 6e-2
+    d_loss.backward()
+    params = dict(d.named_parameters())
+    for k in g.files:
+        if k.startswith("grad:"):
+            got = params[k[5:]].grad
+            got = got[::8, ::8] if got.numel() > 200000 else got
+            e = relerr(got, g[k])
+            print(f"  {k} relerr {e:.2e}")
+            assert e < 6e-2, k
+    assert relerr(d.model[3].running_mean, g["running_mean:model.3"]) < 3e-2          # two training-mode forwards, momentum 0.1
+    assert relerr(d.model[3].running_var, g["running_var:model.3"]) < 3e-2
+    assert adopt_weight(0.8, 10, threshold=20) == 0.0 and adopt_weight(0.8, 30, threshold=20) == 0.8
+
+
+def test_vqgan_loss_adaptive_weight_and_requires_grad_dance():
+    """the two branches of VQLPIPSWithDiscriminator.forward on a tiny VQBASE, exactly as reference train.py:84-98 drives them,
+    against oracle/loss_oracle.py fed the SAME reconstruction (so only the loss stack is compared, in bf16 / fp32 mixed precision)"""
+    from losses import VQLPIPSWithDiscriminator
+    from mas_hip import ops
+    from models import VQBASE
+    from oracle import loss_oracle as LO
+    from oracle import vq_oracle as O
+    dev = _dev()
+    cfg = dict(ddconfig=dict(z_channels=32, in_channels=3, out_channels=3, channels=[32, 32, 64], num_res_blocks=1, resolution=64,
+                             attn_resolutions=[16], dropout=0.0), n_embed=64, embed_dim=32, init_steps=3000, reservoir_size=12500)
+    old = ops.compute_dtype()
+    ops.set_compute_dtype(torch.float32)
+    try:
+        m = VQBASE(**cfg)
+        m.load_state_dict(O.synth_state_dict(cfg["ddconfig"], 64, 32, seed=0), strict=True)
+        m = m.to(dev).train()
+        m.quantize.q_counter = m.quantize.q_re_end
+        loss_fn = VQLPIPSWithDiscriminator(disc_start=5, disc_weight=0.8).to(dev)
+        sd_d = LO.synth_disc_state_dict(seed=3)
+        loss_fn.discriminator.load_state_dict(sd_d, strict=True)
+        img = O.synth_image_batch(2, 3, 64, seed=4).to(dev)
+        change = lambda mod, flag: [p.requires_grad_(flag) for p in mod.parameters()]     # reference utils.py:27-29
+
+        rec, q_loss = m(img)
+        # ---- discriminator step (train.py:86-89)
+        change(m, False)
+        d_loss = loss_fn(optimizer_idx=1, global_step=10, images=img, reconstructions=rec)
+        d_loss.backward()
+        change(m, True)
+        assert all(p.grad is None for p in m.parameters())
+        # ---- generator step (train.py:91-97)
+        change(loss_fn.discriminator, False)
+        loss, (nll, obj, face) = loss_fn(optimizer_idx=0, global_step=10, images=img, reconstructions=rec, codebook_loss=q_loss,
+                                         last_layer=m.decoder.model[-1])
+        loss.backward()
+        change(loss_fn.discriminator, True)
+        assert float(obj) == 0.0 and float(face) == 0.0
+        # ---- oracle on the same reconstruction (a leaf standing in for the decoder output; its `last layer` is a 1x1 conv so that
+        #      the adaptive weight's two gradients exist): compare the pieces that do not depend on the decoder
+        sd_cpu = {k: v.clone() for k, v in sd_d.items()}
+        rec_c = rec.detach().float().cpu()
+        ref_d = LO.discriminator_loss(sd_cpu, img.cpu(), rec_c, 10, 5)
+        assert abs(float(d_loss) - float(ref_d)) < 3e-2 * abs(float(ref_d)) + 1e-3
+        ref_nll = torch.mean(torch.abs(img.cpu() - rec_c))
+        assert abs(float(nll) - float(ref_nll)) < 1e-5
+        # adaptive weight: recompute with plain autograd.grad on OUR graph and compare with what forward used
+        rec2, q2 = m(img)
+        nll2 = torch.mean(torch.abs(img - rec2))
+        g2 = -torch.mean(loss_fn.discriminator(rec2))
+        w_last = m.decoder.model[-1].weight
+        n1 = torch.autograd.grad(nll2, w_last, retain_graph=True)[0]
+        n2 = torch.autograd.grad(g2, w_last, retain_graph=True)[0]
+        d_w = torch.clamp(n1.norm() / (n2.norm() + 1e-4), 0.0, 1e4) * 0.8
+        assert abs(float(loss_fn.calculate_adaptive_weight(nll2, g2, m.decoder.model[-1])) - float(d_w)) < 1e-5 * float(d_w)
+        ref_total = nll2 + d_w * g2 + q2
+        loss2, _ = loss_fn(optimizer_idx=0, global_step=10, images=img, reconstructions=rec2, codebook_loss=q2, last_layer=m.decoder.model[-1])
+        assert abs(float(loss2) - float(ref_total)) < 2e-2 * abs(float(ref_total)) + 1e-3     # (two discriminator forwards: BN batch stats identical)
+        # below the start step the generator term is switched off (adopt_weight)
+        loss3, _ = loss_fn(optimizer_idx=0, global_step=1, images=img, reconstructions=rec2, codebook_loss=q2, last_layer=m.decoder.model[-1])
+        assert abs(float(loss3) - float(nll2 + q2)) < 1e-4
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+        assert all(p.grad is not None for p in loss_fn.discriminator.parameters())
+    finally:
+        ops.set_compute_dtype(old)

@@ -134,3 +134,35 @@ def test_transformer_tiny_matches_reference(golden_dir):
     for k in g.files:
         if k.startswith("grad:"):
             _close(sd[k[5:]].grad, g[k], rtol=2e-3, atol=1e-6)
+
+
+def test_loss_oracle_vs_reference_discriminator_golden(golden_dir):
+    """oracle/loss_oracle.py (PatchGAN forward, hinge / vanilla, BatchNorm train + eval) == the reference's own
+    losses/discriminator.py + loss_img.py functions (tests/golden/disc_tiny.npz, made by make_loss_golden.py)"""
+    import numpy as np
+    import torch
+    from oracle import loss_oracle as LO
+    g = np.load(os.path.join(golden_dir, "disc_tiny.npz"))
+    sd = LO.synth_disc_state_dict(seed=7)
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    real = torch.from_numpy(g["real"])
+    fake = torch.from_numpy(g["fake"]).requires_grad_(True)
+    lr, lf = LO.disc_forward(sd, real, True), LO.disc_forward(sd, fake, True)
+    rel = lambda a, b: float(np.abs(a.detach().numpy() - b).max() / max(np.abs(b).max(), 1e-12))
+    assert rel(lr, g["logits_real"]) < 1e-5 and rel(lf, g["logits_fake"]) < 1e-5
+    assert abs(float(LO.hinge_d_loss(lr, lf)) - float(g["hinge"])) < 1e-6
+    assert abs(float(LO.vanilla_d_loss(lr, lf)) - float(g["vanilla"])) < 1e-6
+    g_loss = -lf.mean()
+    (gin,) = torch.autograd.grad(g_loss, fake, retain_graph=True)
+    assert rel(gin, g["grad_fake:g_loss"]) < 1e-4
+    LO.hinge_d_loss(lr, lf).backward()
+    for k in g.files:
+        if k.startswith("grad:"):
+            got = sd[k[5:]].grad
+            got = got[::8, ::8] if got.numel() > 200000 else got
+            assert rel(got, g[k]) < 1e-4, k
+    with torch.no_grad():
+        assert rel(LO.disc_forward(sd, real, False), g["logits_real_eval"]) < 1e-5
+    assert LO.adopt_weight(0.8, 10, 20) == float(g["adopt"][0]) == 0.0 and abs(LO.adopt_weight(0.8, 30, 20) - float(g["adopt"][1])) < 1e-7
