@@ -56,15 +56,35 @@ def synth_disc_state_dict(seed=0, in_channels=3, nf=64, n_layers=3) -> SD:
     return sd
 
 
-def disc_forward(sd: SD, x: Tensor, training: bool = True, in_channels=3, nf=64, n_layers=3) -> Tensor:
+class _RoundBF16(torch.autograd.Function):
+    """bf16 storage of a tensor AND of its gradient (what the MI355X path does between kernels)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def disc_forward(sd: SD, x: Tensor, training: bool = True, in_channels=3, nf=64, n_layers=3, bf16_storage: bool = False) -> Tensor:
+    """``bf16_storage``: the same arithmetic with every inter-layer tensor (and its gradient) and every conv weight rounded to
+    bf16, fp32 accumulation, fp32 logits -- the precision model of the MI355X path, used to separate "bf16 storage error" (large
+    for gradients that cross three BatchNorms: 13 % rel-L2 on the input gradient of the golden case) from kernel error."""
+    r = _RoundBF16.apply if bf16_storage else (lambda t: t)
     h = x
+    last = disc_layout(in_channels, nf, n_layers)[-1][0]
     for lay in disc_layout(in_channels, nf, n_layers):
         i, kind = lay[0], lay[1]
         if kind == "conv":
-            h = F.conv2d(h, sd[f"model.{i}.weight"], sd.get(f"model.{i}.bias"), stride=lay[4], padding=1)
+            w = sd[f"model.{i}.weight"]
+            h = F.conv2d(r(h), r(w) if bf16_storage else w, sd.get(f"model.{i}.bias"), stride=lay[4], padding=1)
+            if i != last:
+                h = r(h)
         elif kind == "bn":       # nn.BatchNorm2d, eps 1e-5; training: batch statistics (running buffers are not touched here)
-            h = F.batch_norm(h, None if training else sd[f"model.{i}.running_mean"], None if training else sd[f"model.{i}.running_var"],
-                             sd[f"model.{i}.weight"], sd[f"model.{i}.bias"], training, 0.1, 1e-5)
+            h = r(F.batch_norm(h, None if training else sd[f"model.{i}.running_mean"], None if training else sd[f"model.{i}.running_var"],
+                               sd[f"model.{i}.weight"], sd[f"model.{i}.bias"], training, 0.1, 1e-5))
         else:
             h = F.leaky_relu(h, 0.2)
     return h

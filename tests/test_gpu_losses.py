@@ -19,6 +19,12 @@ def _dev():
     return torch.device("cuda:0")
 
 
+def rel_l2(got, ref):
+    got = got.detach().float().cpu()
+    ref = torch.as_tensor(np.asarray(ref)).float() if not isinstance(ref, torch.Tensor) else ref.detach().float().cpu()
+    return float((got - ref).norm() / ref.norm().clamp_min(1e-12))
+
+
 def relerr(got, ref):
     got = got.detach().float().cpu()
     ref = torch.as_tensor(np.asarray(ref)).float() if not isinstance(ref, torch.Tensor) else ref.detach().float().cpu()
@@ -89,16 +95,28 @@ def test_discriminator_vs_reference_golden(golden_dir):
     assert abs(float(vanilla_d_loss(lr, lf)) - float(g["vanilla"])) < 3e-2 * abs(float(g["vanilla"])) + 1e-3
     g_loss = -lf.mean()
     (gin,) = torch.autograd.grad(g_loss, fake, retain_graph=True)
-    assert relerr(gin, g["grad_fake:g_loss"]) < 6e-2
+    # Gradients cross five bf16 convolutions and three BatchNorms.  Two references: (1) the oracle with the SAME precision model
+    # (inter-layer tensors, their gradients and the conv weights stored in bf16) -- tight: this is the kernel check; (2) the
+    # reference's fp32 golden -- loose: bf16 storage alone moves the input gradient by 13 % rel-L2 (measured identically on CPU)
+    from oracle import loss_oracle as LO
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in LO.synth_disc_state_dict(seed=7).items()}
+    fake_c = torch.from_numpy(g["fake"]).requires_grad_(True)
+    lr_o = LO.disc_forward(sd, torch.from_numpy(g["real"]), True, bf16_storage=True)
+    lf_o = LO.disc_forward(sd, fake_c, True, bf16_storage=True)
+    (gin_o,) = torch.autograd.grad(-lf_o.mean(), fake_c, retain_graph=True)
+    LO.hinge_d_loss(lr_o, lf_o).backward()
+    print(f"  grad wrt the fake image: vs bf16-storage oracle rel-L2 {rel_l2(gin, gin_o):.2e}; vs fp32 golden rel-L2 {rel_l2(gin, g['grad_fake:g_loss']):.2e}")
+    assert rel_l2(gin, gin_o) < 4e-2 and rel_l2(gin, g["grad_fake:g_loss"]) < 0.2
     d_loss.backward()
     params = dict(d.named_parameters())
     for k in g.files:
         if k.startswith("grad:"):
-            got = params[k[5:]].grad
-            got = got[::8, ::8] if got.numel() > 200000 else got
-            e = relerr(got, g[k])
-            print(f"  {k} relerr {e:.2e}")
-            assert e < 6e-2, k
+            got, ora = params[k[5:]].grad, sd[k[5:]].grad
+            e_o = rel_l2(got, ora)
+            got_s = got[::8, ::8] if got.numel() > 200000 else got
+            e_g = rel_l2(got_s, g[k])
+            print(f"  {k}: vs bf16-storage oracle rel-L2 {e_o:.2e}; vs fp32 golden rel-L2 {e_g:.2e}")
+            assert e_o < 4e-2 and e_g < 0.2, k
     assert relerr(d.model[3].running_mean, g["running_mean:model.3"]) < 3e-2          # two training-mode forwards, momentum 0.1
     assert relerr(d.model[3].running_var, g["running_var:model.3"]) < 3e-2
     assert adopt_weight(0.8, 10, threshold=20) == 0.0 and adopt_weight(0.8, 30, threshold=20) == 0.8
