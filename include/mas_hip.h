@@ -147,6 +147,15 @@ int mas_attn_causal_fwd(const void* q, const void* k, const void* v, void* o, fl
 int mas_attn_causal_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv,
                         int dtype, int B, int H, int S, int hd, float scale, void* stream);
 
+/* ---- single-head spatial self-attention core of AttnBlock  (replaces the two torch.bmm + softmax of models/modules.py:174-187 and
+ * their autograd).  qkv: [N, S, 3C] bf16, q | k | v stacked on the channel axis (the fused 1x1 projection, NHWC with S = h*w);
+ * out [N, S, C] = softmax_keys(q k^T * C^-1/2) v;  lse [N, S] fp32 (log-sum-exp of the scaled scores; may be NULL when no backward
+ * follows).  Backward: dout [N, S, C] -> dqkv [N, S, 3C] (every element written exactly once, no atomics); delta [N, S] fp32 scratch.
+ * bf16 only, S <= 256 tokens, C <= 512 and C % 32 == 0 (the reference's blocks: 16x16x512, 8x8x512).                                */
+int mas_spatial_attn_fwd(const void* qkv, void* out, float* lse, int dtype, int N, int S, int C, void* stream);
+int mas_spatial_attn_bwd(const void* qkv, const void* dout, const float* lse, float* delta, void* dqkv, int dtype, int N, int S, int C,
+                         void* stream);
+
 /* ---- decode-time (KV-cached) attention  (replaces the cached branch of SelfAttention.forward, models/transformer.py:73-115,
  * for token-by-token sampling: SURVEY 8(f) rank 3).  nq new queries of every (batch, head) against a cache of past + nq keys /
  * values: query i (0 <= i < nq) attends to keys 0 .. past + i (causal inside the block).  q: element (b, i, h, d) at

@@ -47,6 +47,8 @@ _SIGNATURES = {
     "mas_vq_bwd": (_i, [_p, _p, _p, _p, _p, _f, _i, _i, _i, _p, _p, _p]),
     "mas_attn_causal_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, C.c_longlong, C.c_longlong, C.c_longlong, _f, _p]),
     "mas_attn_causal_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "mas_spatial_attn_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "mas_spatial_attn_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mas_attn_decode": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _f, _p]),
     "mas_upsample2x": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "mas_sumpool2x": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),

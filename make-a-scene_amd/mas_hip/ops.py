@@ -442,11 +442,41 @@ def vq_lookup(z, codebook, beta):
 # --------------------------------------------------------------------------- #
 # single-head spatial attention core (AttnBlock, reference models/modules.py:174-187)
 # --------------------------------------------------------------------------- #
+class _SpatialAttention(torch.autograd.Function):
+    """h = softmax_keys(q k^T C^-1/2) v over the h*w tokens of each image, on the fused qkv projection [N,3C,H,W] (channels_last):
+    ``mas_spatial_attn_fwd / _bwd`` (one forward launch, two backward launches; the [S,S] scores live in LDS)."""
+
+    @staticmethod
+    def forward(ctx, qkv, c):
+        n, c3, h, w = qkv.shape
+        x = nhwc(qkv)                                               # memory = [N, H*W, 3C]
+        o = _empty_nhwc(n, c, h, w, x.dtype, x.device)
+        lse = torch.empty((n, h * w), dtype=torch.float32, device=x.device)
+        check(lib().mas_spatial_attn_fwd(_ptr(x), _ptr(o), _ptr(lse), _DT[x.dtype], n, h * w, c, _stream()), "spatial_attn_fwd")
+        ctx.c = c
+        ctx.save_for_backward(x, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        x, lse = ctx.saved_tensors
+        n, c3, h, w = x.shape
+        g = nhwc(do, x.dtype)
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        delta = torch.empty_like(lse)
+        check(lib().mas_spatial_attn_bwd(_ptr(x), _ptr(g), _ptr(lse), _ptr(delta), _ptr(dx), _DT[x.dtype], n, h * w, ctx.c, _stream()),
+              "spatial_attn_bwd")
+        return dx, None
+
+
 def spatial_attention(qkv: torch.Tensor, c: int) -> torch.Tensor:
-    """qkv: [N,3C,H,W] channels_last (q|k|v stacked on channels).  softmax over keys of
-    q.k^T * C^-1/2, then . v.  0.2 % of the model's FLOPs: two plain batched
-    GEMMs on views of the NHWC buffer (library GEMM via torch.bmm) + a row softmax."""
+    """qkv: [N,3C,H,W] channels_last (q|k|v stacked on channels).  softmax over keys of q.k^T * C^-1/2, then . v
+    (reference models/modules.py:174-187).  bf16 (the compute dtype of the benched path): the hand-written HIP kernels, for the
+    shapes they cover (H*W <= 256 tokens, C <= 512, C % 32 == 0 -- every AttnBlock of the reference's configs).  fp32 (the parity /
+    debug mode) and anything outside that envelope: two batched library GEMMs on views of the NHWC buffer + a row softmax."""
     n, c3, h, w = qkv.shape
+    if qkv.is_cuda and qkv.dtype == torch.bfloat16 and h * w <= 256 and c <= 512 and c % 32 == 0:
+        return _SpatialAttention.apply(qkv, c)
     t = qkv.permute(0, 2, 3, 1).reshape(n, h * w, c3)          # a view of the NHWC buffer
     q, k, v = t[..., :c], t[..., c:2 * c], t[..., 2 * c:]
     s = torch.bmm(q, k.transpose(1, 2)) * (int(c) ** (-0.5))
