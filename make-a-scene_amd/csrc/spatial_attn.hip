@@ -42,12 +42,13 @@ __device__ __forceinline__ bf16x8 sp_tr_frag(const unsigned char* a0, const unsi
 // LDS map (bytes); row strides padded so that 32 consecutive rows do not share banks
 struct SpLds {
     int RX;      // X_blk row stride: C*2 + 16
-    int ST;      // T row stride: S*4 + 16
-    int SP;      // P / dS row stride: S*2 + 16
+    int ST;      // T row stride: roundup(S,32)*4 + 16
+    int SP;      // P / dS row stride: roundup(S,32)*2 + 16
     int RM;      // M tile row stride: C*2 + 64 (the transpose read wants 4 consecutive rows x 64 B to tile a 256-byte bank row)
     int o_x, o_t, o_p, o_p2, o_m, total;
     __host__ __device__ SpLds(int S, int C) {
-        RX = C * 2 + 16; ST = S * 4 + 16; SP = S * 2 + 16; RM = C * 2 + 64;
+        const int Sp = (S + 31) & ~31;           // the products write whole 32-column tiles
+        RX = C * 2 + 16; ST = Sp * 4 + 16; SP = Sp * 2 + 16; RM = C * 2 + 64;
         o_x = 0; o_t = o_x + 32 * RX; o_p = o_t + 32 * ST; o_p2 = o_p + 32 * SP; o_m = o_p2 + 32 * SP; total = o_m + 32 * RM;
     }
 };
@@ -76,11 +77,22 @@ __device__ __forceinline__ void sp_prod(float* T, int STf, const unsigned char* 
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        for (int c0 = 0; c0 < C; c0 += 16) {
-            bf16x8 a = *reinterpret_cast<const bf16x8*>(yr + c0);
-            if (m >= S) a = zero8<bf16_t>();
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(xr + c0 * 2);
-            mma16(acc, a, b);
+        // C % 32 == 0: two k-steps per iteration at least; 8 global fragments are put in flight before the first MFMA of a
+        // group (one L2 round trip per 8 MFMAs instead of one per MFMA)
+        for (int c0 = 0; c0 < C; c0 += 128) {
+            bf16x8 a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u] = zero8<bf16_t>();
+                if (c0 + 16 * u < C && m < S) a[u] = *reinterpret_cast<const bf16x8*>(yr + c0 + 16 * u);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (c0 + 16 * u < C) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(xr + (c0 + 16 * u) * 2);
+                    mma16(acc, a[u], b);
+                }
+            }
         }
         // acc[r] = D[m_local = (r&3) + 8(r>>2) + 4g][n = l31]
 #pragma unroll
