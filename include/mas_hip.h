@@ -109,6 +109,17 @@ int    mas_gn_bwd(const void* x, const void* da, const void* dres, int dtype, in
 int mas_conv_fwd(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed,
                  const float* bias, const void* residual, void* y, void* stream);
 
+/* Fused GroupNorm statistics: mas_conv_fwd_stats is mas_conv_fwd that ALSO writes, per output tile, the sum and the sum of squares
+ * of every output channel (of the values as stored, i.e. after the bf16 rounding) into stats_partial [N][rows][Cout][2] fp32, where
+ * rows = mas_conv_stat_rows(d) > 0 (0: this convolution's kernel has no fused statistics -- call mas_conv_fwd and mas_gn_stats).
+ * mas_gn_stats_from_partials then replaces mas_gn_stats' pass over the tensor for the GroupNorm that consumes y (same outputs).
+ * No atomics: the table is written once per tile and summed in a fixed order (bitwise run-to-run deterministic).                   */
+int mas_conv_stat_rows(const MasConvDesc* d);
+int mas_conv_fwd_stats(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed,
+                       const float* bias, const void* residual, void* y, float* stats_partial, void* stream);
+int mas_gn_stats_from_partials(const float* partial, int N, int HW, int C, int G, int rows, float eps, const float* gamma,
+                               const float* beta, float* mean_rstd, float* scale_shift, void* stream);
+
 /* ---- convolution weight gradient  (autograd of the F.conv2d sites above)
  *   dw [Cout][ks][ks][Cin] fp32 (caller zero-fills; accumulated with fp32 atomics),
  *   dbias [Cout] fp32 or NULL (same).  x / scale_shift / act as in mas_conv_fwd

@@ -31,6 +31,7 @@ __device__ __forceinline__ void w_static_for(std::integer_sequence<int, I...>, F
 struct WideParams {
     unsigned long long* dbg;                   // -DW_TIMELINE builds only
     const unsigned char* x; const float* ss; const unsigned char* w; const float* bias; const unsigned char* res; unsigned char* y;
+    float* stats;                              // optional [N][tiles_h * tiles_w][Cout][2]: per-tile sum / sum of squares of the bf16 OUTPUT (the consumer's GroupNorm statistics)
     int N, H, W, Cin, Ho, Wo, Cout;
     int Hl, Wl, pad_top, pad_left, upsample, act;
     int n_chunks, Cout_pad, tiles_h, tiles_w, n_ct;
@@ -48,7 +49,8 @@ constexpr int W_WBUF = 0;                      // LDS map: [2][W_WSTAGE] weights
 constexpr int W_PBUF = 2 * W_WSTAGE;
 constexpr int W_BIAS = W_PBUF + 2 * W_PATCH;   // [Cout] fp32 bias (zeros without one), staged once per work-group
 constexpr int W_MAXCOUT = 2048;
-constexpr int W_LDS = W_BIAS + W_MAXCOUT * 4;
+constexpr int W_STAT = W_BIAS + W_MAXCOUT * 4;  // [8 waves][128 couts][2] fp32 per-wave partial statistics of the tile just finished
+constexpr int W_LDS = W_STAT + 8 * 128 * 2 * 4;
 constexpr int W_NSLOT = 5;                     // patch DMA pieces (and 16-byte activation slots) per wave (thread) per chunk
 constexpr int W_OOB = (int)0x80000000;
 
@@ -74,7 +76,8 @@ __device__ __forceinline__ void w_wait_barrier(int n) {   // n is a compile-time
 }
 
 // ACT: GroupNorm(+SiLU) prologue (in-place activation of the raw patch).  RES: residual add in the epilogue.
-template <bool ACT, bool RES>
+// STATS: per-tile sum / sum of squares of the output channels (the consumer's GroupNorm statistics) written to p.stats.
+template <bool ACT, bool RES, bool STATS>
 __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const wbuf = smem + W_WBUF;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
         pc = q - pr * W_PWL;
         return q < W_NPIX;
     };
-    auto make_plan = [&](const Tile& tc, int (&vo)[W_NSLOT], unsigned& inb_mask, int (&ob)[3]) {
+    auto make_plan = [&](const Tile& tc, int (&vo)[W_NSLOT], unsigned& inb_mask, int (&ob)[4]) {
         inb_mask = 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {           // byte offset of (n, ho, w0 + 4 g, c0 + 4 l31); the epilogue adds the pixel column
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
             ob[j] = (ho < p.Ho) ? (int)((((size_t)(tc.n * p.Ho + ho) * p.Wo + tc.w0 + 4 * g) * p.Cout + tc.c0 + 4 * l31) * 2) : W_OOB;
         }
         ob[2] = p.Wo - tc.w0 - 4 * g;           // pixel columns (relative to this lane's first) that exist
+        ob[3] = (tc.n * p.tiles_h + (tc.h0 >> 4)) * p.tiles_w + (tc.w0 >> 5);   // row of the statistics table (uniform)
 #pragma unroll
         for (int k = 0; k < W_NSLOT; ++k) {
             int q, pr, pc;
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
 
     // ---- prologue ----------------------------------------------------------------------------------------------------------------
     int tile = blockIdx.x;                      // grid <= total_tiles
-    int c0_cur, c0_nxt, ob_cur[3], ob_nxt[3];
+    int c0_cur, c0_nxt, ob_cur[4], ob_nxt[4];
     // ONE plan / image descriptor: the current tile's until its last chunk-B patch has been issued (stage 1 of the last pair),
     // the next tile's from stage 2 of the last pair on (only the in-bounds masks of both tiles are live at the same time)
     int vo[W_NSLOT];
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
         const Tile t0 = decode(tile);
         make_plan(t0, vo, inb_cur, ob_cur);
         c0_cur = c0_nxt = t0.c0; n_cur = n_nxt = t0.n;
-        ob_nxt[0] = ob_cur[0]; ob_nxt[1] = ob_cur[1]; ob_nxt[2] = ob_cur[2];
+        ob_nxt[0] = ob_cur[0]; ob_nxt[1] = ob_cur[1]; ob_nxt[2] = ob_cur[2]; ob_nxt[3] = ob_cur[3];
         rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.x) + (size_t)t0.n * img_bytes, 0, (unsigned)img_bytes, 0x00020000);
     }
     inb_nxt = inb_cur;
@@ -240,6 +244,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
         const int n = (int)((blockIdx.x * 5u) % 8u) * p.stagger;
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
     }
+    // fused GroupNorm statistics (p.stats): the epilogue leaves per-wave partial sums in LDS; after the next work-group barrier 256
+    // threads add the 8 waves in a fixed order and write the tile's row of the statistics table (no atomics: deterministic)
+    int stat_row = -1, stat_c0 = 0;              // pending flush (uniform)
+    auto stats_flush = [&]() {
+        if (tid < 256) {
+            const float* sl = reinterpret_cast<const float*>(smem + W_STAT);
+            float t = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += sl[w * 256 + tid];
+            p.stats[((size_t)stat_row * p.Cout + stat_c0) * 2 + tid] = t;
+        }
+        stat_row = -1;
+    };
     bool stores_in_flight = false;               // the previous tile's 32 epilogue stores may still be in flight at the first wait
     const int n_pairs = p.n_chunks >> 1;
 #ifdef W_TIMELINE
@@ -274,6 +291,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                     constexpr int allow = khp == 0 ? 3 : (khp == 1 ? (ACT ? 0 : 2) : 0);
                     if (s == 0 && pair == 0 && stores_in_flight) { w_wait_barrier(32); stores_in_flight = false; }
                     else w_wait_barrier(allow);
+                    if constexpr (STATS) { if (s == 0 && pair == 0 && stat_row >= 0) stats_flush(); }      // one store, older than this stage's weight DMA
                 }
                 if (pair < 2) WTS(2 + 3 * (pair * 6 + s));
                 if (s == 2 && last_pair && has_next) {        // the next tile's plan (used by the chunk-B stages 3, 4); without a next
@@ -396,9 +414,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
 #ifndef W_ST_AUX
 #define W_ST_AUX 0
 #endif
+            float st_s[4] = {0.0f, 0.0f, 0.0f, 0.0f}, st_q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             auto store = [&](int j, int r, u32x2 o) {
                 const int pc = (r & 3) + 8 * (r >> 2);
-                __builtin_amdgcn_raw_buffer_store_b64(o, rs_y, pc < ob_cur[2] ? ob_cur[j] : W_OOB, pc * row_bytes, W_ST_AUX);
+                const bool ok = (pc < ob_cur[2]) && (ob_cur[j] != W_OOB);
+                __builtin_amdgcn_raw_buffer_store_b64(o, rs_y, ok ? ob_cur[j] : W_OOB, pc * row_bytes, W_ST_AUX);
+                if (STATS && ok) {              // statistics of the ROUNDED values, i.e. of what the consumer will read
+                    const float f0 = __uint_as_float(o[0] << 16), f1 = __uint_as_float(o[0] & 0xffff0000u);
+                    const float f2 = __uint_as_float(o[1] << 16), f3 = __uint_as_float(o[1] & 0xffff0000u);
+                    st_s[0] += f0; st_q[0] += f0 * f0; st_s[1] += f1; st_q[1] += f1 * f1;
+                    st_s[2] += f2; st_q[2] += f2 * f2; st_s[3] += f3; st_q[3] += f3 * f3;
+                }
             };
             if constexpr (RES) res_load(0);
 #pragma unroll
@@ -412,19 +438,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) store(1, r, pack(1, r));
             stores_in_flight = true;
+            if constexpr (STATS) {               // the two half-waves hold different pixels of the same 4 couts; then one LDS row per wave
+                float* sl = reinterpret_cast<float*>(smem + W_STAT) + wave * 256 + (4 * l31) * 2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float a = st_s[i] + __shfl_xor(st_s[i], 32), b = st_q[i] + __shfl_xor(st_q[i], 32);
+                    if (g == 0) { sl[2 * i] = a; sl[2 * i + 1] = b; }
+                }
+                stat_row = ob_cur[3]; stat_c0 = c0_cur;
+            }
         }
         WTS(61);
 #ifdef W_TIMELINE
         ++tl_iter;
 #endif
         if (!has_next) break;
-        tile = next_tile; c0_cur = c0_nxt; n_cur = n_nxt; inb_cur = inb_nxt; ob_cur[0] = ob_nxt[0]; ob_cur[1] = ob_nxt[1]; ob_cur[2] = ob_nxt[2];
+        tile = next_tile; c0_cur = c0_nxt; n_cur = n_nxt; inb_cur = inb_nxt; ob_cur[0] = ob_nxt[0]; ob_cur[1] = ob_nxt[1]; ob_cur[2] = ob_nxt[2]; ob_cur[3] = ob_nxt[3];
+    }
+    if constexpr (STATS) {
+        if (stat_row >= 0) {                     // the last tile's statistics
+            __syncthreads();
+            stats_flush();
+        }
     }
 }
 
-template <bool ACT, bool RES>
+template <bool ACT, bool RES, bool STATS>
 int launch_wide(const WideParams& p, hipStream_t s) {
-    auto kern = conv3x3_wide_kernel<ACT, RES>;
+    auto kern = conv3x3_wide_kernel<ACT, RES, STATS>;
     static mas_devmask_t attr_mask{0};
     unsigned long long attr_bit;
     if (mas_attr_needed(attr_mask, &attr_bit)) {
@@ -464,10 +505,14 @@ bool mas_conv3x3_wide_eligible(const MasConvDesc* d) {
     return true;
 }
 
+// rows per image of the statistics table the wide kernel can fill for this convolution (its 16x32-pixel tiles)
+int mas_conv3x3_wide_stat_rows(const MasConvDesc* d) { return mas_cdiv(d->Ho, 16) * mas_cdiv(d->Wo, 32); }
+
 int mas_conv3x3_wide_launch(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed, const float* bias,
-                            const void* residual, void* y, hipStream_t s) {
+                            const void* residual, void* y, float* stats, hipStream_t s) {
     WideParams p;
     p.dbg = nullptr;
+    p.stats = stats;
 #ifdef W_TIMELINE
     if (const char* e = getenv("MAS_DBG_PTR")) p.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
 #endif
@@ -482,6 +527,10 @@ int mas_conv3x3_wide_launch(const MasConvDesc* d, const void* x, const float* sc
     p.stagger = stagger;
     auto magic = [](int dv) { return (unsigned)((0x100000000ULL + (unsigned)dv - 1) / (unsigned)dv); };   // (d = 1 handled in the kernel)
     p.m_ct = magic(p.n_ct); p.m_tw = magic(p.tiles_w); p.m_th = magic(p.tiles_h);
-    if (d->act != MAS_ACT_NONE) return residual ? launch_wide<true, true>(p, s) : launch_wide<true, false>(p, s);
-    return residual ? launch_wide<false, true>(p, s) : launch_wide<false, false>(p, s);
+    if (stats) {
+        if (d->act != MAS_ACT_NONE) return residual ? launch_wide<true, true, true>(p, s) : launch_wide<true, false, true>(p, s);
+        return residual ? launch_wide<false, true, true>(p, s) : launch_wide<false, false, true>(p, s);
+    }
+    if (d->act != MAS_ACT_NONE) return residual ? launch_wide<true, true, false>(p, s) : launch_wide<true, false, false>(p, s);
+    return residual ? launch_wide<false, true, false>(p, s) : launch_wide<false, false, false>(p, s);
 }

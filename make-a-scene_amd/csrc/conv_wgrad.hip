@@ -786,12 +786,19 @@ int launch_t(const WgradParams& p, int ks, int stride, hipStream_t s) {
 
 }  // namespace
 
+int mas_conv_wgrad_dma_try(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy, float* dw, float* dbias,
+                           hipStream_t s);   // conv_wgrad_dma.hip
+
 extern "C" int mas_conv_wgrad(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy,
                               float* dw, float* dbias, void* stream) {
     MAS_ENTER();
     if (!d || !x || !dy || !dw) MAS_FAIL(MAS_EINVAL, "conv_wgrad: null argument");
     if (d->act != MAS_ACT_NONE && !scale_shift) MAS_FAIL(MAS_EINVAL, "conv_wgrad: act prologue needs scale_shift");
     if (d->upsample && d->stride != 1) MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad: upsample fold needs stride 1");
+    {   // the FLOP-carrying shapes (3x3, stride 1, bf16, Cin % 64 == 0, Cout % 128 == 0) take the LDS-DMA kernel
+        const int rc = mas_conv_wgrad_dma_try(d, x, scale_shift, dy, dw, dbias, reinterpret_cast<hipStream_t>(stream));
+        if (rc != 0) return rc < 0 ? rc : MAS_OK;
+    }
     WgradParams p;
     p.dbg = nullptr;
 #ifdef MAS_TIMELINE          // s_memtime timeline builds only (tools/build_variant.sh tl -DMAS_TIMELINE)

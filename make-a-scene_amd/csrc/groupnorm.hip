@@ -330,6 +330,20 @@ extern "C" int mas_gn_stats(const void* x, int dtype, int N, int HW, int C, int 
     return MAS_OK;
 }
 
+// GroupNorm statistics from a table of per-tile partial sums [N][rows][C][2] (sum, sum of squares) that the producing convolution
+// filled in its epilogue (mas_conv_fwd_stats): the full-tensor read of mas_gn_stats disappears, only this finalize remains.
+extern "C" int mas_gn_stats_from_partials(const float* partial, int N, int HW, int C, int G, int rows, float eps, const float* gamma,
+                                          const float* beta, float* mean_rstd, float* scale_shift, void* stream) {
+    MAS_ENTER();
+    if (!partial || !mean_rstd) MAS_FAIL(MAS_EINVAL, "gn_stats_from_partials: null argument");
+    if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G || rows <= 0) MAS_FAIL(MAS_EINVAL, "gn_stats_from_partials: bad shape");
+    const size_t lds2 = (size_t)2 * C * sizeof(double) + (size_t)2 * G * sizeof(float);
+    hipLaunchKernelGGL(gn_stats_finalize, dim3(N), dim3(NT), lds2, reinterpret_cast<hipStream_t>(stream), partial, HW, C, G, rows, eps, gamma, beta,
+                       mean_rstd, scale_shift);
+    MAS_CHECK_LAUNCH("gn_stats_from_partials");
+    return MAS_OK;
+}
+
 // workspace: partial [N][MAX_SPLIT][C][2] + coef [N][C][4] + nsum [N][C][2]
 extern "C" size_t mas_gn_bwd_workspace(int N, int C) {
     return ((size_t)N * MAX_SPLIT * C * 2 + (size_t)N * C * 4 + (size_t)N * C * 2) * sizeof(float);

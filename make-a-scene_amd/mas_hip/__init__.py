@@ -41,6 +41,9 @@ _SIGNATURES = {
     "mas_gn_bwd_workspace": (_sz, [_i, _i]),
     "mas_gn_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "mas_conv_fwd": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p]),
+    "mas_conv_stat_rows": (_i, [C.POINTER(ConvDesc)]),
+    "mas_conv_fwd_stats": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
+    "mas_gn_stats_from_partials": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
     "mas_conv_wgrad": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
     "mas_vq_workspace": (_sz, [_i, _i]),
     "mas_vq_argmin_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),

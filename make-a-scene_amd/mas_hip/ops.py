@@ -127,11 +127,36 @@ class ConvWeight:
 # --------------------------------------------------------------------------- #
 # raw kernel calls
 # --------------------------------------------------------------------------- #
-def gn_stats(x: torch.Tensor, gamma, beta, groups: int, eps: float):
-    """x channels_last [N,C,H,W] -> (mean_rstd [N,G,2], scale_shift [N,C,2]) fp32."""
+_stats_state = {"on": os.environ.get("MAS_FUSED_GN_STATS", "1") != "0", "stash": None}
+
+
+def _take_stats(x: torch.Tensor):
+    """(partial table, rows per image) the convolution that produced ``x`` left for its consumer's GroupNorm, or (None, 0).
+    The table rides on the tensor OBJECT (``x._mas_gn``, set by ``norm_act_conv`` / ``resblock``): a copy, a cast or an in-place
+    write (``_version``) silently drops it and the statistics are recomputed from the tensor."""
+    st = getattr(x, "_mas_gn", None)
+    if st is None or st[2] != x._version or not x.is_contiguous(memory_format=torch.channels_last):
+        return None, 0
+    return st[0], st[1]
+
+
+def _attach_stats(y: torch.Tensor):
+    st, _stats_state["stash"] = _stats_state["stash"], None
+    if st is not None:
+        y._mas_gn = (st[0], st[1], y._version)
+    return y
+
+
+def gn_stats(x: torch.Tensor, gamma, beta, groups: int, eps: float, partial: Optional[torch.Tensor] = None, rows: int = 0):
+    """x channels_last [N,C,H,W] -> (mean_rstd [N,G,2], scale_shift [N,C,2]) fp32.  With ``partial`` (the per-tile sums the producing
+    convolution wrote, ``mas_conv_fwd_stats``) the pass over the tensor is skipped: only the finalize runs."""
     n, c, h, w = x.shape
     mr = torch.empty((n, groups, 2), dtype=torch.float32, device=x.device)
     ss = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+    if partial is not None:
+        check(lib().mas_gn_stats_from_partials(_ptr(partial), n, h * w, c, groups, int(rows), float(eps), _ptr(gamma), _ptr(beta), _ptr(mr),
+                                               _ptr(ss), _stream()), "gn_stats_from_partials")
+        return mr, ss
     wsb = lib().mas_gn_stats_workspace(n, c)
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
     check(lib().mas_gn_stats(_ptr(x), _DT[x.dtype], n, h * w, c, groups, float(eps), _ptr(gamma), _ptr(beta), _ptr(mr), _ptr(ss),
@@ -166,22 +191,41 @@ def _preferred_layout(d: ConvDesc) -> int:
     return lay
 
 
-def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, upsample, out_dtype):
+_stat_rows_memo = {}
+
+
+def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, upsample, out_dtype, want_stats=False):
     """``wp``: a ``ConvWeight`` (packed here in the layout the library prefers for this convolution) or an already packed
-    K64 image from ``pack_conv_weight`` (always accepted; the call then stays on the kernels that read K64)."""
+    K64 image from ``pack_conv_weight`` (always accepted; the call then stays on the kernels that read K64).
+    ``want_stats``: returns (y, partial, rows) -- the per-tile channel sums of y for the GroupNorm that consumes it
+    (``mas_conv_fwd_stats``), or (y, None, 0) when this convolution's kernel has no fused statistics."""
     y = _empty_nhwc(n, cout, ho, wo, out_dtype, x.device)
     d = _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, x.dtype, out_dtype, act, upsample)
     if isinstance(wp, ConvWeight):
         d.w_layout = _preferred_layout(d)
         wp = _pack_cache.get(wp.w, wp.transpose, x.dtype, d.w_layout)
+    partial, rows = None, 0
+    if want_stats and _stats_state["on"]:
+        key = tuple(getattr(d, f) for f, _ in ConvDesc._fields_)
+        rows = _stat_rows_memo.get(key)
+        if rows is None:
+            rows = _stat_rows_memo[key] = int(lib().mas_conv_stat_rows(C.byref(d)))
+        if rows > 0:
+            partial = torch.empty(n * rows * cout * 2, dtype=torch.float32, device=x.device)
 
     def launch():
-        check(lib().mas_conv_fwd(C.byref(d), _ptr(x), _ptr(ss), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), _stream()), "conv_fwd")
+        if partial is not None:
+            check(lib().mas_conv_fwd_stats(C.byref(d), _ptr(x), _ptr(ss), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), _ptr(partial),
+                                           _stream()), "conv_fwd_stats")
+        else:
+            check(lib().mas_conv_fwd(C.byref(d), _ptr(x), _ptr(ss), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), _stream()), "conv_fwd")
 
     if _launch_hook is not None:
         _launch_hook("conv_fwd", (n, h, w, cin, ho, wo, cout, ks, stride, act, int(residual is not None)), launch)
     else:
         launch()
+    if want_stats:
+        return y, partial, (rows if partial is not None else 0)
     return y
 
 
@@ -255,7 +299,7 @@ class _NormActConv(torch.autograd.Function):
     GroupNorm(+SiLU) backward kernels."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gn_w, gn_b, residual, cfg):
+    def forward(ctx, x, weight, bias, gn_w, gn_b, residual, cfg, xpart=None, xrows=0):
         _require_cuda(x, "conv")
         cd = cfg["in_dtype"]
         x = nhwc(x, cd)
@@ -270,11 +314,13 @@ class _NormActConv(torch.autograd.Function):
         act = cfg["act"]
         mr = ss = None
         if act != ACT_NONE:
-            mr, ss = gn_stats(x, gn_w.detach().float(), gn_b.detach().float(), cfg["groups"], cfg["eps"])
+            mr, ss = gn_stats(x, gn_w.detach().float(), gn_b.detach().float(), cfg["groups"], cfg["eps"], xpart, xrows)
         wp = ConvWeight(weight, False)
         b32 = bias.detach().float() if bias is not None else None
         res = nhwc(residual, cd) if residual is not None else None
-        y = conv_fwd_raw(x, ss, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, cfg["out_dtype"])
+        y, ypart, yrows = conv_fwd_raw(x, ss, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, cfg["out_dtype"],
+                                       want_stats=True)
+        _stats_state["stash"] = (ypart, yrows) if ypart is not None else None
         ctx.cfg = cfg
         ctx.dims = (n, h, w, cin, ho, wo, cout, ks)
         ctx.has_res = residual is not None
@@ -313,7 +359,7 @@ class _NormActConv(torch.autograd.Function):
             else:
                 dx = da
         dres = dy if ctx.has_res and ctx.needs_input_grad[5] else None
-        return dx, dw, (db.to(weight.dtype) if db is not None else None), dgw, dgb, dres, None
+        return dx, dw, (db.to(weight.dtype) if db is not None else None), dgw, dgb, dres, None, None, None
 
 
 def norm_act_conv(x, weight, bias, gn_w=None, gn_b=None, residual=None, *, stride=1, padding=(1, 1, 1, 1), act=ACT_NONE,
@@ -339,7 +385,8 @@ def norm_act_conv(x, weight, bias, gn_w=None, gn_b=None, residual=None, *, strid
         if bias is not None:
             bias = torch.nn.functional.pad(bias, (0, padc))
         return _NormActConv.apply(x, weight, bias, gn_w, gn_b, residual, cfg)[:, :cout]
-    return _NormActConv.apply(x, weight, bias, gn_w, gn_b, residual, cfg)
+    xpart, xrows = _take_stats(x) if act != ACT_NONE else (None, 0)
+    return _attach_stats(_NormActConv.apply(x, weight, bias, gn_w, gn_b, residual, cfg, xpart, xrows))
 
 
 class _ResBlock(torch.autograd.Function):
@@ -349,15 +396,18 @@ class _ResBlock(torch.autograd.Function):
     streaming pass instead of by a separate elementwise add over the full activation."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, groups, eps, cd):
+    def forward(ctx, x, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, groups, eps, cd, xpart=None, xrows=0):
         _require_cuda(x, "resblock")
         x = nhwc(x, cd)
         n, c, h, w = x.shape
         f32 = lambda t: t.detach().float()
-        mr1, ss1 = gn_stats(x, f32(n1w), f32(n1b), groups, eps)
-        hh = conv_fwd_raw(x, ss1, ConvWeight(c1w, False), f32(c1b), None, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU, False, cd)
-        mr2, ss2 = gn_stats(hh, f32(n2w), f32(n2b), groups, eps)
-        y = conv_fwd_raw(hh, ss2, ConvWeight(c2w, False), f32(c2b), x, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU, False, cd)
+        mr1, ss1 = gn_stats(x, f32(n1w), f32(n1b), groups, eps, xpart, xrows)
+        hh, hpart, hrows = conv_fwd_raw(x, ss1, ConvWeight(c1w, False), f32(c1b), None, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU, False,
+                                        cd, want_stats=True)
+        mr2, ss2 = gn_stats(hh, f32(n2w), f32(n2b), groups, eps, hpart, hrows)
+        y, ypart, yrows = conv_fwd_raw(hh, ss2, ConvWeight(c2w, False), f32(c2b), x, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU, False,
+                                       cd, want_stats=True)
+        _stats_state["stash"] = (ypart, yrows) if ypart is not None else None
         ctx.groups, ctx.cd = groups, cd
         ctx.save_for_backward(x, hh, mr1, ss1, mr2, ss2, n1w, c1w, n2w, c2w)
         return y
@@ -385,12 +435,13 @@ class _ResBlock(torch.autograd.Function):
             dx, dg1w, dg1b = gn_bwd(x, da1, dy, groups, ACT_AFFINE_SILU, n1w.detach().float(), mr1, ss1)
         cast = lambda g, ref: g.to(ref.dtype) if g is not None else None
         return (dx, cast(dg1w, n1w), cast(dg1b, n1w), cast(dw1, c1w), cast(db1, c1w), cast(dg2w, n2w), cast(dg2b, n2w),
-                cast(dw2, c2w), cast(db2, c2w), None, None, None)
+                cast(dw2, c2w), cast(db2, c2w), None, None, None, None, None)
 
 
 def resblock(x, norm1, conv1, norm2, conv2):
-    return _ResBlock.apply(x, norm1.weight, norm1.bias, conv1.weight, conv1.bias, norm2.weight, norm2.bias, conv2.weight,
-                           conv2.bias, norm1.num_groups, norm1.eps, compute_dtype())
+    xpart, xrows = _take_stats(x)
+    return _attach_stats(_ResBlock.apply(x, norm1.weight, norm1.bias, conv1.weight, conv1.bias, norm2.weight, norm2.bias, conv2.weight,
+                                         conv2.bias, norm1.num_groups, norm1.eps, compute_dtype(), xpart, xrows))
 
 
 # --------------------------------------------------------------------------- #

@@ -46,3 +46,38 @@ def test_weight_layout_query_and_k64_is_always_accepted():
     y32 = ops.conv_fwd_raw(x, None, ops.ConvWeight(w, False), None, None, 8, 64, 64, 128, 64, 64, 128, 3, 1, 1, 1, 0, False, bf)
     y64 = ops.conv_fwd_raw(x, None, ops.pack_conv_weight(w, False, bf), None, None, 8, 64, 64, 128, 64, 64, 128, 3, 1, 1, 1, 0, False, bf)
     assert float((y32.float() - y64.float()).abs().max() / y64.float().abs().max()) < 1e-2
+
+
+def test_fused_groupnorm_statistics_equal_the_standalone_pass():
+    """mas_conv_fwd_stats: the per-tile channel sums the wide kernel writes in its epilogue give the SAME GroupNorm statistics as
+    mas_gn_stats' pass over the stored tensor (they are sums of the bf16-rounded outputs), ragged tiles and residual included; the
+    table rides on the output tensor object and is dropped by an in-place write."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, os.path.join(ROOT, "make-a-scene_amd"))
+    from mas_hip import ops
+    bf = torch.bfloat16
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    for (n, c, h, w, cout, res) in ((8, 128, 64, 64, 128, False), (3, 128, 40, 72, 256, True), (32, 128, 128, 128, 128, True)):
+        x = torch.randn(n, c, h, w, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn(cout, c, 3, 3, generator=g) / (9 * c) ** 0.5).to(dev)
+        b = (0.1 * torch.randn(cout, generator=g)).to(dev)
+        r = torch.randn(n, cout, h, w, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last) if res else None
+        y, part, rows = ops.conv_fwd_raw(x, None, ops.ConvWeight(wt, False), b, r, n, h, w, c, h, w, cout, 3, 1, 1, 1, 0, False, bf, want_stats=True)
+        assert part is not None and rows == ((h + 15) // 16) * ((w + 31) // 32)
+        ga, be = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+        mr_f, ss_f = ops.gn_stats(y, ga, be, 32, 1e-6, part, rows)
+        mr_s, ss_s = ops.gn_stats(y, ga, be, 32, 1e-6)
+        assert float((mr_f - mr_s).abs().max() / mr_s.abs().max()) < 2e-5
+        assert float((ss_f - ss_s).abs().max() / ss_s.abs().max()) < 2e-5
+        y2, part2, _ = ops.conv_fwd_raw(x, None, ops.ConvWeight(wt, False), b, r, n, h, w, c, h, w, cout, 3, 1, 1, 1, 0, False, bf, want_stats=True)
+        assert torch.equal(part, part2) and torch.equal(y, y2)                    # no atomics: bitwise reproducible
+    # the table travels on the tensor object and is invalidated by an in-place write
+    from models.modules import Conv2d, Normalize
+    conv = Conv2d(128, 128, 3, 1, 1).to(dev)
+    xx = torch.randn(8, 128, 64, 64, device=dev)
+    yy = conv(xx)
+    assert ops._take_stats(yy)[0] is not None
+    yy.mul_(1.0)
+    assert ops._take_stats(yy)[0] is None
