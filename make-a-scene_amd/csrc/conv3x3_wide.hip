@@ -50,7 +50,8 @@ constexpr int W_PBUF = 2 * W_WSTAGE;
 constexpr int W_BIAS = W_PBUF + 2 * W_PATCH;   // [Cout] fp32 bias (zeros without one), staged once per work-group
 constexpr int W_MAXCOUT = 2048;
 constexpr int W_STAT = W_BIAS + W_MAXCOUT * 4;  // [8 waves][128 couts][2] fp32 per-wave partial statistics of the tile just finished
-constexpr int W_LDS = W_STAT + 8 * 128 * 2 * 4;
+constexpr int W_NEXT = W_STAT + 8 * 128 * 2 * 4 + 16;   // [512 threads][4] the NEXT tile's output offsets / statistics row (kept out of the VGPRs)
+constexpr int W_LDS = W_NEXT + 512 * 16;   // + {table row, cout offset} of the pending statistics flush
 constexpr int W_NSLOT = 5;                     // patch DMA pieces (and 16-byte activation slots) per wave (thread) per chunk
 constexpr int W_OOB = (int)0x80000000;
 
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
 
     // ---- prologue ----------------------------------------------------------------------------------------------------------------
     int tile = blockIdx.x;                      // grid <= total_tiles
-    int c0_cur, c0_nxt, ob_cur[4], ob_nxt[4];
+    int c0_cur, c0_nxt, ob_cur[4];
     // ONE plan / image descriptor: the current tile's until its last chunk-B patch has been issued (stage 1 of the last pair),
     // the next tile's from stage 2 of the last pair on (only the in-bounds masks of both tiles are live at the same time)
     int vo[W_NSLOT];
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
         const Tile t0 = decode(tile);
         make_plan(t0, vo, inb_cur, ob_cur);
         c0_cur = c0_nxt = t0.c0; n_cur = n_nxt = t0.n;
-        ob_nxt[0] = ob_cur[0]; ob_nxt[1] = ob_cur[1]; ob_nxt[2] = ob_cur[2]; ob_nxt[3] = ob_cur[3];
+        *reinterpret_cast<u32x4*>(smem + W_NEXT + tid * 16) = u32x4{(unsigned)ob_cur[0], (unsigned)ob_cur[1], (unsigned)ob_cur[2], (unsigned)ob_cur[3]};
         rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.x) + (size_t)t0.n * img_bytes, 0, (unsigned)img_bytes, 0x00020000);
     }
     inb_nxt = inb_cur;
@@ -246,16 +247,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
     }
     // fused GroupNorm statistics (p.stats): the epilogue leaves per-wave partial sums in LDS; after the next work-group barrier 256
     // threads add the 8 waves in a fixed order and write the tile's row of the statistics table (no atomics: deterministic)
-    int stat_row = -1, stat_c0 = 0;              // pending flush (uniform)
+    // (the pending tile's table row / cout offset wait in LDS, not in registers: this kernel has no SGPRs to spare)
     auto stats_flush = [&]() {
         if (tid < 256) {
             const float* sl = reinterpret_cast<const float*>(smem + W_STAT);
+            const int* meta = reinterpret_cast<const int*>(smem + W_STAT + 8 * 128 * 2 * 4);
             float t = 0.0f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) t += sl[w * 256 + tid];
-            p.stats[((size_t)stat_row * p.Cout + stat_c0) * 2 + tid] = t;
+            p.stats[((size_t)meta[0] * p.Cout + meta[1]) * 2 + tid] = t;
         }
-        stat_row = -1;
     };
     bool stores_in_flight = false;               // the previous tile's 32 epilogue stores may still be in flight at the first wait
     const int n_pairs = p.n_chunks >> 1;
@@ -289,14 +290,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                 {
                     constexpr int khp = (kh + 2) % 3;         // filter row of the previous stage
                     constexpr int allow = khp == 0 ? 3 : (khp == 1 ? (ACT ? 0 : 2) : 0);
-                    if (s == 0 && pair == 0 && stores_in_flight) { w_wait_barrier(32); stores_in_flight = false; }
-                    else w_wait_barrier(allow);
-                    if constexpr (STATS) { if (s == 0 && pair == 0 && stat_row >= 0) stats_flush(); }      // one store, older than this stage's weight DMA
+                    if (s == 0 && pair == 0 && stores_in_flight) {
+                        w_wait_barrier(32); stores_in_flight = false;
+                        if constexpr (STATS) stats_flush();      // the finished tile's statistics: one store, older than this stage's weight DMA
+                    } else w_wait_barrier(allow);      // one store, older than this stage's weight DMA
                 }
                 if (pair < 2) WTS(2 + 3 * (pair * 6 + s));
                 if (s == 2 && last_pair && has_next) {        // the next tile's plan (used by the chunk-B stages 3, 4); without a next
                     const Tile nt = decode(next_tile);        // tile the current one is re-fetched, harmlessly
-                    make_plan(nt, vo, inb_nxt, ob_nxt);
+                    int ob_n[4];
+                    make_plan(nt, vo, inb_nxt, ob_n);
+                    *reinterpret_cast<u32x4*>(smem + W_NEXT + tid * 16) = u32x4{(unsigned)ob_n[0], (unsigned)ob_n[1], (unsigned)ob_n[2], (unsigned)ob_n[3]};
                     c0_nxt = nt.c0; n_nxt = nt.n;
                     rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.x) + (size_t)nt.n * img_bytes, 0,
                                                              (unsigned)img_bytes, 0x00020000);
@@ -426,17 +430,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                     st_s[2] += f2; st_q[2] += f2 * f2; st_s[3] += f3; st_q[3] += f3 * f3;
                 }
             };
-            if constexpr (RES) res_load(0);
+            if constexpr (RES) {
+                res_load(0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o0[r] = pack(0, r);
-            asm volatile("" ::: "memory");
-            if constexpr (RES) res_load(1);
-            asm volatile("" ::: "memory");
+                for (int r = 0; r < 16; ++r) o0[r] = pack(0, r);
+                asm volatile("" ::: "memory");
+                res_load(1);
+                asm volatile("" ::: "memory");
 #pragma unroll
-            for (int r = 0; r < 16; ++r) store(0, r, o0[r]);
-            asm volatile("" ::: "memory");
+                for (int r = 0; r < 16; ++r) store(0, r, o0[r]);
+                asm volatile("" ::: "memory");
 #pragma unroll
-            for (int r = 0; r < 16; ++r) store(1, r, pack(1, r));
+                for (int r = 0; r < 16; ++r) store(1, r, pack(1, r));
+            } else {                             // nothing to load: pack and store pixel by pixel (no staging registers)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) store(j, r, pack(j, r));
+            }
             stores_in_flight = true;
             if constexpr (STATS) {               // the two half-waves hold different pixels of the same 4 couts; then one LDS row per wave
                 float* sl = reinterpret_cast<float*>(smem + W_STAT) + wave * 256 + (4 * l31) * 2;
@@ -445,7 +456,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                     const float a = st_s[i] + __shfl_xor(st_s[i], 32), b = st_q[i] + __shfl_xor(st_q[i], 32);
                     if (g == 0) { sl[2 * i] = a; sl[2 * i + 1] = b; }
                 }
-                stat_row = ob_cur[3]; stat_c0 = c0_cur;
+                if (tid == 0) { int* meta = reinterpret_cast<int*>(smem + W_STAT + 8 * 128 * 2 * 4); meta[0] = ob_cur[3]; meta[1] = c0_cur; }
             }
         }
         WTS(61);
@@ -453,13 +464,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
         ++tl_iter;
 #endif
         if (!has_next) break;
-        tile = next_tile; c0_cur = c0_nxt; n_cur = n_nxt; inb_cur = inb_nxt; ob_cur[0] = ob_nxt[0]; ob_cur[1] = ob_nxt[1]; ob_cur[2] = ob_nxt[2]; ob_cur[3] = ob_nxt[3];
+        tile = next_tile; c0_cur = c0_nxt; n_cur = n_nxt; inb_cur = inb_nxt;
+        { const u32x4 nx = *reinterpret_cast<const u32x4*>(smem + W_NEXT + tid * 16); ob_cur[0] = (int)nx[0]; ob_cur[1] = (int)nx[1]; ob_cur[2] = (int)nx[2]; ob_cur[3] = (int)nx[3]; }
     }
-    if constexpr (STATS) {
-        if (stat_row >= 0) {                     // the last tile's statistics
-            __syncthreads();
-            stats_flush();
-        }
+    if constexpr (STATS) {                       // the last tile's statistics
+        __syncthreads();
+        stats_flush();
     }
 }
 

@@ -127,7 +127,10 @@ class ConvWeight:
 # --------------------------------------------------------------------------- #
 # raw kernel calls
 # --------------------------------------------------------------------------- #
-_stats_state = {"on": os.environ.get("MAS_FUSED_GN_STATS", "1") != "0", "stash": None}
+# Fused GroupNorm statistics (mas_conv_fwd_stats): OFF by default.  Measured on the VQ-IMG step (gpurun r2_21): the statistics
+# passes shrink by ~1.0 ms but the epilogue of the 20 producing conv launches grows by ~0.07 ms each at this kernel's register
+# pressure (spilled accumulator staging): 69.85 ms with, 69.7 ms without.  MAS_FUSED_GN_STATS=1 turns it on.
+_stats_state = {"on": os.environ.get("MAS_FUSED_GN_STATS", "0") == "1", "stash": None}
 
 
 def _take_stats(x: torch.Tensor):

@@ -59,7 +59,9 @@ def test_fused_groupnorm_statistics_equal_the_standalone_pass():
     bf = torch.bfloat16
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(3)
-    for (n, c, h, w, cout, res) in ((8, 128, 64, 64, 128, False), (3, 128, 40, 72, 256, True), (32, 128, 128, 128, 128, True)):
+    old_on = ops._stats_state["on"]
+    ops._stats_state["on"] = True               # (default off: measured neutral on the VQ-IMG step, DESIGN R2)
+    for (n, c, h, w, cout, res) in ((64, 128, 64, 64, 128, False), (32, 128, 40, 72, 256, True), (32, 128, 128, 128, 128, True)):
         x = torch.randn(n, c, h, w, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
         wt = (torch.randn(cout, c, 3, 3, generator=g) / (9 * c) ** 0.5).to(dev)
         b = (0.1 * torch.randn(cout, generator=g)).to(dev)
@@ -76,8 +78,9 @@ def test_fused_groupnorm_statistics_equal_the_standalone_pass():
     # the table travels on the tensor object and is invalidated by an in-place write
     from models.modules import Conv2d, Normalize
     conv = Conv2d(128, 128, 3, 1, 1).to(dev)
-    xx = torch.randn(8, 128, 64, 64, device=dev)
+    xx = torch.randn(64, 128, 64, 64, device=dev)
     yy = conv(xx)
     assert ops._take_stats(yy)[0] is not None
     yy.mul_(1.0)
     assert ops._take_stats(yy)[0] is None
+    ops._stats_state["on"] = old_on
