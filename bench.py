@@ -185,6 +185,7 @@ def _setup_dist(args):
     dev = torch.device("cuda", local_rank)
     ddp = world > 1 or os.environ.get("MAS_BENCH_FORCE_DDP") == "1"     # the env knob exercises the N>1 code path on one GPU
     if ddp:
+        os.environ.setdefault("MAS_WGRAD_OVERSUB", "2")     # wgrad grids at 2 work-groups per CU: a co-running RCCL kernel costs half a round
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
@@ -294,7 +295,9 @@ def run_vq(args):
         if reducer is not None:
             reducer.finish()
         opt.step()
-        opt.zero_grad(set_to_none=True)
+        # with the reducer the gradients stay views of its flat buckets and the next backward accumulates into them in place
+        # (no 381 MB gather copy per step); without it the reference's own set_to_none behaviour
+        opt.zero_grad(set_to_none=reducer is None)
         return loss
 
     dt, final_loss = _timed(step, args, ddp, dev, on_start=lambda on: dom.__setitem__("on", on))

@@ -51,7 +51,9 @@ constexpr int W_BIAS = W_PBUF + 2 * W_PATCH;   // [Cout] fp32 bias (zeros withou
 constexpr int W_MAXCOUT = 2048;
 constexpr int W_STAT = W_BIAS + W_MAXCOUT * 4;  // [8 waves][128 couts][2] fp32 per-wave partial statistics of the tile just finished
 constexpr int W_NEXT = W_STAT + 8 * 128 * 2 * 4 + 16;   // [512 threads][4] the NEXT tile's output offsets / statistics row (kept out of the VGPRs)
-constexpr int W_LDS = W_NEXT + 512 * 16;   // + {table row, cout offset} of the pending statistics flush
+constexpr int W_SS = W_NEXT + 512 * 16;        // [2][Cin <= 512][2] fp32 GroupNorm scale / shift of the current and of the next tile's image
+constexpr int W_MAXCIN = 512;
+constexpr int W_LDS = W_SS + 2 * W_MAXCIN * 8;   // + {table row, cout offset} of the pending statistics flush
 constexpr int W_NSLOT = 5;                     // patch DMA pieces (and 16-byte activation slots) per wave (thread) per chunk
 constexpr int W_OOB = (int)0x80000000;
 
@@ -70,6 +72,7 @@ __device__ __forceinline__ void w_wait_barrier(int n) {   // n is a compile-time
         case 0: W_WAIT_BARRIER(0); break;
         case 2: W_WAIT_BARRIER(2); break;
         case 3: W_WAIT_BARRIER(3); break;
+        case 5: W_WAIT_BARRIER(5); break;
         case 7: W_WAIT_BARRIER(7); break;
         case 32: W_WAIT_BARRIER(32); break;
         default: W_WAIT_BARRIER(0); break;
@@ -161,9 +164,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                                                      16, vo[k], soff, 0, 0);
         }
     };
+    // GroupNorm scale / shift: the whole [Cin][2] row of an image is staged in LDS once per tile (table `sel`), and a chunk's 8
+    // pairs per thread are read back right where they are used -- an LDS latency instead of an L2 round trip in front of every
+    // activation, and no registers alive across the MFMA blocks
+    auto ss_stage = [&](int n, int sel) {
+        float* tab = reinterpret_cast<float*>(smem + W_SS) + sel * (W_MAXCIN * 2);
+        const float* src = p.ss + (size_t)n * p.Cin * 2;
+        for (int k = tid; k < p.Cin * 2; k += 512) tab[k] = src[k];
+    };
     float sc[8], sh[8];
-    auto ss_load = [&](int n, int ci0) {        // 8 (scale, shift) pairs of this thread's logical channel slot
-        const f32x4* sp = reinterpret_cast<const f32x4*>(p.ss + ((size_t)n * p.Cin + ci0 + (lane & 3) * 8) * 2);
+    auto ss_fetch = [&](int sel, int ci0) {      // 8 (scale, shift) pairs of this thread's logical channel slot
+        const f32x4* sp = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem + W_SS) + sel * (W_MAXCIN * 2) + (ci0 + (lane & 3) * 8) * 2);
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             const f32x4 v = sp[q4];
@@ -236,9 +247,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
     }
     w_issue(0, c0_cur, 0);
     p_dma(rs_x, vo, 0, 0, 0, W_NSLOT);
+    int ss_sel = 0;                              // table of the CURRENT tile's image
     if constexpr (ACT) {
-        ss_load(n_cur, 0);
-        W_WAIT_BARRIER(0);                       // the raw patch of chunk 0 has landed for every wave
+        ss_stage(n_cur, 0);
+        W_WAIT_BARRIER(0);                       // the raw patch of chunk 0 has landed for every wave, the table is visible
+        ss_fetch(0, 0);
         p_activate(inb_cur, 0);
     }
     if (p.stagger > 0) {
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                 //      vmcnt allowance = VMEM operations issued AFTER the weight DMA in the previous stage
                 {
                     constexpr int khp = (kh + 2) % 3;         // filter row of the previous stage
-                    constexpr int allow = khp == 0 ? 3 : (khp == 1 ? (ACT ? 0 : 2) : 0);
+                    constexpr int allow = khp == 0 ? (ACT ? 5 : 3) : (khp == 1 ? (ACT ? 0 : 2) : 0);
                     if (s == 0 && pair == 0 && stores_in_flight) {
                         w_wait_barrier(32); stores_in_flight = false;
                         if constexpr (STATS) stats_flush();      // the finished tile's statistics: one store, older than this stage's weight DMA
@@ -302,12 +315,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                     make_plan(nt, vo, inb_nxt, ob_n);
                     *reinterpret_cast<u32x4*>(smem + W_NEXT + tid * 16) = u32x4{(unsigned)ob_n[0], (unsigned)ob_n[1], (unsigned)ob_n[2], (unsigned)ob_n[3]};
                     c0_nxt = nt.c0; n_nxt = nt.n;
+                    if constexpr (ACT) ss_stage(nt.n, ss_sel ^ 1);      // visible after the next barrier, first read three stages later
                     rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.x) + (size_t)nt.n * img_bytes, 0,
                                                              (unsigned)img_bytes, 0x00020000);
                 }
                 // ---- GroupNorm(+SiLU) in place on the NEXT chunk's raw patch (all of it has landed: allowance 0 above)
                 if constexpr (ACT) {
                     if (kh == 2) {
+                        if (cb == 0) ss_fetch(ss_sel, ciA + 32);
+                        else if (last_pair) ss_fetch(ss_sel ^ 1, 0);
+                        else ss_fetch(ss_sel, ciA + 64);
                         p_activate((cb == 1 && last_pair) ? inb_nxt : inb_cur, cb ^ 1);
                         asm volatile("" ::: "memory");
                     }
@@ -320,8 +337,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                 }
                 asm volatile("" ::: "memory");                // VMEM order = source order: the counted waits depend on it
                 // ---- patch DMA for the next chunk (3 pieces in the kh = 0 stage, 2 in the kh = 1 stage)
-                if (kh < 2) {
-                    constexpr int k0 = kh == 0 ? 0 : 3, cnt = kh == 0 ? 3 : 2;
+                if (kh < 2 && !(ACT && kh == 1)) {
+                    // plain: 3 + 2 pieces over the kh = 0, 1 stages.  With the prologue all 5 in the kh = 0 stage: the activation that
+                    // opens the kh = 2 stage then waits for DMA that has had two stages to land
+                    constexpr int k0 = (ACT || kh == 0) ? 0 : 3, cnt = ACT ? 5 : (kh == 0 ? 3 : 2);
                     if (cb == 0) {                            // chunk B of this pair -> buffer 1
                         p_dma(rs_x, vo, (ciA + 32) * 2, 1, k0, cnt);
                     } else {                                  // chunk A of the next pair, or chunk 0 of the next tile -> buffer 0
@@ -360,14 +379,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-                }
-                // ---- the next chunk's scale/shift, fetched at the END of the kh = 1 stage (fragments dead) for the activation that
-                //      opens the kh = 2 stage: 16 registers live across one barrier instead of across two MFMA blocks
-                if constexpr (ACT) {
-                    if (kh == 1) {
-                        asm volatile("" ::: "memory");
-                        if (cb == 0) ss_load(n_cur, ciA + 32); else ss_load(last_pair ? n_nxt : n_cur, last_pair ? 0 : ciA + 64);
-                    }
                 }
             });
         }
@@ -464,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
         ++tl_iter;
 #endif
         if (!has_next) break;
-        tile = next_tile; c0_cur = c0_nxt; n_cur = n_nxt; inb_cur = inb_nxt;
+        tile = next_tile; c0_cur = c0_nxt; n_cur = n_nxt; inb_cur = inb_nxt; ss_sel ^= 1;
         { const u32x4 nx = *reinterpret_cast<const u32x4*>(smem + W_NEXT + tid * 16); ob_cur[0] = (int)nx[0]; ob_cur[1] = (int)nx[1]; ob_cur[2] = (int)nx[2]; ob_cur[3] = (int)nx[3]; }
     }
     if constexpr (STATS) {                       // the last tile's statistics
@@ -502,7 +513,7 @@ bool mas_conv3x3_wide_eligible(const MasConvDesc* d) {
     if (d->ks != 3 || d->stride != 1 || d->in_dtype != MAS_BF16 || d->out_dtype != MAS_BF16) return false;
     if (d->Cin % 64 != 0 || d->Cout % 128 != 0) return false;
     static const int any_width = mas_env_int("MAS_CONV_WIDE_ANY_WIDTH", 0);   // tests: ragged tile columns at small sizes
-    if (d->Cout > W_MAXCOUT) return false;
+    if (d->Cout > W_MAXCOUT || (d->act != MAS_ACT_NONE && d->Cin > W_MAXCIN)) return false;
     if (!any_width && (d->Wo < 32 || 4 * d->Wo < 3 * 32 * mas_cdiv(d->Wo, 32))) return false;   // < 75 % of the 32-pixel tile rows used
     const long long img_bytes = (long long)d->H * d->W * d->Cin * 2;
     const long long out_bytes = (long long)d->N * d->Ho * d->Wo * d->Cout * 2;

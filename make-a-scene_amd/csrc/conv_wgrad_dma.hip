@@ -307,7 +307,12 @@ int mas_conv_wgrad_dma_try(const MasConvDesc* d, const void* x, const float* sca
     p.n_pt = p.N * p.tiles_h * p.tiles_w;
     p.n_co_t = d->Cout / 128; p.n_ci_t = d->Cin / 64;
     const int out_tiles = p.n_co_t * p.n_ci_t;
-    int nsplit = mas_cdiv(mas_num_cus(), out_tiles);
+    // One register-file-filling work-group per CU.  Under a co-running RCCL collective (data-parallel backward) some CUs are taken
+    // and a grid of exactly one work-group per CU runs the displaced ones as a second FULL round; MAS_WGRAD_OVERSUB=2 (bench.py sets
+    // it for N > 1) halves the work-groups so the hardware rebalances at half-round granularity, for 2x the split-K atomics
+    // (+3 % of this kernel on an idle GPU).
+    static const int oversub = mas_env_int("MAS_WGRAD_OVERSUB", 1);
+    int nsplit = mas_cdiv(mas_num_cus() * (oversub > 0 ? oversub : 1), out_tiles);
     if (nsplit > p.n_pt) nsplit = p.n_pt;
     if (nsplit < 1) nsplit = 1;
     p.nsplit = nsplit;
