@@ -76,7 +76,9 @@ def test_fused_groupnorm_statistics_equal_the_standalone_pass():
         y2, part2, _ = ops.conv_fwd_raw(x, None, ops.ConvWeight(wt, False), b, r, n, h, w, c, h, w, cout, 3, 1, 1, 1, 0, False, bf, want_stats=True)
         assert torch.equal(part, part2) and torch.equal(y, y2)                    # no atomics: bitwise reproducible
     # the table travels on the tensor object and is invalidated by an in-place write
-    from models.modules import Conv2d, Normalize
+    from models.modules import Conv2d
+    old_dt = ops.compute_dtype()
+    ops.set_compute_dtype(torch.bfloat16)        # (another test of the session may have left the fp32 parity mode on)
     conv = Conv2d(128, 128, 3, 1, 1).to(dev)
     xx = torch.randn(64, 128, 64, 64, device=dev)
     yy = conv(xx)
@@ -84,3 +86,4 @@ def test_fused_groupnorm_statistics_equal_the_standalone_pass():
     yy.mul_(1.0)
     assert ops._take_stats(yy)[0] is None
     ops._stats_state["on"] = old_on
+    ops.set_compute_dtype(old_dt)

@@ -1,32 +1,40 @@
 #!/bin/bash
-# End-of-round evidence run on one MI355X box: tests, smoke, bench, single-kernel numbers, rocprofv3 kernel traces.
+# End-of-round evidence run on one MI355X box: tests, smoke, bench lines, single-kernel numbers, rocprofv3 kernel traces.
 # Writes everything under gpurun_out/final/ (copy the summaries to profiles/ afterwards).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/final; mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt
+timeout 1500 python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -3 > $O/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
-timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+timeout 600 python bench.py --workload transformer > $O/bench_transformer.json 2> $O/bench_transformer.err
+KB="timeout 100 python tools/kbench.py"
 {
-  for act in 0 2; do timeout 100 python tools/kbench.py conv_fwd --n 32 --c 128 --hw 256 --act $act | tail -1; done
-  timeout 100 python tools/kbench.py dgrad --n 32 --c 128 --hw 256 | tail -1
-  for act in 0 2; do timeout 100 python tools/kbench.py wgrad --n 32 --c 128 --hw 256 --act $act | tail -1; done
-  timeout 100 python tools/kbench.py gn_stats --n 32 --c 128 --hw 256 | tail -1
-  timeout 100 python tools/kbench.py gn_bwd --n 32 --c 128 --hw 256 | grep "^gn_bwd"
-  timeout 100 python tools/kbench.py vq --n 32 | tail -1
-  timeout 100 python tools/kbench.py conv_fwd --n 32 --c 512 --hw 32 | tail -1
-  timeout 100 python tools/kbench.py wgrad --n 32 --c 512 --hw 32 | tail -1
-  timeout 100 python tools/kbench.py conv_fwd --n 32 --c 256 --hw 64 | tail -1
-  timeout 100 python tools/kbench.py wgrad --n 32 --c 256 --hw 64 | tail -1
-  timeout 100 python tools/kbench.py attn --n 8 | tail -2
-  timeout 100 python tools/kbench.py attn --n 32 | tail -2
-  timeout 200 python tools/bench_transformer.py --batch 8 | tail -1
+  for act in 0 2; do $KB conv_fwd --n 32 --c 128 --hw 256 --act $act | tail -1; done
+  $KB conv_fwd --n 32 --c 128 --hw 256 --act 2 --res 1 | tail -1
+  $KB dgrad --n 32 --c 128 --hw 256 | tail -1
+  for act in 0 2; do $KB wgrad --n 32 --c 128 --hw 256 --act $act | tail -1; done
+  echo "-- the same launches on round 1's kernels (MAS_CONV_WIDE=0 MAS_CONV_STREAM=0 MAS_WGRAD_DMA=0)"
+  for act in 0 2; do MAS_CONV_WIDE=0 MAS_CONV_STREAM=0 $KB conv_fwd --n 32 --c 128 --hw 256 --act $act | tail -1; done
+  for act in 0 2; do MAS_WGRAD_DMA=0 $KB wgrad --n 32 --c 128 --hw 256 --act $act | tail -1; done
+  echo "-- other shapes"
+  $KB gn_stats --n 32 --c 128 --hw 256 | tail -1
+  $KB gn_bwd --n 32 --c 128 --hw 256 | grep "^gn_bwd"
+  $KB vq --n 32 | tail -1
+  for s in "512 32" "256 64" "128 128" "256 128" "512 64"; do set -- $s
+    $KB conv_fwd --n 32 --c $1 --hw $2 --act 2 | tail -1; $KB wgrad --n 32 --c $1 --hw $2 --act 2 | tail -1
+  done
+  $KB conv_fwd --n 32 --c 128 --hw 256 --stride 2 | tail -1
+  $KB attn --n 8 | tail -2
+  $KB attn --n 32 | tail -2
   timeout 60 tools/probes/mfma_peak
-} > $O/kbench.txt 2>&1
+} 2>&1 | grep -v amdgpu.ids > $O/kbench.txt
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/pf_vq -o vq -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pf_vq.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/pf_tr -o tr -- python $R/tools/bench_transformer.py --batch 8 --steps 3 > /tmp/pf_tr.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/pf_tr -o tr -- python $R/bench.py --workload transformer --steps 3 --warmup 1 > /tmp/pf_tr.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pf_enc -o enc -- python $R/tools/enc_fwd.py > /tmp/pf_enc.log 2>&1
 cd $R
 python tools/rocprof_summary.py $(find /tmp/pf_vq -name "*.db" | head -1) $O/kernel_trace_vq.txt > /dev/null
 python tools/rocprof_summary.py $(find /tmp/pf_tr -name "*.db" | head -1) $O/kernel_trace_transformer.txt > /dev/null
-tail -2 $O/pytest_gpu.txt; cat $O/smoke.txt | tail -1; cut -c1-300 $O/bench.json
+python tools/rocprof_summary.py $(find /tmp/pf_enc -name "*.db" | head -1) $O/kernel_trace_encoder_fwd.txt > /dev/null
+tail -2 $O/pytest_gpu.txt; tail -1 $O/smoke.txt; cut -c1-300 $O/bench.json; cut -c1-300 $O/bench_transformer.json; head -12 $O/kbench.txt
