@@ -18,3 +18,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _session_state_is_restored():
+    """the global compute dtype (bf16 / fp32 parity mode) and the fused-statistics switch never leak from one test into the next"""
+    from mas_hip import ops
+    dt, on = ops.compute_dtype(), ops._stats_state["on"]
+    yield
+    ops.set_compute_dtype(dt)
+    ops._stats_state["on"] = on
