@@ -36,12 +36,20 @@ __global__ __launch_bounds__(NT) void gn_stats_partial(const T* __restrict__ x, 
         float s[EPU], q[EPU];
 #pragma unroll
         for (int e = 0; e < EPU; ++e) { s[e] = 0.0f; q[e] = 0.0f; }
-        for (int r = r0 + tid / upp; r < r1; r += rstep) {
-            u32x4 raw = *reinterpret_cast<const u32x4*>(x + base + (size_t)r * C + cu * EPU);
+        auto add = [&](const u32x4& raw) {
             const T* rv = reinterpret_cast<const T*>(&raw);
 #pragma unroll
             for (int e = 0; e < EPU; ++e) { const float v = (float)rv[e]; s[e] += v; q[e] += v * v; }
+        };
+        // four rows in flight per thread (one load per iteration left this HBM-bound pass at 61 % of 8 TB/s)
+        int r = r0 + tid / upp;
+        for (; r + 3 * rstep < r1; r += 4 * rstep) {
+            const T* px = x + base + (size_t)r * C + cu * EPU;
+            const u32x4 a0 = *reinterpret_cast<const u32x4*>(px), a1 = *reinterpret_cast<const u32x4*>(px + (size_t)rstep * C);
+            const u32x4 a2 = *reinterpret_cast<const u32x4*>(px + (size_t)2 * rstep * C), a3 = *reinterpret_cast<const u32x4*>(px + (size_t)3 * rstep * C);
+            add(a0); add(a1); add(a2); add(a3);
         }
+        for (; r < r1; r += rstep) add(*reinterpret_cast<const u32x4*>(x + base + (size_t)r * C + cu * EPU));
         // fixed-order (deterministic) reduction over the NT/upp pixel-row groups
         float* slots = red + 2 * C;                 // [NT/upp][C][2]
         const int rg = tid / upp;
@@ -142,7 +150,38 @@ __global__ __launch_bounds__(NT) void gn_bwd_partial(const T* __restrict__ x, co
     float sc[EPU], sh[EPU], mu[EPU], rs[EPU], s1[EPU], s2[EPU];
 #pragma unroll
     for (int e = 0; e < EPU; ++e) { s1[e] = 0.0f; s2[e] = 0.0f; sc[e] = sh[e] = mu[e] = rs[e] = 0.0f; }
-    for (long long u = tid; u < total; u += NT) {
+    long long u_start = tid;
+    if (fixed && total > 0) {            // the channel unit of a thread is loop invariant: constants once, two units in flight per iteration
+        const int cu = tid % upp;
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) {
+            const int c = cu * EPU + e;
+            sc[e] = ss[((size_t)n * C + c) * 2 + 0]; sh[e] = ss[((size_t)n * C + c) * 2 + 1];
+            mu[e] = mean_rstd[((size_t)n * G + c / cpg) * 2 + 0]; rs[e] = mean_rstd[((size_t)n * G + c / cpg) * 2 + 1];
+        }
+        cu_prev = cu;
+        auto acc2 = [&](const u32x4& rx, const u32x4& rd) {
+            const T* xv = reinterpret_cast<const T*>(&rx);
+            const T* dv = reinterpret_cast<const T*>(&rd);
+#pragma unroll
+            for (int e = 0; e < EPU; ++e) {
+                const float xe = (float)xv[e];
+                float du = (float)dv[e];
+                if (act == MAS_ACT_AFFINE_SILU) du *= dsilu_f(xe * sc[e] + sh[e]);
+                s1[e] += du; s2[e] += du * (xe - mu[e]) * rs[e];
+            }
+        };
+        long long u = tid;
+        const size_t rb = base + (size_t)r0 * C;
+        for (; u + NT < total; u += 2 * NT) {
+            const size_t o0 = rb + (size_t)u * EPU, o1 = rb + (size_t)(u + NT) * EPU;
+            const u32x4 x0 = *reinterpret_cast<const u32x4*>(x + o0), x1 = *reinterpret_cast<const u32x4*>(x + o1);
+            const u32x4 d0 = *reinterpret_cast<const u32x4*>(da + o0), d1 = *reinterpret_cast<const u32x4*>(da + o1);
+            acc2(x0, d0); acc2(x1, d1);
+        }
+        u_start = u;
+    }
+    for (long long u = u_start; u < total; u += NT) {
         const int r = r0 + (int)(u / upp), cu = (int)(u % upp);
         if (cu != cu_prev) {
             if (cu_prev >= 0 && !fixed) {
@@ -269,12 +308,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply(const T* __restrict__ x, cons
         const float* k = coef + ((size_t)n * C + c) * 4;
         k0[e] = k[0]; k1[e] = k[1]; k2[e] = k[2];
     }
-    for (long long u = u0; u < units_per_n; u += (long long)gridDim.x * NT) {
-        const size_t off = base + (size_t)u * EPU;
-        u32x4 rx = *reinterpret_cast<const u32x4*>(x + off);
-        u32x4 rd = *reinterpret_cast<const u32x4*>(da + off);
-        u32x4 rr = {0u, 0u, 0u, 0u};
-        if (dres) rr = *reinterpret_cast<const u32x4*>(dres + off);
+    auto body = [&](const u32x4& rx, const u32x4& rd, const u32x4& rr, size_t off) {
         const T* xv = reinterpret_cast<const T*>(&rx);
         const T* dv = reinterpret_cast<const T*>(&rd);
         const T* rv = reinterpret_cast<const T*>(&rr);
@@ -290,6 +324,26 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply(const T* __restrict__ x, cons
             o[e] = (T)v;
         }
         *reinterpret_cast<u32x4*>(dx + off) = ov;
+    };
+    // two 16-byte units per iteration: 4-6 loads in flight per thread (the pass is HBM-bound; one unit per iteration left the
+    // memory pipeline at 55 % of 8 TB/s)
+    const long long stride = (long long)gridDim.x * NT;
+    long long u = u0;
+    for (; u + stride < units_per_n; u += 2 * stride) {
+        const size_t o0 = base + (size_t)u * EPU, o1 = base + (size_t)(u + stride) * EPU;
+        const u32x4 rx0 = *reinterpret_cast<const u32x4*>(x + o0), rx1 = *reinterpret_cast<const u32x4*>(x + o1);
+        const u32x4 rd0 = *reinterpret_cast<const u32x4*>(da + o0), rd1 = *reinterpret_cast<const u32x4*>(da + o1);
+        u32x4 rr0 = {0u, 0u, 0u, 0u}, rr1 = rr0;
+        if (dres) { rr0 = *reinterpret_cast<const u32x4*>(dres + o0); rr1 = *reinterpret_cast<const u32x4*>(dres + o1); }
+        body(rx0, rd0, rr0, o0);
+        body(rx1, rd1, rr1, o1);
+    }
+    for (; u < units_per_n; u += stride) {
+        const size_t off = base + (size_t)u * EPU;
+        const u32x4 rx = *reinterpret_cast<const u32x4*>(x + off), rd = *reinterpret_cast<const u32x4*>(da + off);
+        u32x4 rr = {0u, 0u, 0u, 0u};
+        if (dres) rr = *reinterpret_cast<const u32x4*>(dres + off);
+        body(rx, rd, rr, off);
     }
 }
 
