@@ -43,6 +43,24 @@ def test_argument_validation_without_gpu():
     assert L.mas_packed_weight_elems(3, 128, 3) == 9 * 128 * 128    # Cout padded to the 128-row tile
 
 
+def test_round2_entry_points_validate_arguments_without_gpu():
+    """the ABI v2 additions follow the same convention: negative code + message, nothing computed"""
+    import mas_hip
+    L = mas_hip.lib()
+    assert L.mas_abi_version() == 2
+    assert L.mas_conv_weight_layout(None) == mas_hip.WLAYOUT_K64
+    d = mas_hip.ConvDesc(32, 256, 256, 128, 256, 256, 128, 3, 1, 1, 1, mas_hip.BF16, mas_hip.BF16, 0, 0, 0)
+    assert L.mas_conv_weight_layout(ctypes.byref(d)) in (mas_hip.WLAYOUT_K64, mas_hip.WLAYOUT_K32)
+    assert L.mas_conv_stat_rows(ctypes.byref(d)) == 0                       # a K64 image never takes the fused-statistics kernel
+    d.w_layout = 7
+    assert L.mas_conv_fwd(ctypes.byref(d), 1, None, 1, None, None, 1, None) == -1 and b"w_layout" in L.mas_last_error()
+    assert L.mas_attn_decode(None, None, None, None, 1, 1, 1, 1, 0, 64, 64, 64, 64, 64, 0, 0, 0, 0, 0.125, None) == -1
+    assert L.mas_spatial_attn_fwd(1, 1, None, mas_hip.F32, 1, 16, 64, None) == -2 and b"bf16" in L.mas_last_error()
+    assert L.mas_spatial_attn_fwd(1, 1, None, mas_hip.BF16, 1, 300, 64, None) == -2    # more than 256 tokens
+    assert L.mas_pack_conv_weight_layout(1, 1, 128, 128, 3, 0, mas_hip.F32, mas_hip.WLAYOUT_K32, None) == -2   # K32 is bf16 only
+    assert L.mas_space_to_depth2x(None, None, 1, 1, 2, 2, 8, 2, 2, 1, None) == -1
+
+
 def test_surface_matches_reference_contract():
     from models import VQBASE
     from models.modules import Encoder, Decoder, Codebook, ResnetBlock, AttnBlock, Upsample, Downsample  # noqa: F401
@@ -57,6 +75,13 @@ def test_surface_matches_reference_contract():
     assert set(sd) == set(ref_keys) and all(sd[k].shape == ref_keys[k].shape for k in sd)
     assert hasattr(m.decoder.model[-1], "weight") and m.quantize.q_counter == 0
     assert all(type(p) is torch.nn.Parameter for p in m.parameters())
+    # the loss stack and stage-2 helpers resolve under the reference's import paths too
+    import losses
+    from losses.loss_img import VQLPIPSWithDiscriminator, hinge_d_loss, vanilla_d_loss, adopt_weight  # noqa: F401
+    from losses.discriminator import Discriminator, weights_init  # noqa: F401
+    assert losses.VQLPIPSWithDiscriminator is VQLPIPSWithDiscriminator and hasattr(losses, "BCELossWithQuant")
+    assert len(Discriminator().state_dict()) == 22
+    assert hasattr(m, "encode_to_indices") and hasattr(m, "decode_code")
 
 
 def test_no_cpu_fallback():

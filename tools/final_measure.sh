@@ -8,6 +8,7 @@ timeout 1500 python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -3 > $O/
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 600 python bench.py --workload transformer > $O/bench_transformer.json 2> $O/bench_transformer.err
+timeout 600 python bench.py --workload e2e > $O/bench_e2e.json 2> $O/bench_e2e.err
 KB="timeout 100 python tools/kbench.py"
 {
   for act in 0 2; do $KB conv_fwd --n 32 --c 128 --hw 256 --act $act | tail -1; done
