@@ -14,7 +14,12 @@
 //     XOR swizzle of the 64-byte block index instead of the 64-byte row padding: block ^ (pixel & 3) for the 256-byte dY rows,
 //     block ^ ((pixel >> 1) & 1) for the 128-byte patch rows (any 4 consecutive pixels then tile the 256-byte bank row);
 //   * the GroupNorm(+SiLU) prologue is applied IN PLACE to the patch of the NEXT tile (each wave activates the pieces it
-//     DMA'd itself: no extra barrier), the bias-gradient column sums are read back from the LDS dY tile.
+//     DMA'd itself: no extra barrier), the bias-gradient column sums are read back from the LDS dY tile; the per-image
+//     scale/shift rows come by DMA too, two tiles ahead, into a wave-private 2 x 1 KiB slot;
+//   * the DMA instructions are written in inline assembly.  With the clang builtin the compiler knows a buffer_load ... lds
+//     is pending and puts an `s_waitcnt vmcnt(0)` in front of the first ds_read_b64_tr_b16 that follows (its transpose-read
+//     intrinsic carries no memory operand to disambiguate) -- which waits for the look-ahead that was issued a few hundred
+//     cycles earlier, every tile.  Ordering is entirely by the counted waits below.
 #include "mas_common.h"
 
 namespace {
@@ -29,7 +34,8 @@ struct DmaWgradParams {
 constexpr int D_NT = 512, D_THW = 8, D_TWW = 16, D_PH = 10, D_PW = 18, D_NPP = 180;
 constexpr int D_DY = 128 * 256;                // one dY tile: 128 pixels x 128 couts x 2 B
 constexpr int D_XP = 23 * 1024;                // one patch: 180 pixels x 128 B -> 23 DMA pieces of 8 pixels
-constexpr int D_LDS = 2 * D_DY + 3 * D_XP;     // 136192 B
+constexpr int D_SS = 8 * 2 * 1024;             // scale/shift rows: per wave 2 x (64 channels x 2 floats = 512 B, in a 1 KiB DMA piece)
+constexpr int D_LDS = 2 * D_DY + 3 * D_XP + D_SS;     // 152576 B
 constexpr int D_OOB = (int)0x80000000;
 
 typedef __attribute__((ext_vector_type(4))) short d_s16x4;
@@ -42,11 +48,27 @@ __device__ __forceinline__ bf16x8 d_tr_frag(const unsigned char* a0, const unsig
 
 #define D_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
+typedef __attribute__((ext_vector_type(4))) int d_i32x4;
+// one LDS-DMA piece: 64 lanes x 16 B from descriptor `rs` at per-lane byte offset `vo` (out of range -> zeros) to LDS byte
+// address `lds` (wave-uniform) + 16 lane
+__device__ __forceinline__ void d_dma16(d_i32x4 rs, unsigned lds, int vo) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(vo), "s"(rs) : "memory", "m0");
+}
+__device__ __forceinline__ d_i32x4 d_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    d_i32x4 r = {(int)(unsigned)a, (int)(unsigned)(a >> 32), (int)bytes, 0x00020000};
+    r[0] = __builtin_amdgcn_readfirstlane(r[0]); r[1] = __builtin_amdgcn_readfirstlane(r[1]);
+    r[2] = __builtin_amdgcn_readfirstlane(r[2]); r[3] = __builtin_amdgcn_readfirstlane(r[3]);
+    return r;
+}
+
 template <bool ACT>
 __global__ __launch_bounds__(D_NT) void conv_wgrad_dma_kernel(DmaWgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const dyb = smem;               // [2][D_DY]
     unsigned char* const xb = smem + 2 * D_DY;     // [3][D_XP]
+    unsigned char* const ssb = smem + 2 * D_DY + 3 * D_XP;        // [8 waves][2][1024]
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -59,10 +81,9 @@ __global__ __launch_bounds__(D_NT) void conv_wgrad_dma_kernel(DmaWgradParams p) 
     const int co0 = co_t * 128, ci0 = ci_t * 64;
     const int n_mine = (p.n_pt - split + p.nsplit - 1) / p.nsplit;     // tiles of this work-group: split, split + nsplit, ...
 
-    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.dy), 0,
-                                                                            (unsigned)((size_t)p.N * p.Ho * p.Wo * p.Cout * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.x), 0,
-                                                                           (unsigned)((size_t)p.N * p.H * p.W * p.Cin * 2), 0x00020000);
+    const d_i32x4 rs_dy = d_rsrc(p.dy, (unsigned)((size_t)p.N * p.Ho * p.Wo * p.Cout * 2));
+    const d_i32x4 rs_x = d_rsrc(p.x, (unsigned)((size_t)p.N * p.H * p.W * p.Cin * 2));
+    const d_i32x4 rs_ss = d_rsrc(p.ss, ACT ? (unsigned)((size_t)p.N * p.Cin * 8) : 0u);
 
     f32x16 acc[9];
 #pragma unroll
@@ -93,7 +114,7 @@ __global__ __launch_bounds__(D_NT) void conv_wgrad_dma_kernel(DmaWgradParams p) 
 #ifdef D_ABL_NODMA
             if (p.N != -12345) continue;
 #endif
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dyb + buf * D_DY + piece * 1024), 16, vo, 0, 0, 0);
+            d_dma16(rs_dy, __builtin_amdgcn_readfirstlane(lds0 + buf * D_DY + piece * 1024), vo);
         }
     };
     // patch: wave w moves pieces w, w+8, w+16 (8 pixels x 128 B each; wave 7 repeats piece 22 as its third); lane -> patch pixel
@@ -120,22 +141,27 @@ __global__ __launch_bounds__(D_NT) void conv_wgrad_dma_kernel(DmaWgradParams p) 
 #ifdef D_ABL_NODMA
             if (p.N != -12345) continue;
 #endif
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(xb + buf * D_XP + x_piece(k) * 1024), 16, vo, 0, 0, 0);
+            d_dma16(rs_x, __builtin_amdgcn_readfirstlane(lds0 + 2 * D_DY + buf * D_XP + x_piece(k) * 1024), vo);
         }
     };
     // GroupNorm(+SiLU) in place: this thread takes LOGICAL 16-byte slot lane & 7 (channels ci0 + 8 (lane & 7) ..+7) of the pixels of
     // its own wave's pieces; padding pixels were written as zeros by the DMA and stay zero
-    f32x4 rss[4];
-    auto ss_load = [&](int i) {
+    // (scale, shift) of the 64 channels of tile i's image: 512 B, lanes 0..31 of one DMA piece, into this wave's slot i & 1
+    auto ss_issue = [&](int i) {
         int n, h0, w0;
         coords(i, n, h0, w0);
-        const f32x4* sp = reinterpret_cast<const f32x4*>(p.ss + ((size_t)n * p.Cin + ci0 + (lane & 7) * 8) * 2);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rss[q] = sp[q];
+        const int vo = lane < 32 ? (int)(((size_t)n * p.Cin + ci0) * 8 + lane * 16) : D_OOB;
+        d_dma16(rs_ss, __builtin_amdgcn_readfirstlane(lds0 + 2 * D_DY + 3 * D_XP + (wave * 2 + (i & 1)) * 1024), vo);
     };
     auto x_activate = [&](int i, int buf) {
         int n, h0, w0;
         coords(i, n, h0, w0);
+        f32x4 rss[4];
+        {
+            const f32x4* sp = reinterpret_cast<const f32x4*>(ssb + (wave * 2 + (i & 1)) * 1024 + (lane & 7) * 64);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rss[q] = sp[q];
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             if (k == 2 && wave == 7) continue;                    // piece 22 is wave 6's
@@ -170,12 +196,12 @@ __global__ __launch_bounds__(D_NT) void conv_wgrad_dma_kernel(DmaWgradParams p) 
     for (int e = 0; e < 8; ++e) bsum[e] = 0.0f;
     const bool do_bias = (p.dbias != nullptr) && (ci_t == 0);
 
-    // ---- prologue: dY(0), x(0), x(1) (+ scale/shift of tile 0), everything landed, x(0) activated
+    // ---- prologue: (scale/shift of tiles 0 and 1,) dY(0), x(0), x(1); for the prologue variant everything landed and x(0) activated
+    if constexpr (ACT) { ss_issue(0); ss_issue(1); }
     dy_issue(0, 0);
     x_issue(0, 0);
     x_issue(1, 1);
     if constexpr (ACT) {
-        ss_load(0);
         D_WAIT(0);
         x_activate(0, 0);
     }
@@ -184,10 +210,11 @@ __global__ __launch_bounds__(D_NT) void conv_wgrad_dma_kernel(DmaWgradParams p) 
         const int dsel = i & 1, xsel = i % 3;
         // every wave: its own DMA for tile i has landed (dY(i): issued one tile ago; x(i): two tiles ago), its activation of x(i) is in
         // LDS; after the barrier all of tile i is visible and the buffers of tile i-1 are free.  In flight across it: x(i+1) (3 pieces)
+        // (the scale/shift of tile i+1 was issued BEFORE dY(i) and has landed with it)
         asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (ACT) ss_load(i + 1);                        // 4 loads, older than the DMA below
+        if constexpr (ACT) ss_issue(i + 2);                       // slot i & 1: tile i's values were last read one tile ago
         asm volatile("" ::: "memory");
 #ifndef D_SPREAD_ISSUE
         dy_issue(i + 1, dsel ^ 1);
@@ -198,7 +225,7 @@ __global__ __launch_bounds__(D_NT) void conv_wgrad_dma_kernel(DmaWgradParams p) 
 #ifdef D_SPREAD_ISSUE
             D_WAIT(0);                                            // (spread issue: nothing younger than x(i+1) / the scale-shift is in flight yet)
 #else
-            D_WAIT(7);                                            // x(i+1) and the scale/shift have landed; 4 + 3 younger pieces fly
+            D_WAIT(8);                                            // x(i+1) has landed; 1 + 4 + 3 younger pieces fly
 #endif
             x_activate(i + 1, (i + 1) % 3);
             asm volatile("" ::: "memory");
