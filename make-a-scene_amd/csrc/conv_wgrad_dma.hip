@@ -29,17 +29,21 @@ struct DmaWgradParams {
     int N, H, W, Cin, Ho, Wo, Cout;
     int Hl, Wl, pad_top, pad_left, act, upsample;
     int tiles_h, tiles_w, n_pt, n_co_t, n_ci_t, nsplit;
+    unsigned long long* dbg;                       // -DD_TIMELINE builds only
 };
 
-constexpr int D_NT = 512, D_THW = 8, D_TWW = 16, D_PH = 10, D_PW = 18, D_NPP = 180;
+constexpr int D_THW = 8, D_TWW = 16, D_PH = 10, D_PW = 18, D_NPP = 180;
 constexpr int D_DY = 128 * 256;                // one dY tile: 128 pixels x 128 couts x 2 B
 constexpr int D_XP = 23 * 1024;                // one patch: 180 pixels x 128 B -> 23 DMA pieces of 8 pixels
-constexpr int D_SS = 8 * 2 * 1024;             // scale/shift rows: per wave 2 x (64 channels x 2 floats = 512 B, in a 1 KiB DMA piece)
-constexpr int D_LDS = 2 * D_DY + 3 * D_XP + D_SS;     // 152576 B
+constexpr int D_SS = 2 * 1024;                 // scale/shift rows of two tiles (64 channels x 2 floats = 512 B, in a 1 KiB DMA piece)
+constexpr int D_LDS = 2 * D_DY + 3 * D_XP + D_SS;     // 138240 B
 constexpr int D_OOB = (int)0x80000000;
 
 typedef __attribute__((ext_vector_type(4))) short d_s16x4;
 __device__ __forceinline__ bf16x8 d_tr_frag(const unsigned char* a0, const unsigned char* a1) {
+#ifdef D_ABL_NOREAD     // timing experiment only: fragments without LDS reads
+    { const unsigned k = (unsigned)(size_t)a0 | 0x3f803f80u; u32x4 q = {k, k, k, k}; return *reinterpret_cast<const bf16x8*>(&q); }
+#endif
     const d_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) d_s16x4*)a0);
     const d_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) d_s16x4*)a1);
     const __attribute__((ext_vector_type(8))) short v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -62,18 +66,31 @@ __device__ __forceinline__ d_i32x4 d_rsrc(const void* base, unsigned bytes) {
     return r;
 }
 
-template <bool ACT>
-__global__ __launch_bounds__(D_NT) void conv_wgrad_dma_kernel(DmaWgradParams p) {
+template <int I> struct d_ic { static constexpr int v = I; };
+
+// SPLIT = 1: 8 waves, each a 32(co) x 32(ci) x 9-tap accumulator (144 registers, 2 waves per SIMD).
+// SPLIT = 2 (-DD_SPLIT2 experiment builds): 16 waves; waves w and w + 8 share a 32 x 32 tile and split its taps 5 / 4 (80 / 64
+//            accumulator registers, 4 waves per SIMD).  The idea: a wave issues in order and one LDS read costs it ~20 cycles, one
+//            DMA piece 60-180 (tools/probes/lds_rate.hip), so two waves per SIMD need ~5.2k cycles of issue time per tile against
+//            4.6k cycles of MFMA pipe and serialise on top of that (measured 7.5k); four waves would each carry half the instruction
+//            stream.  It does not fit: 80 + 24 fragment registers leave 24 of the 128-register cap for everything else, the
+//            compiler spills 88 registers into the loop.
+template <bool ACT, int SPLIT>
+__global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradParams p) {
+    constexpr int NW = 8 * SPLIT, NT = 512 * SPLIT;
+    constexpr int DYK = 4 / SPLIT;                 // dY pieces per wave
+    constexpr int XK = SPLIT == 1 ? 3 : 2;         // patch piece slots per wave (piece = wave + NW k, valid below 23)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const dyb = smem;               // [2][D_DY]
     unsigned char* const xb = smem + 2 * D_DY;     // [3][D_XP]
-    unsigned char* const ssb = smem + 2 * D_DY + 3 * D_XP;        // [8 waves][2][1024]
+    unsigned char* const ssb = smem + 2 * D_DY + 3 * D_XP;        // [2][1024]
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wt = wave & 7, half = wave >> 3;
     const int g = lane >> 5, l31 = lane & 31, G16 = (lane >> 4) & 1, sl = lane & 15;
-    const int wco = (wave & 3) * 32, wci = (wave >> 2) * 32;
+    const int wco = (wt & 3) * 32, wci = (wt >> 2) * 32;
 
     int bid = blockIdx.x;
     const int split = bid % p.nsplit; bid /= p.nsplit;
@@ -85,101 +102,94 @@ __global__ __launch_bounds__(D_NT) void conv_wgrad_dma_kernel(DmaWgradParams p) 
     const d_i32x4 rs_x = d_rsrc(p.x, (unsigned)((size_t)p.N * p.H * p.W * p.Cin * 2));
     const d_i32x4 rs_ss = d_rsrc(p.ss, ACT ? (unsigned)((size_t)p.N * p.Cin * 8) : 0u);
 
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-
-    auto coords = [&](int i, int& n, int& h0, int& w0) {          // i-th tile of this work-group (clamped: harmless re-reads at the end)
-        int t = split + (i < n_mine ? i : n_mine - 1) * p.nsplit;
-        const int tw_i = t % p.tiles_w; t /= p.tiles_w;
-        const int th_i = t % p.tiles_h; n = t / p.tiles_h;
-        h0 = th_i * D_THW; w0 = tw_i * D_TWW;
+    // ---- tile cursor: the decode (image, tile row, tile column) is advanced incrementally (no division in the loop) and parks on
+    //      the last tile (harmless re-reads at the end)
+    struct TC { int n, h0, w0, idx; };
+    const int adv_w = (p.nsplit % p.tiles_w) * D_TWW, adv_q = p.nsplit / p.tiles_w;
+    const int adv_h = (adv_q % p.tiles_h) * D_THW, adv_n = adv_q / p.tiles_h;
+    const int lim_w = p.tiles_w * D_TWW, lim_h = p.tiles_h * D_THW;
+    auto first_tile = [&]() {
+        int t = split;
+        TC c; c.w0 = (t % p.tiles_w) * D_TWW; t /= p.tiles_w;
+        c.h0 = (t % p.tiles_h) * D_THW; c.n = t / p.tiles_h; c.idx = 0;
+        return c;
     };
-    // dY: wave w moves pieces 4w .. 4w+3 (4 pixels x 256 B each); lane -> pixel 4 piece + (lane >> 4), physical 64-byte block
-    // (lane >> 2) & 3 holding logical block ^ (pixel & 3), 16-byte slot lane & 3
-    auto dy_issue = [&](int i, int buf, int k0 = 0, int k1 = 4) {
-        int n, h0, w0;
-        coords(i, n, h0, w0);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k < k0 || k >= k1) continue;
-            const int piece = wave * 4 + k;
-            const int pix = piece * 4 + (lane >> 4);
-            const int ho = h0 + (pix >> 4), wo = w0 + (pix & 15);
-            const int blk = ((lane >> 2) & 3) ^ (pix & 3);
-            const bool ok = (ho < p.Ho) && (wo < p.Wo);
-            const int vo = ok ? (int)((((size_t)(n * p.Ho + ho) * p.Wo + wo) * p.Cout + co0 + blk * 32 + (lane & 3) * 8) * 2) : D_OOB;
+    auto next_tile = [&](TC c) {
+        if (c.idx + 1 >= n_mine) return c;
+        c.idx += 1;
+        c.w0 += adv_w; int cy = c.w0 >= lim_w; c.w0 -= cy ? lim_w : 0;
+        c.h0 += adv_h + (cy ? D_THW : 0); cy = c.h0 >= lim_h; c.h0 -= cy ? lim_h : 0;
+        c.n += adv_n + cy;
+        return c;
+    };
+    auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };   // per-piece address terms are recomputed,
+                                                                                       // not kept in registers across the tile loop
+    // dY: wave w moves pieces DYK w .. DYK w + DYK - 1 (4 pixels x 256 B each); lane -> pixel 4 piece + (lane >> 4), physical 64-byte
+    // block (lane >> 2) & 3 holding logical block ^ (pixel & 3), 16-byte slot lane & 3
+    auto dy_issue = [&](const TC& c, int buf, int k) {
+        const int lane = fresh_lane();
+        const int piece = wave * DYK + k;
+        const int pix = piece * 4 + (lane >> 4);
+        const int ho = c.h0 + (pix >> 4), wo = c.w0 + (pix & 15);
+        const int blk = ((lane >> 2) & 3) ^ (pix & 3);
+        const bool ok = (ho < p.Ho) && (wo < p.Wo);
+        const int vo = ok ? (int)((((size_t)(c.n * p.Ho + ho) * p.Wo + wo) * p.Cout + co0 + blk * 32 + (lane & 3) * 8) * 2) : D_OOB;
 #ifdef D_ABL_NODMA
-            if (p.N != -12345) continue;
+        if (p.N != -12345) return;
 #endif
-            d_dma16(rs_dy, __builtin_amdgcn_readfirstlane(lds0 + buf * D_DY + piece * 1024), vo);
-        }
+        d_dma16(rs_dy, __builtin_amdgcn_readfirstlane(lds0 + buf * D_DY + piece * 1024), vo);
     };
-    // patch: wave w moves pieces w, w+8, w+16 (8 pixels x 128 B each; wave 7 repeats piece 22 as its third); lane -> patch pixel
-    // 8 piece + (lane >> 3), physical block (lane >> 2) & 1 holding logical block ^ ((pixel >> 1) & 1), slot lane & 3
-    auto x_piece = [&](int k) { return (k < 2 || wave < 7) ? wave + 8 * k : 22; };
-    auto x_pix = [&](int k, int h0, int w0, int& P, int& ih, int& iw) -> bool {
-        P = x_piece(k) * 8 + (lane >> 3);
+    // patch: wave w moves pieces w, w + NW, .. below 23 (8 pixels x 128 B each); lane -> patch pixel 8 piece + (lane >> 3), physical
+    // block (lane >> 2) & 1 holding logical block ^ ((pixel >> 1) & 1), slot lane & 3
+    auto x_pix = [&](int k, const TC& c, int lane, int& P, int& ih, int& iw) -> bool {
+        P = (wave + NW * k) * 8 + (lane >> 3);
         const int pr = (P * 3641) >> 16, pc = P - pr * D_PW;     // P / 18 for P < 3641
-        ih = h0 + pr - p.pad_top; iw = w0 + pc - p.pad_left;
+        ih = c.h0 + pr - p.pad_top; iw = c.w0 + pc - p.pad_left;
         const bool inb = (P < D_NPP) && (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl);
         if (p.upsample) { ih >>= 1; iw >>= 1; }
         return inb;
     };
-    auto x_issue = [&](int i, int buf, int k0 = 0, int k1 = 3) {
-        int n, h0, w0;
-        coords(i, n, h0, w0);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (k < k0 || k >= k1) continue;
-            int P, ih, iw;
-            const bool inb = x_pix(k, h0, w0, P, ih, iw);
-            const int blk = ((lane >> 2) & 1) ^ ((P >> 1) & 1);
-            const int vo = inb ? (int)((((size_t)(n * p.H + ih) * p.W + iw) * p.Cin + ci0 + blk * 32 + (lane & 3) * 8) * 2) : D_OOB;
+    auto x_issue = [&](const TC& c, int buf, int k) {
+        if (wave + NW * k >= 23) return;
+        const int lane = fresh_lane();
+        int P, ih, iw;
+        const bool inb = x_pix(k, c, lane, P, ih, iw);
+        const int blk = ((lane >> 2) & 1) ^ ((P >> 1) & 1);
+        const int vo = inb ? (int)((((size_t)(c.n * p.H + ih) * p.W + iw) * p.Cin + ci0 + blk * 32 + (lane & 3) * 8) * 2) : D_OOB;
 #ifdef D_ABL_NODMA
-            if (p.N != -12345) continue;
+        if (p.N != -12345) return;
 #endif
-            d_dma16(rs_x, __builtin_amdgcn_readfirstlane(lds0 + 2 * D_DY + buf * D_XP + x_piece(k) * 1024), vo);
-        }
+        d_dma16(rs_x, __builtin_amdgcn_readfirstlane(lds0 + 2 * D_DY + buf * D_XP + (wave + NW * k) * 1024), vo);
+    };
+    // (scale, shift) of the 64 channels of a tile's image: 512 B, lanes 0..31 of one DMA piece, ONE copy per work-group (wave 0 moves
+    // it BEFORE the barrier that precedes its first use)
+    auto ss_issue = [&](const TC& c, int par) {
+        if (wave != 0) return;
+        const int lane = fresh_lane();
+        const int vo = lane < 32 ? (int)(((size_t)c.n * p.Cin + ci0) * 8 + lane * 16) : D_OOB;
+        d_dma16(rs_ss, __builtin_amdgcn_readfirstlane(lds0 + 2 * D_DY + 3 * D_XP + par * 1024), vo);
     };
     // GroupNorm(+SiLU) in place: this thread takes LOGICAL 16-byte slot lane & 7 (channels ci0 + 8 (lane & 7) ..+7) of the pixels of
     // its own wave's pieces; padding pixels were written as zeros by the DMA and stay zero
-    // (scale, shift) of the 64 channels of tile i's image: 512 B, lanes 0..31 of one DMA piece, into this wave's slot i & 1
-    auto ss_issue = [&](int i) {
-        int n, h0, w0;
-        coords(i, n, h0, w0);
-        const int vo = lane < 32 ? (int)(((size_t)n * p.Cin + ci0) * 8 + lane * 16) : D_OOB;
-        d_dma16(rs_ss, __builtin_amdgcn_readfirstlane(lds0 + 2 * D_DY + 3 * D_XP + (wave * 2 + (i & 1)) * 1024), vo);
-    };
-    auto x_activate = [&](int i, int buf) {
-        int n, h0, w0;
-        coords(i, n, h0, w0);
-        f32x4 rss[4];
-        {
-            const f32x4* sp = reinterpret_cast<const f32x4*>(ssb + (wave * 2 + (i & 1)) * 1024 + (lane & 7) * 64);
+    auto x_activate = [&](const TC& c, int buf, int k, int par) {
+        if (wave + NW * k >= 23) return;
+        const int lane = fresh_lane();
+        int P, ih, iw;
+        if (!x_pix(k, c, lane, P, ih, iw)) return;
+        const f32x4* sp = reinterpret_cast<const f32x4*>(ssb + par * 1024 + (lane & 7) * 64);
+        const int u = lane & 7;
+        unsigned char* dst = xb + buf * D_XP + P * 128 + ((((u >> 2) ^ ((P >> 1) & 1))) << 6) + (u & 3) * 16;
+        u32x4 v = *reinterpret_cast<const u32x4*>(dst);
+        const bool silu = p.act == MAS_ACT_AFFINE_SILU;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rss[q] = sp[q];
+        for (int q = 0; q < 4; ++q) {                             // (scale, shift) of channels 2q, 2q+1: 4 registers at a time
+            const f32x4 r = sp[q];
+            float lo = __uint_as_float(v[q] << 16) * r[0] + r[1], hi = __uint_as_float(v[q] & 0xffff0000u) * r[2] + r[3];
+            if (silu) { lo = silu_f(lo); hi = silu_f(hi); }
+            bf16_t pk[2] = {(bf16_t)lo, (bf16_t)hi};
+            v[q] = *reinterpret_cast<const unsigned*>(pk);
         }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (k == 2 && wave == 7) continue;                    // piece 22 is wave 6's
-            int P, ih, iw;
-            if (!x_pix(k, h0, w0, P, ih, iw)) continue;
-            const int u = lane & 7;
-            unsigned char* dst = xb + buf * D_XP + P * 128 + ((((u >> 2) ^ ((P >> 1) & 1))) << 6) + (u & 3) * 16;
-            u32x4 v = *reinterpret_cast<const u32x4*>(dst);
-            bf16_t* tv = reinterpret_cast<bf16_t*>(&v);
-            if (p.act == MAS_ACT_AFFINE_SILU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) tv[e] = (bf16_t)silu_f((float)tv[e] * rss[e >> 1][(e & 1) * 2] + rss[e >> 1][(e & 1) * 2 + 1]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) tv[e] = (bf16_t)((float)tv[e] * rss[e >> 1][(e & 1) * 2] + rss[e >> 1][(e & 1) * 2 + 1]);
-            }
-            *reinterpret_cast<u32x4*>(dst) = v;
-        }
+        *reinterpret_cast<u32x4*>(dst) = v;
     };
 
     // ---- transpose-read lane addressing (conv_wgrad.hip tr_probe semantics): lane -> pixel 8 g + (sl >> 2) (+4 for the second read),
@@ -196,112 +206,204 @@ __global__ __launch_bounds__(D_NT) void conv_wgrad_dma_kernel(DmaWgradParams p) 
     for (int e = 0; e < 8; ++e) bsum[e] = 0.0f;
     const bool do_bias = (p.dbias != nullptr) && (ci_t == 0);
 
-    // ---- prologue: (scale/shift of tiles 0 and 1,) dY(0), x(0), x(1); for the prologue variant everything landed and x(0) activated
-    if constexpr (ACT) { ss_issue(0); ss_issue(1); }
-    dy_issue(0, 0);
-    x_issue(0, 0);
-    x_issue(1, 1);
+    // ---- prologue: all of tile 0, the scale/shift rows of tiles 0 and 1 and the dY pieces of tile 1 that steady state issues in
+    //      steps 8, 9 of the previous iteration; everything landed, tile 0 activated, barrier
+    TC cA = first_tile(), cN = next_tile(cA);
+    if constexpr (ACT) { ss_issue(cA, 0); ss_issue(cN, 1); }
+#pragma unroll
+    for (int k = 0; k < DYK; ++k) dy_issue(cA, 0, k);
+#pragma unroll
+    for (int k = 0; k < XK; ++k) x_issue(cA, 0, k);
+#pragma unroll
+    for (int k = 0; k < DYK && k < 2; ++k) dy_issue(cN, 1, k);
+    D_WAIT(0);
     if constexpr (ACT) {
-        D_WAIT(0);
-        x_activate(0, 0);
+        __builtin_amdgcn_s_barrier();                             // the scale/shift row is wave 0's piece
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < XK; ++k) x_activate(cA, 0, k, 0);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    cA = cN;                                       // inside iteration j: cA = tile j+1 (fetched in steps 0..7), cN = tile j+2 (steps 7..9)
 
-    for (int i = 0; i < n_mine; ++i) {
-        const int dsel = i & 1, xsel = i % 3;
-        // every wave: its own DMA for tile i has landed (dY(i): issued one tile ago; x(i): two tiles ago), its activation of x(i) is in
-        // LDS; after the barrier all of tile i is visible and the buffers of tile i-1 are free.  In flight across it: x(i+1) (3 pieces)
-        // (the scale/shift of tile i+1 was issued BEFORE dY(i) and has landed with it)
-        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if constexpr (ACT) ss_issue(i + 2);                       // slot i & 1: tile i's values were last read one tile ago
-        asm volatile("" ::: "memory");
-#ifndef D_SPREAD_ISSUE
-        dy_issue(i + 1, dsel ^ 1);
-        x_issue(i + 2, (i + 2) % 3);
-        asm volatile("" ::: "memory");
-#endif
-        if constexpr (ACT) {
-#ifdef D_SPREAD_ISSUE
-            D_WAIT(0);                                            // (spread issue: nothing younger than x(i+1) / the scale-shift is in flight yet)
+#ifdef D_TIMELINE      // s_memtime stamps of iterations 40 and 41 of work-group 100: [0] arrive, [1] released, [2 + s] MFMAs of step s issued
+    unsigned long long tsv[12];
+#define DTS(k) asm volatile("s_memtime %0" : "=s"(tsv[k]) :: "memory")
 #else
-            D_WAIT(8);                                            // x(i+1) has landed; 1 + 4 + 3 younger pieces fly
+#define DTS(k)
 #endif
-            x_activate(i + 1, (i + 1) % 3);
-            asm volatile("" ::: "memory");
-        }
-        const unsigned char* dys = dyb + dsel * D_DY;
-        const unsigned char* xs = xb + xsel * D_XP;
-        if (do_bias) {                                            // column sums of the dY tile: channel unit tid & 15, pixels (tid >> 4) + 32 j
+
+    // ---- schedule.  A tile is 10 steps (patch rows); the taps of this wave are [LO, HI).  SPLIT = 1 prefetches the patch fragments
+    // of step s+1 during step s (double-buffered registers); SPLIT = 2 reads them at the start of their step (the SIMD's other three
+    // waves cover the latency).  The ONE work-group barrier per tile sits between steps 7 and 8 -- not at the tile boundary -- so the
+    // thin steps 8, 9 of tile j and 0, 1 of tile j+1 run through without a pipeline drain.  It publishes tile j+1: its first two dY
+    // pieces were issued in steps 8, 9 of iteration j-1, the other pieces in steps 0.. of iteration j, the in-place activation runs
+    // after a vmcnt(0) in the steps that follow; its scale/shift row was issued (wave 0) in step 7 of iteration j-1, BEFORE that
+    // iteration's barrier.  Every wave waits for its own pieces (vmcnt(0)) before it arrives.
+    // Buffers: dY(t) in t & 1 (last read in step 7 of its tile, before the barrier that precedes the first write of dY(t+2));
+    // patch(t) in t % 3 (read until step 8 of iteration t, AFTER that iteration's barrier, hence the third buffer).
+    f32x16 acc[SPLIT == 1 ? 9 : 5];
+    auto run = [&](auto HALF_T) {
+        constexpr int HALF = decltype(HALF_T)::v;
+        constexpr int LO = SPLIT == 1 ? 0 : (HALF ? 5 : 0), HI = SPLIT == 1 ? 9 : (HALF ? 9 : 5);
+        constexpr bool PREFETCH = SPLIT == 1;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int pix = (tid >> 4) + 32 * j, cu = tid & 15;
-                const u32x4 raw = *reinterpret_cast<const u32x4*>(dys + pix * 256 + (((cu >> 2) ^ (pix & 3)) << 6) + (cu & 3) * 16);
-                const bf16_t* rv = reinterpret_cast<const bf16_t*>(&raw);
+        for (int t = 0; t < HI - LO; ++t)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bsum[e] += (float)rv[e];
-            }
-        }
-        // ---- MFMA: for every patch row, every tap that touches it (sliding window of dY rows)
-        bf16x8 aw[3];
-#pragma unroll
-        for (int pr = 0; pr < D_PH; ++pr) {
-            bf16x8 bf[3];
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const unsigned char* b0 = xs + pr * (D_PW * 128) + (b_off[kw] ^ ((pr & 1) << 6));      // patch pixels (pr, kw + 8g + j)
-                bf[kw] = d_tr_frag(b0, b0 + 4 * 128);
-            }
-            if (pr < D_THW) {
-                const unsigned char* a0 = dys + pr * (16 * 256) + a_lane;                                 // dY pixels (pr, 8g + j)
-                aw[pr % 3] = d_tr_frag(a0, a0 + 4 * 256);
-            }
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        bf16x8 aw[3], bf[PREFETCH ? 2 : 1][3];
+        auto kw_needed = [&](int pr, int kw) {                    // does step pr of this wave use the patch fragment kw ?
+            bool need = false;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-                const int rr = pr - kh;
-                if (rr < 0 || rr >= D_THW) continue;
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) mma16(acc[kh * 3 + kw], aw[rr % 3], bf[kw]);
+                const int t = kh * 3 + kw, rr = pr - kh;
+                if (t >= LO && t < HI && rr >= 0 && rr < D_THW) need = true;
             }
-#ifdef D_SPREAD_ISSUE   // one DMA piece of the look-ahead tiles after each of the first 7 patch rows (same VMEM order: dY x4, then x x3)
-            if (pr < 4) dy_issue(i + 1, dsel ^ 1, pr, pr + 1);
-            else if (pr < 7) x_issue(i + 2, (i + 2) % 3, pr - 4, pr - 3);
+            return need;
+        };
+        auto load_b = [&](const unsigned char* xs, int pr) {      // -> bf[PREFETCH ? pr & 1 : 0]
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                if (!kw_needed(pr, kw)) continue;
+                const unsigned char* b0 = xs + pr * (D_PW * 128) + (b_off[kw] ^ ((pr & 1) << 6));      // patch pixels (pr, kw + 8g + j)
+                bf[PREFETCH ? (pr & 1) : 0][kw] = d_tr_frag(b0, b0 + 4 * 128);
+            }
+        };
+        auto load_a = [&](const unsigned char* dys, int pr) {     // -> aw[pr % 3]
+            const unsigned char* a0 = dys + pr * (16 * 256) + a_lane;                                 // dY pixels (pr, 8g + j)
+            aw[pr % 3] = d_tr_frag(a0, a0 + 4 * 256);
+        };
+        auto mfma_kh = [&](int pr, int kh) {
+            const int rr = pr - kh;
+            if (rr < 0 || rr >= D_THW) return;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int t = kh * 3 + kw;
+                if (t < LO || t >= HI) continue;
+#ifdef D_ABL_NOMFMA     // timing experiment only
+                acc[t - LO][0] += (float)aw[rr % 3][0] + (float)bf[PREFETCH ? (pr & 1) : 0][kw][0];
+#else
+                mma16(acc[t - LO], aw[rr % 3], bf[PREFETCH ? (pr & 1) : 0][kw]);
 #endif
+            }
+        };
+        if constexpr (PREFETCH) load_b(xb, 0);
+        load_a(dyb, 0);
+        for (int j = 0; j < n_mine; ++j) {
+#ifdef D_TIMELINE
+            if (j >= 41 && j < 43 && blockIdx.x == 100 && lane == 0 && p.dbg) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) p.dbg[((j - 41) * NW + wave) * 16 + k] = tsv[k];
+            }
+            asm volatile("" ::: "memory");
+#endif
+            const unsigned char* dys = dyb + (j & 1) * D_DY;
+            const unsigned char* xs = xb + (j % 3) * D_XP;
+            const int xn = (j + 1) % 3, dn = (j + 1) & 1;         // buffers of tile j+1
+#pragma unroll
+            for (int pr = 0; pr < D_PH; ++pr) {
+                if (pr == 8) {                                    // ---- the barrier: tile j+1 complete and visible, dY(j) dead
+                    DTS(0);
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifndef D_ABL_NOBAR
+                    __builtin_amdgcn_s_barrier();
+#endif
+                    asm volatile("" ::: "memory");
+                    DTS(1);
+                }
+                if constexpr (PREFETCH) {
+                    if (pr + 1 < D_PH) load_b(xs, pr + 1);
+                    else load_b(xb + xn * D_XP, 0);               // step 9: row 0 of the next tile
+                } else {
+                    load_b(xs, pr);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_kh(pr, 2);                                   // the oldest dY row first: its registers take the next fragment
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- side work of this step.  DMA pieces of a wave in issue order: dY 0 .. DYK-1, then patch 0 .. XK-1, at steps
+                //      8, 9 (tile j+2) and 0, 1, 2, .. (tile j+1)
+#pragma unroll
+                for (int q = 0; q < DYK + XK; ++q) {
+                    if ((8 + q) % D_PH != pr) continue;
+                    const bool late = q < 2;                      // issued at the end of the previous iteration
+                    if (q < DYK) dy_issue(late ? cN : cA, late ? (j & 1) : dn, q);
+                    else x_issue(late ? cN : cA, late ? (j + 2) % 3 : xn, q - DYK);
+                }
+                constexpr int ACT0 = (8 + DYK + XK) % D_PH + (SPLIT == 1 ? 0 : 2);     // first activation step: 5 (SPLIT 1), 4 (SPLIT 2)
+                if (pr == (SPLIT == 1 ? (ACT ? 4 : 5) : 2) && do_bias) {   // column sums of the dY tile: channel unit tid & 15, pixels (tid >> 4) + (NT / 16) q
+#pragma unroll
+                    for (int q = 0; q < 2048 / NT; ++q) {
+                        const int pix = (tid >> 4) + (NT / 16) * q, cu = tid & 15;
+                        const u32x4 raw = *reinterpret_cast<const u32x4*>(dys + pix * 256 + (((cu >> 2) ^ (pix & 3)) << 6) + (cu & 3) * 16);
+                        const bf16_t* rv = reinterpret_cast<const bf16_t*>(&raw);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) bsum[e] += (float)rv[e];
+                    }
+                }
+                if constexpr (ACT) {
+                    if (pr == ACT0) D_WAIT(0);                    // this wave's pieces of tile j+1 (the oldest issued a tile ago) have landed
+                    if (pr >= ACT0 && pr < ACT0 + XK) x_activate(cA, xn, pr - ACT0, dn);
+                }
+                if (pr == 7) {
+                    cN = next_tile(cA);
+                    if constexpr (ACT) ss_issue(cN, j & 1);       // tile j+2's row; slot j & 1 was last read in iteration j-1
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_kh(pr, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pr + 1 < D_THW) load_a(dys, pr + 1);
+                else if (pr == D_PH - 1) load_a(dyb + dn * D_DY, 0);   // step 9: dY row 0 of the next tile (slot 0: row 6 is done)
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_kh(pr, 0);
+#ifdef D_TIMELINE
+                __builtin_amdgcn_sched_barrier(0);
+                DTS(2 + pr);
+                if (pr == D_PH - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cA = cN;
         }
-    }
-    D_WAIT(0);                                                    // the look-ahead DMA of tiles past the end must land before the LDS is reused / the block exits
+        D_WAIT(0);                                                // the look-ahead DMA of tiles past the end must land before the LDS is reused / the block exits
 
-    const int ci = ci0 + wci + l31;
+        const int ci = ci0 + wci + l31;
 #ifdef D_ABL_NOATOM     // timing experiment only
-    if (p.N != -12345) {
-        float t = 0.0f;
-        for (int k = 0; k < 9; ++k) for (int r = 0; r < 16; ++r) t += acc[k][r];
-        if (t == 123.456f) p.dw[0] = t;
-        return;
-    }
+        if (p.N != -12345) {
+            float t = 0.0f;
+            for (int k = 0; k < HI - LO; ++k) for (int r = 0; r < 16; ++r) t += acc[k][r];
+            if (t == 123.456f) p.dw[0] = t;
+            return;
+        }
 #endif
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+        for (int t = LO; t < HI; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wco + acc_row(lane, r);
-            atomicAdd(p.dw + ((size_t)co * 9 + t) * p.Cin + ci, acc[t][r]);
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco + acc_row(lane, r);
+                atomicAdd(p.dw + ((size_t)co * 9 + t) * p.Cin + ci, acc[t - LO][r]);
+            }
+    };
+    if (SPLIT == 1 || half == 0) run(d_ic<0>{}); else run(d_ic<1>{});
+#ifdef D_ABL_NOATOM
+    if (p.N != -12345) return;
+#endif
     if (do_bias) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);
-        for (int k = tid; k < 128; k += D_NT) red[k] = 0.0f;
+        for (int k = tid; k < 128; k += NT) red[k] = 0.0f;
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 8; ++e) atomicAdd(&red[(tid & 15) * 8 + e], bsum[e]);
         __syncthreads();
-        for (int k = tid; k < 128; k += D_NT) atomicAdd(p.dbias + co0 + k, red[k]);
+        for (int k = tid; k < 128; k += NT) atomicAdd(p.dbias + co0 + k, red[k]);
     }
 }
 
-template <bool ACT>
+template <bool ACT, int SPLIT>
 int launch_dma(DmaWgradParams p, hipStream_t s) {
-    auto kern = conv_wgrad_dma_kernel<ACT>;
+    auto kern = conv_wgrad_dma_kernel<ACT, SPLIT>;
     static mas_devmask_t attr_mask{0};
     unsigned long long attr_bit;
     if (mas_attr_needed(attr_mask, &attr_bit)) {
@@ -309,7 +411,7 @@ int launch_dma(DmaWgradParams p, hipStream_t s) {
             MAS_FAIL(MAS_ELAUNCH, "conv_wgrad_dma: cannot set dynamic LDS size %d", D_LDS);
         mas_attr_done(attr_mask, attr_bit);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.n_co_t * p.n_ci_t * p.nsplit)), dim3(D_NT), D_LDS, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.n_co_t * p.n_ci_t * p.nsplit)), dim3(512 * SPLIT), D_LDS, s, p);
     MAS_CHECK_LAUNCH("conv_wgrad_dma");
     return MAS_OK;
 }
@@ -333,6 +435,10 @@ int mas_conv_wgrad_dma_try(const MasConvDesc* d, const void* x, const float* sca
     p.tiles_h = mas_cdiv(p.Ho, D_THW); p.tiles_w = mas_cdiv(p.Wo, D_TWW);
     p.n_pt = p.N * p.tiles_h * p.tiles_w;
     p.n_co_t = d->Cout / 128; p.n_ci_t = d->Cin / 64;
+    p.dbg = nullptr;
+#ifdef D_TIMELINE
+    if (const char* e = getenv("MAS_DBG_PTR")) p.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
+#endif
     const int out_tiles = p.n_co_t * p.n_ci_t;
     // One register-file-filling work-group per CU.  Under a co-running RCCL collective (data-parallel backward) some CUs are taken
     // and a grid of exactly one work-group per CU runs the displaced ones as a second FULL round; MAS_WGRAD_OVERSUB=2 (bench.py sets
@@ -343,6 +449,11 @@ int mas_conv_wgrad_dma_try(const MasConvDesc* d, const void* x, const float* sca
     if (nsplit > p.n_pt) nsplit = p.n_pt;
     if (nsplit < 1) nsplit = 1;
     p.nsplit = nsplit;
-    const int rc = d->act != MAS_ACT_NONE ? launch_dma<true>(p, s) : launch_dma<false>(p, s);
+    const bool act = d->act != MAS_ACT_NONE;
+#ifdef D_SPLIT2         // experiment builds only: the 16-wave tap-split variant does not fit the 128-register cap (88 spilled registers)
+    static const int wsplit = mas_env_int("MAS_WGRAD_SPLIT", 2);
+    if (wsplit == 2) { const int rc2 = act ? launch_dma<true, 2>(p, s) : launch_dma<false, 2>(p, s); return rc2 == MAS_OK ? 1 : rc2; }
+#endif
+    const int rc = act ? launch_dma<true, 1>(p, s) : launch_dma<false, 1>(p, s);
     return rc == MAS_OK ? 1 : rc;
 }

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Per-tile phase timeline of conv_wgrad from a -DMAS_TIMELINE build (work-group 100, first 4 tiles)."""
+"""Per-wave row timeline of the LDS-DMA wgrad kernel (a -DD_TIMELINE build: tools/build_file_variant.sh wg_tl conv_wgrad_dma.hip
+-DD_TIMELINE; run with MAS_HIP_LIB=<that .so>).  Work-group 100, its tiles 40 and 41; s_memtime ticks (shader cycles)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "make-a-scene_amd"))
 import torch
 dev = torch.device("cuda:0")
-dbg = torch.zeros(4 * 8 * 8, dtype=torch.int64, device=dev)
+dbg = torch.zeros(2 * 8 * 16, dtype=torch.int64, device=dev)
 os.environ["MAS_DBG_PTR"] = hex(dbg.data_ptr())
 from mas_hip import ops
 act = int(sys.argv[1]) if len(sys.argv) > 1 else 0
@@ -16,14 +17,16 @@ ss = torch.randn(n, c, 2, device=dev) if act else None
 for _ in range(3):
     ops.conv_wgrad_raw(x, ss, dy, n, h, h, c, h, h, c, 3, 1, 1, 1, act, False, True)
 torch.cuda.synchronize()
-d = dbg.cpu().view(4, 8, 8).double()
-if os.environ.get("MAS_WGRAD_NO_TR"):
-    names = ["tile top", "barrier0 released", "dY staged", "A staged", "barrier1 released", "MFMA issued"]
-else:       # transpose-read kernel: two LDS stages, one barrier per tile
-    names = ["tile top", "next loads issued", "MFMA issued", "next tile staged", "barrier released"]
-for it in range(1, 4):
-    t0 = d[it, :, 0].min()
-    print(f"tile {it}: " + "  ".join(f"{names[k]}={int(d[it, :, k].mean() - t0)}" for k in range(len(names))) +
-          f"   next tile top={int(d[it + 1, :, 0].mean() - t0) if it < 3 else -1}")
-    for wv in range(8):
-        print("     wave", wv, [int(d[it, wv, k] - t0) for k in range(len(names))])
+d = dbg.cpu().view(2, 8, 16)
+for it in range(2):
+    t0 = int(d[it, :, 0].min())
+    print(f"--- tile {40 + it} of work-group 100 (act={act}); cycles since the earliest wave's arrival; waves 0..7")
+    names = ["arrive", "released"] + [f"row {r} issued" for r in range(10)]
+    prev = None
+    for k, nm in enumerate(names):
+        v = [int(t) - t0 for t in d[it, :, k]]
+        m = sum(v) / 8
+        print(f"{nm:14s} mean {int(m):6d}  d {int(m - prev) if prev is not None else 0:5d}   {v}")
+        prev = m
+    if it == 0:
+        print("tile period (arrive -> next arrive), per wave:", [int(d[1, w, 0] - d[0, w, 0]) for w in range(8)])
