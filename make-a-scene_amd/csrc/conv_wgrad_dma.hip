@@ -171,19 +171,24 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
     };
     // GroupNorm(+SiLU) in place: this thread takes LOGICAL 16-byte slot lane & 7 (channels ci0 + 8 (lane & 7) ..+7) of the pixels of
     // its own wave's pieces; padding pixels were written as zeros by the DMA and stay zero
-    auto x_activate = [&](const TC& c, int buf, int k, int par) {
+    f32x4 rss[4];                                  // the lane's 8 (scale, shift) pairs of the tile being activated
+    auto ss_fetch = [&](int par) {
+        const f32x4* sp = reinterpret_cast<const f32x4*>(ssb + par * 1024 + (lane & 7) * 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rss[q] = sp[q];
+    };
+    auto x_activate = [&](const TC& c, int buf, int k) {
         if (wave + NW * k >= 23) return;
         const int lane = fresh_lane();
         int P, ih, iw;
         if (!x_pix(k, c, lane, P, ih, iw)) return;
-        const f32x4* sp = reinterpret_cast<const f32x4*>(ssb + par * 1024 + (lane & 7) * 64);
         const int u = lane & 7;
         unsigned char* dst = xb + buf * D_XP + P * 128 + ((((u >> 2) ^ ((P >> 1) & 1))) << 6) + (u & 3) * 16;
         u32x4 v = *reinterpret_cast<const u32x4*>(dst);
         const bool silu = p.act == MAS_ACT_AFFINE_SILU;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {                             // (scale, shift) of channels 2q, 2q+1: 4 registers at a time
-            const f32x4 r = sp[q];
+        for (int q = 0; q < 4; ++q) {                             // (scale, shift) of channels 2q, 2q+1
+            const f32x4 r = rss[q];
             float lo = __uint_as_float(v[q] << 16) * r[0] + r[1], hi = __uint_as_float(v[q] & 0xffff0000u) * r[2] + r[3];
             if (silu) { lo = silu_f(lo); hi = silu_f(hi); }
             bf16_t pk[2] = {(bf16_t)lo, (bf16_t)hi};
@@ -220,8 +225,9 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
     if constexpr (ACT) {
         __builtin_amdgcn_s_barrier();                             // the scale/shift row is wave 0's piece
         asm volatile("" ::: "memory");
+        ss_fetch(0);
 #pragma unroll
-        for (int k = 0; k < XK; ++k) x_activate(cA, 0, k, 0);
+        for (int k = 0; k < XK; ++k) x_activate(cA, 0, k);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
     auto run = [&](auto HALF_T) {
         constexpr int HALF = decltype(HALF_T)::v;
         constexpr int LO = SPLIT == 1 ? 0 : (HALF ? 5 : 0), HI = SPLIT == 1 ? 9 : (HALF ? 9 : 5);
-        constexpr bool PREFETCH = SPLIT == 1;
+        constexpr bool PREFETCH = SPLIT == 1 && !ACT;     // the prologue variant spends those 12 registers on the scale/shift pairs
 #pragma unroll
         for (int t = 0; t < HI - LO; ++t)
 #pragma unroll
@@ -343,8 +349,8 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
                     }
                 }
                 if constexpr (ACT) {
-                    if (pr == ACT0) D_WAIT(0);                    // this wave's pieces of tile j+1 (the oldest issued a tile ago) have landed
-                    if (pr >= ACT0 && pr < ACT0 + XK) x_activate(cA, xn, pr - ACT0, dn);
+                    if (pr == ACT0) { D_WAIT(0); ss_fetch(dn); }  // this wave's pieces of tile j+1 (the oldest issued a tile ago) have landed
+                    if (pr >= ACT0 && pr < ACT0 + XK) x_activate(cA, xn, pr - ACT0);
                 }
                 if (pr == 7) {
                     cN = next_tile(cA);
