@@ -2,3 +2,5 @@
 ``conf/*.yaml`` (``_target_: losses.loss_img.VQLPIPSWithDiscriminator``, ``losses.VQVAEWithBCELoss``) resolve unchanged."""
 from .loss_seg import BCELossWithQuant, VQVAEWithBCELoss
 from .loss_img import VQLPIPSWithDiscriminator
+from .lpips import LPIPS
+from .lpips_with_object import LPIPSWithObject

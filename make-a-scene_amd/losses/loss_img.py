@@ -4,8 +4,9 @@ obtained with ``torch.autograd.grad(..., retain_graph=True)`` THROUGH the HIP au
 
 The discriminator runs on the MI355X kernels (``losses.discriminator``).  The two terms of the reference that need pretrained
 networks at absolute paths -- LPIPS-VGG16 (``/home/ubuntu/.../vgg.pth``, lpips.py:15) and the face-embedding loss
-(face_loss.py:76) -- are pluggable callables here (``perceptual_loss`` / ``face_loss``, default: absent = contribute 0); with
-neither the arithmetic below is the reference's line for line.  ``forward`` keeps the reference's signature and return shapes
+(face_loss.py:76) -- are pluggable here: ``perceptual_loss="lpips"`` builds ``losses.lpips_with_object.LPIPSWithObject`` on the
+HIP convolutions (weights from ``MAS_LPIPS_CKPT``), a callable is used as given, ``None`` (default) contributes 0; ``face_loss`` is a
+callable or None (its face-embedding network is not part of this repository).  The arithmetic below is the reference's line for line.  ``forward`` keeps the reference's signature and return shapes
 (optimizer_idx 0 -> ``loss, (nll_loss, object_loss, face_loss)``; 1 -> ``d_loss``)."""
 import torch
 import torch.nn as nn
@@ -36,6 +37,9 @@ class VQLPIPSWithDiscriminator(nn.Module):
         super().__init__()
         self.codebook_weight = codebook_weight
         self.pixel_weight = pixelloss_weight
+        if perceptual_loss == "lpips":                 # the reference's default (loss_img.py:45)
+            from .lpips_with_object import LPIPSWithObject
+            perceptual_loss = LPIPSWithObject().eval()
         self.perceptual_loss = perceptual_loss        # callable(images, reconstructions, bbox_obj) -> per-sample map, or None
         self.perceptual_weight = perceptual_weight
         self.face_loss = face_loss                    # callable(images, reconstructions, bbox_face) -> scalar, or None

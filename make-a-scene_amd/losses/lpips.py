@@ -1,0 +1,127 @@
+"""LPIPS-VGG16 perceptual distance (reference losses/lpips.py:41-144) on the MI355X convolution kernels.
+
+Same class names, constructor-free surface and ``state_dict`` layout as the reference (``scaling_layer.{shift,scale}``,
+``vgg.slice<k>.<i>.{weight,bias}`` with the indices torchvision's ``features[a:b]`` slices give, ``lin<k>.model.1.weight``), so a
+state_dict saved from the reference's module loads with ``strict=True``.  The thirteen 3x3 convolutions of VGG16 -- all of the
+FLOPs: ~20 GFLOP per 256x256 image and pass -- run on libmas_hip's implicit-GEMM kernels in bf16 with fp32 accumulation, forward
+and data gradient (the network is frozen: no weight gradients); real and reconstructed images go through the stack as ONE batch.
+ReLU, the four 2x2 max-pools and the channel normalisation / squared difference / 1x1 linear heads / spatial mean of the distance
+are the reference's own torch expressions (elementwise and reduction passes).
+
+What the reference does at construction and this module cannot: it downloads ``vgg.pth`` and takes torchvision's pretrained VGG16
+(lpips.py:10-15,55,101).  There is no network here: weights come from ``MAS_LPIPS_CKPT`` (a state_dict with the keys above, e.g.
+``LPIPS().state_dict()`` saved from the reference), or from the reference's path if that file exists; otherwise the module keeps
+its random initialisation and says so once -- the loss is then a perceptual distance in name only."""
+import os
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from models.modules import Conv2d
+
+CKPT_PATHS = (os.environ.get("MAS_LPIPS_CKPT", ""), "/home/ubuntu/Make-A-Scene/weights/vgg.pth")      # lpips.py:15
+
+
+class ScalingLayer(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("shift", torch.Tensor([-.030, -.088, -.188])[None, :, None, None])
+        self.register_buffer("scale", torch.Tensor([.458, .448, .450])[None, :, None, None])
+
+    def forward(self, x):
+        return (x - self.shift) / self.scale
+
+
+class NetLinLayer(nn.Module):
+    """Dropout + bias-free 1x1 convolution C -> 1 (lpips.py:89-95); a plain nn.Conv2d holder: the head is applied as a weighted
+    channel sum inside ``LPIPS.forward``."""
+
+    def __init__(self, in_channels, out_channels=1):
+        super().__init__()
+        self.model = nn.Sequential(nn.Dropout(), nn.Conv2d(in_channels, out_channels, 1, 1, 0, bias=False))
+
+
+class _VggConv(Conv2d):
+    in_dtype = torch.bfloat16
+    out_dtype = torch.bfloat16
+
+
+class VGG16(nn.Module):
+    """torchvision's VGG16 ``features[0:30]`` in the reference's five slices (lpips.py:98-124)."""
+
+    def __init__(self):
+        super().__init__()
+
+        def block(cin, cout, n, pool):
+            layers = [nn.MaxPool2d(kernel_size=2, stride=2)] if pool else []
+            for k in range(n):
+                layers += [_VggConv(cin if k == 0 else cout, cout, 3, 1, 1), nn.ReLU(inplace=True)]
+            return nn.Sequential(*layers)
+        self.slice1 = block(3, 64, 2, False)
+        self.slice2 = block(64, 128, 2, True)
+        self.slice3 = block(128, 256, 3, True)
+        self.slice4 = block(256, 512, 3, True)
+        self.slice5 = block(512, 512, 3, True)
+        for param in self.parameters():
+            param.requires_grad = False
+
+    def forward(self, x):
+        feats = []
+        h = x
+        for s in (self.slice1, self.slice2, self.slice3, self.slice4, self.slice5):
+            h = s(h)
+            feats.append(h)
+        return tuple(feats)
+
+
+def norm_tensor(x):
+    norm_factor = torch.sqrt(torch.sum(x ** 2, dim=1, keepdim=True))
+    return x / (norm_factor + 1e-10)
+
+
+def spatial_average(x):
+    return x.mean([2, 3], keepdim=True)
+
+
+class LPIPS(nn.Module):
+    _warned = False
+
+    def __init__(self):
+        super().__init__()
+        self.scaling_layer = ScalingLayer()
+        self.channels = [64, 128, 256, 512, 512]
+        self.vgg = VGG16()
+        self.lin0 = NetLinLayer(self.channels[0])
+        self.lin1 = NetLinLayer(self.channels[1])
+        self.lin2 = NetLinLayer(self.channels[2])
+        self.lin3 = NetLinLayer(self.channels[3])
+        self.lin4 = NetLinLayer(self.channels[4])
+        self.load_from_pretrained()
+        self.lins = [self.lin0, self.lin1, self.lin2, self.lin3, self.lin4]
+        for param in self.parameters():
+            param.requires_grad = False
+
+    def load_from_pretrained(self, name="vgg_lpips"):
+        for path in CKPT_PATHS:
+            if path and os.path.exists(path):
+                self.load_state_dict(torch.load(path, map_location=torch.device("cpu")), strict=False)
+                return
+        if not LPIPS._warned:
+            LPIPS._warned = True
+            warnings.warn("LPIPS: no checkpoint (set MAS_LPIPS_CKPT to a state_dict of the reference's LPIPS module); keeping the random "
+                          "initialisation -- the perceptual term is not meaningful until weights are loaded")
+
+    def forward(self, real_x, fake_x):
+        b = real_x.shape[0]
+        feats = self.vgg(self.scaling_layer(torch.cat([real_x, fake_x], dim=0)))            # one pass for both images
+        total = 0
+        for i, f in enumerate(feats):
+            f = f.float()
+            d = (norm_tensor(f[:b]) - norm_tensor(f[b:])) ** 2
+            w = self.lins[i].model[1].weight.float()                                          # [1, C, 1, 1], eval-mode Dropout = identity
+            if self.training and self.lins[i].model[0].p > 0 and self.lins[i].training:
+                d = self.lins[i].model[0](d)
+            total = total + spatial_average((d * w).sum(dim=1, keepdim=True))
+        return total

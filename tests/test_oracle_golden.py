@@ -166,3 +166,32 @@ def test_loss_oracle_vs_reference_discriminator_golden(golden_dir):
     with torch.no_grad():
         assert rel(LO.disc_forward(sd, real, False), g["logits_real_eval"]) < 1e-5
     assert LO.adopt_weight(0.8, 10, 20) == float(g["adopt"][0]) == 0.0 and abs(LO.adopt_weight(0.8, 30, 20) - float(g["adopt"][1])) < 1e-7
+
+
+def test_lpips_oracle_vs_reference_golden(golden_dir):
+    """oracle/lpips_oracle.py against the reference's own LPIPS class (tests/golden/make_lpips_golden.py): distance, input
+    gradient, the five feature taps, and the state_dict layout our module must expose."""
+    import warnings
+    from oracle import lpips_oracle as LO
+    g = np.load(os.path.join(golden_dir, "lpips_tiny.npz"))
+    assert [str(k) for k in g["keys"]] == LO.expected_keys()
+    sd = LO.synth_lpips_state_dict(seed=3)
+    real = torch.from_numpy(g["real"])
+    fake = torch.from_numpy(g["fake"]).requires_grad_(True)
+    out = LO.lpips(sd, real, fake)
+    out.sum().backward()
+    assert out.shape == (2, 1, 1, 1)
+    assert np.abs(out.detach().numpy() - g["out"]).max() <= 1e-6 * np.abs(g["out"]).max()
+    assert np.abs(fake.grad.numpy() - g["dfake"]).max() <= 1e-5 * np.abs(g["dfake"]).max()
+    feats = LO.vgg_features(sd, (real - sd["scaling_layer.shift"]) / sd["scaling_layer.scale"])
+    assert [list(f.shape) for f in feats] == g["feat_shapes"].tolist()
+    assert np.allclose([float(f.mean()) for f in feats], g["feat_means"], rtol=1e-5)
+    # the product's module: same keys in the same order, strict load of a reference-shaped state_dict (no kernel runs here)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import losses
+        m = losses.LPIPS()
+    assert list(m.state_dict().keys()) == LO.expected_keys()
+    m.load_state_dict(sd, strict=True)
+    assert not any(p.requires_grad for p in m.parameters())
+    assert isinstance(losses.LPIPSWithObject(), losses.LPIPS)
