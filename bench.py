@@ -29,6 +29,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL / cross-process device memory needs on this driver
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "make-a-scene_amd"), ROOT):
     if p not in sys.path:
