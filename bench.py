@@ -357,8 +357,28 @@ def run_vq(args):
 # --------------------------------------------------------------------------------------------------------------------
 # workloads: transformer (config 4) and e2e (config 5)
 # --------------------------------------------------------------------------------------------------------------------
+def _library_gemm_selection():
+    """The Linear layers are plain library GEMMs (hipBLASLt / rocBLAS through torch).  PyTorch's TunableOp picks, per GEMM shape,
+    the fastest of the libraries' own solutions; the selection measured on an MI355X for this workload's 15 shapes is committed
+    (make-a-scene_amd/tuning/, +2 % on the step) and only REPLAYED here: no tuning inside a bench run, and a file whose validator
+    lines do not match the installed libraries is ignored by TunableOp itself.  MAS_BENCH_TUNABLEOP=0 turns it off."""
+    path = os.path.join(ROOT, "make-a-scene_amd", "tuning", "tunableop_gfx950_transformer.csv")
+    if os.environ.get("MAS_BENCH_TUNABLEOP", "1") != "1" or not os.path.exists(path):
+        return None
+    try:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(False)
+        tunable.set_filename(path)
+        return os.path.basename(path) if tunable.read_file(path) else None
+    except Exception as e:                                   # a torch build without TunableOp: library defaults
+        print(f"bench.py: TunableOp replay unavailable ({e}); library default GEMM selection", file=sys.stderr)
+        return None
+
+
 def run_transformer(args, e2e):
     world, rank, local_rank, dev, ddp = _setup_dist(args)
+    gemm_sel = _library_gemm_selection()
     from mas_hip import ops
     from models import VQBASE
     from models.transformer import MakeAScene
@@ -445,7 +465,8 @@ def run_transformer(args, e2e):
             wl = f"BASELINE configs[3]: MakeAScene 24L/1024d/16 heads (head_dim 64, assumed: SURVEY 8(d)), 256 text + 256 seg + 1024 image tokens"
         out.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                     "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-                    "config": {"workload": wl, "per_gpu_batch": batch, "global_batch": batch * world, "parallelism": _par(world, args, ddp)},
+                    "config": {"workload": wl, "per_gpu_batch": batch, "global_batch": batch * world, "parallelism": _par(world, args, ddp),
+                               "library_gemm_selection": gemm_sel or "library default"},
                     "final_loss": round(final_loss, 5), "replica_weight_checksum_spread": spread,
                     "model_tflops_per_gpu": round(samples / world / dt * gf / 1e3, 1)})
         if att["ev"]:
