@@ -205,6 +205,13 @@ int mas_layernorm_bwd(const void* x, const void* dy, const float* gamma, const f
                       float* dgamma, float* dbeta, int in_dtype, int out_dtype, int rows, int D,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* mas_colsum: out[c] = sum over rows of x[r][c] (fp32 accumulation, fixed summation order: bitwise run-to-run deterministic).
+ *   The bias gradient of the transformer's Linear layers (torch.nn.Linear in reference models/transformer.py:31,34,125,126:
+ *   grad_bias = grad_output.sum(0)) over [B*S, N] activations.  x bf16 or fp32, row stride = cols, cols % 8 == 0 (bf16) / % 4 (fp32).
+ *   workspace: mas_colsum_workspace(rows, cols) bytes, caller-owned.                                                          */
+size_t mas_colsum_workspace(int rows, int cols);
+int mas_colsum(const void* x, int dtype, int rows, int cols, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

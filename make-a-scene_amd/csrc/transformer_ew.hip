@@ -265,6 +265,62 @@ __global__ __launch_bounds__(NT) void layernorm_param_reduce(const float* __rest
     }
 }
 
+// Column sums of a [rows][cols] matrix, two stages.  Stage 1: work-group (cb, sl) = one wave, one 16-byte vector of columns per
+// lane, rows sl, sl + nsl, ... (8 loads in flight per lane) -> tmp[sl][cols]; stage 2: 32 columns x 8 row groups per work-group add
+// the nsl <= 128 partial rows (fixed order: bitwise run-to-run deterministic).
+constexpr int CS_NT = 64, CS_MAX_SLICES = 128;
+template <typename T>
+__global__ __launch_bounds__(CS_NT) void colsum_partial(const T* __restrict__ x, int rows, int cols, int nsl, float* __restrict__ tmp) {
+    constexpr int N = EwVec<T>::N;
+    const int c0 = (blockIdx.x * CS_NT + threadIdx.x) * N, sl = blockIdx.y;
+    if (c0 >= cols) return;
+    float acc[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[e] = 0.0f;
+    int r = sl;
+    for (; r + 7 * nsl < rows; r += 8 * nsl) {
+        u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const u32x4*>(x + (size_t)(r + u * nsl) * cols + c0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const T* e_ = reinterpret_cast<const T*>(&v[u]);
+#pragma unroll
+            for (int e = 0; e < N; ++e) acc[e] += (float)e_[e];
+        }
+    }
+    for (; r < rows; r += nsl) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + (size_t)r * cols + c0);
+        const T* e_ = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[e] += (float)e_[e];
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) tmp[(size_t)sl * cols + c0 + e] = acc[e];
+}
+__global__ __launch_bounds__(256) void colsum_final(const float* __restrict__ tmp, int nsl, int cols, float* __restrict__ out) {
+    __shared__ float red[8][32];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5, col = blockIdx.x * 32 + c;
+    float t = 0.0f;
+    if (col < cols)
+        for (int k = rg; k < nsl; k += 8) t += tmp[(size_t)k * cols + col];
+    red[rg][c] = t;
+    __syncthreads();
+    if (threadIdx.x < 32 && col < cols) {
+        float a = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a += red[r][c];
+        out[col] = a;
+    }
+}
+int colsum_slices(int rows, int cols, int vec) {
+    const int col_blocks = mas_cdiv(cols, CS_NT * vec);
+    int nsl = mas_cdiv(4 * mas_num_cus(), col_blocks > 0 ? col_blocks : 1);      // ~4 one-wave work-groups per CU
+    if (nsl > CS_MAX_SLICES) nsl = CS_MAX_SLICES;
+    if (nsl > mas_cdiv(rows, 8)) nsl = mas_cdiv(rows, 8);                         // at least 8 rows per work-group
+    return nsl < 1 ? 1 : nsl;
+}
+
 int ln_blocks(int rows) {
     int nb = mas_cdiv(rows, NT / 64);
     const int cap = 4 * mas_num_cus();
@@ -356,5 +412,31 @@ extern "C" int mas_layernorm_bwd(const void* x, const void* dy, const float* gam
     hipLaunchKernelGGL(layernorm_param_reduce, dim3(mas_cdiv(D, 32), LN_SLICES), dim3(NT), 0, s, partial, nblk, D, LN_SLICES, tmp, tmp + D, 2 * D);
     hipLaunchKernelGGL(layernorm_param_reduce, dim3(mas_cdiv(D, 32), 1), dim3(NT), 0, s, tmp, LN_SLICES, D, 1, dgamma, dbeta, 0);
     MAS_CHECK_LAUNCH("layernorm_bwd");
+    return MAS_OK;
+}
+
+extern "C" size_t mas_colsum_workspace(int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    return (size_t)CS_MAX_SLICES * cols * sizeof(float);
+}
+
+extern "C" int mas_colsum(const void* x, int dtype, int rows, int cols, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !out || !workspace) MAS_FAIL(MAS_EINVAL, "colsum: null argument");
+    if (rows <= 0 || cols <= 0) MAS_FAIL(MAS_EINVAL, "colsum: bad shape rows=%d cols=%d", rows, cols);
+    if (dtype != MAS_BF16 && dtype != MAS_F32) MAS_FAIL(MAS_EUNSUPPORTED, "colsum: dtype %d (bf16 or fp32)", dtype);
+    const int vec = dtype == MAS_BF16 ? 8 : 4;
+    if (cols % vec) MAS_FAIL(MAS_EUNSUPPORTED, "colsum: cols=%d must be a multiple of %d", cols, vec);
+    if (workspace_bytes < mas_colsum_workspace(rows, cols)) MAS_FAIL(MAS_EINVAL, "colsum: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    int nsl = colsum_slices(rows, cols, vec);
+    const int cap = (int)(workspace_bytes / ((size_t)cols * sizeof(float)));
+    if (nsl > cap) nsl = cap;
+    float* tmp = (float*)workspace;
+    if (dtype == MAS_BF16)
+        hipLaunchKernelGGL(colsum_partial<bf16_t>, dim3(mas_cdiv(cols, CS_NT * 8), nsl), dim3(CS_NT), 0, s, (const bf16_t*)x, rows, cols, nsl, tmp);
+    else
+        hipLaunchKernelGGL(colsum_partial<float>, dim3(mas_cdiv(cols, CS_NT * 4), nsl), dim3(CS_NT), 0, s, (const float*)x, rows, cols, nsl, tmp);
+    hipLaunchKernelGGL(colsum_final, dim3(mas_cdiv(cols, 32)), dim3(256), 0, s, tmp, nsl, cols, out);
+    MAS_CHECK_LAUNCH("colsum");
     return MAS_OK;
 }

@@ -699,3 +699,78 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None, out_dtype=None):
     if out_dtype not in _DT:
         raise RuntimeError(f"layer_norm: output dtype {out_dtype} not supported")
     return _LayerNorm.apply(x, weight, bias, residual, eps, out_dtype)
+
+
+# --------------------------------------------------------------------------- #
+# Linear layers of the transformer under bf16 autocast: library GEMMs + the HIP column-sum for the bias gradient
+# --------------------------------------------------------------------------- #
+def colsum(x2d: torch.Tensor) -> torch.Tensor:
+    """[rows, cols] bf16 / fp32 (contiguous) -> fp32 [cols] column sums (``mas_colsum``: fixed summation order)."""
+    _require_cuda(x2d, "colsum")
+    if x2d.dim() != 2 or not x2d.is_contiguous() or x2d.dtype not in _DT:
+        raise RuntimeError("colsum: a contiguous 2-D bf16 / fp32 matrix")
+    rows, cols = x2d.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x2d.device)
+    wsb = lib().mas_colsum_workspace(rows, cols)
+    ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=x2d.device)
+    check(lib().mas_colsum(_ptr(x2d), _DT[x2d.dtype], rows, cols, _ptr(out), _ptr(ws), wsb, _stream()), "colsum")
+    return out
+
+
+# MAS_LINEAR_FP32_DW=1: weight gradients straight from the GEMM's fp32 accumulators (torch.mm(..., out_dtype=float32): no bf16
+# rounding, no cast kernel).  Off by default: that call is outside TunableOp, so the K = 12288 weight-gradient shapes fall back to the
+# library's default solution (148 us instead of the tuned 103-125 us): 53.4 ms per MakeAScene step with it, 52.3 ms without.
+_mm_fp32_out = {"ok": None if os.environ.get("MAS_LINEAR_FP32_DW", "0") == "1" else False}
+
+
+def _mm_to_fp32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a @ b (bf16 operands) with an fp32 result: straight from the GEMM's fp32 accumulators where the library build supports an
+    fp32 output for bf16 inputs (no bf16 rounding of the weight gradient, no cast kernel), else GEMM + cast."""
+    if _mm_fp32_out["ok"] is not False:
+        try:
+            out = torch.mm(a, b, out_dtype=torch.float32)
+            _mm_fp32_out["ok"] = True
+            return out
+        except (TypeError, RuntimeError):
+            if _mm_fp32_out["ok"]:
+                raise
+            _mm_fp32_out["ok"] = False
+    return torch.mm(a, b).float()
+
+
+class _LinearBf16(torch.autograd.Function):
+    """y = x W^T + b with bf16 operands / fp32 accumulation (what ``torch.autocast(bfloat16)`` makes of nn.Linear, reference
+    models/transformer.py:31,34,125,126), as ONE autograd node: forward and the two backward products are the library GEMMs,
+    the bias gradient is ``mas_colsum`` (fp32, fixed order) instead of a generic reduction + cast; the weight gradient is the
+    GEMM's bf16 result cast to fp32 (or, ``MAS_LINEAR_FP32_DW=1``, its fp32 accumulators directly)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        with torch.autocast("cuda", enabled=False):
+            k = x.shape[-1]
+            x2 = x.reshape(-1, k)
+            x2 = x2 if x2.dtype == torch.bfloat16 else x2.to(torch.bfloat16)
+            wb = weight.detach().to(torch.bfloat16)
+            y = torch.addmm(bias.detach().to(torch.bfloat16), x2, wb.t())
+        ctx.save_for_backward(x2, wb)
+        ctx.in_shape, ctx.in_dtype = x.shape, x.dtype
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wb = ctx.saved_tensors
+        with torch.autocast("cuda", enabled=False):
+            dy2 = dy.reshape(-1, dy.shape[-1])
+            dy2 = (dy2 if dy2.dtype == torch.bfloat16 else dy2.to(torch.bfloat16)).contiguous()
+            dx = dw = db = None
+            if ctx.needs_input_grad[0]:
+                dx = torch.mm(dy2, wb).view(ctx.in_shape).to(ctx.in_dtype)
+            if ctx.needs_input_grad[1]:
+                dw = _mm_to_fp32(dy2.t(), x2)
+            if ctx.needs_input_grad[2]:
+                db = colsum(dy2)
+        return dx, dw, db
+
+
+def linear_bf16(x, weight, bias):
+    return _LinearBf16.apply(x, weight, bias)

@@ -41,15 +41,27 @@ class LayerNorm(nn.LayerNorm):
         return ops.layer_norm(x, self.weight, self.bias, self.eps, residual)
 
 
+class Linear(nn.Linear):
+    """nn.Linear parameters / state_dict keys.  Under bf16 autocast on the GPU (the mode the transformer is trained and benched
+    in) the layer is one autograd node around the library GEMMs with a fp32 weight gradient and the HIP column-sum bias gradient
+    (``ops.linear_bf16``); in every other mode it is nn.Linear."""
+
+    def forward(self, x):
+        if (x.is_cuda and self.bias is not None and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+                and self.weight.dtype == torch.float32 and self.in_features % 8 == 0 and self.out_features % 8 == 0):
+            return ops.linear_bf16(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 class SelfAttention(nn.Module):
     def __init__(self, hidden_dim, num_attn_heads, attn_dropout_prob, out_dropout_prob, cogview_pb_relax=True, rudalle_relax=False):
         super(SelfAttention, self).__init__()
         self.hidden_dim = hidden_dim
         self.num_attn_heads = num_attn_heads
         self.d = math.sqrt(self.hidden_dim // self.num_attn_heads)
-        self.qkv = nn.Linear(hidden_dim, 3 * hidden_dim)
+        self.qkv = Linear(hidden_dim, 3 * hidden_dim)
         self.attn_drop = nn.Dropout(attn_dropout_prob)
-        self.out_proj = nn.Linear(hidden_dim, hidden_dim)
+        self.out_proj = Linear(hidden_dim, hidden_dim)
         self.out_drop = nn.Dropout(out_dropout_prob)
         self.cogview_pb_relax = cogview_pb_relax
         self.rudalle_relax = rudalle_relax
@@ -107,8 +119,8 @@ class SelfAttention(nn.Module):
 class MLP(nn.Module):
     def __init__(self, hidden_dim, dropout_prob, rudalle_relax=False):
         super(MLP, self).__init__()
-        self.lin1 = nn.Linear(hidden_dim, 4 * hidden_dim)
-        self.lin2 = nn.Linear(4 * hidden_dim, hidden_dim)
+        self.lin1 = Linear(hidden_dim, 4 * hidden_dim)
+        self.lin2 = Linear(4 * hidden_dim, hidden_dim)
         self.dropout = nn.Dropout(dropout_prob)
         self.rudalle_relax = rudalle_relax
 
@@ -239,7 +251,7 @@ class MakeAScene(nn.Module):
         for m in (self.text_pos_embeddings, self.seg_row_embeddings, self.seg_col_embeddings, self.image_row_embeddings,
                   self.image_col_embeddings):
             self._init_weights(m)
-        self.to_logits = torch.nn.Sequential(LayerNorm(hidden_dim), torch.nn.Linear(hidden_dim, image_vocab_size))
+        self.to_logits = torch.nn.Sequential(LayerNorm(hidden_dim), Linear(hidden_dim, image_vocab_size))
 
     @property
     def device(self):

@@ -240,3 +240,51 @@ def test_causal_attention_full_size_properties():
     op_.backward(go)
     assert torch.equal(a.grad[:, :t], p.grad[:, :t])                      # their gradients cannot see tokens >= t either
     assert float(a.grad[:, t:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rows,cols,dtype", [(12288, 1024, torch.bfloat16), (12288, 4096, torch.bfloat16), (100, 64, torch.bfloat16),
+                                             (1537, 3072, torch.bfloat16), (7, 8, torch.bfloat16), (300, 12, torch.float32),
+                                             (4099, 1024, torch.float32)])
+def test_colsum_vs_torch(rows, cols, dtype):
+    """mas_colsum (the Linear bias gradient) against an fp64 column sum of the same (already rounded) values: fp32 accumulation in
+    a fixed order -> within 1e-6 of sum|x| per column, and bitwise identical run to run."""
+    from mas_hip import ops
+    g = torch.Generator().manual_seed(rows * 7 + cols)
+    x = (torch.randn(rows, cols, generator=g) + 0.25).to(dtype).cuda()
+    got = ops.colsum(x)
+    ref = x.double().sum(0)
+    scale = x.double().abs().sum(0)
+    assert got.dtype == torch.float32 and got.shape == (cols,)
+    assert float(((got.double() - ref).abs() / scale).max()) < 1e-6
+    assert torch.equal(got, ops.colsum(x))
+    with pytest.raises(RuntimeError):
+        ops.colsum(x.t())                                  # not contiguous
+
+
+def test_linear_bf16_node_vs_autocast_nn_linear():
+    """models.transformer.Linear under bf16 autocast (one autograd node: library GEMMs, fp32 weight gradient, HIP bias gradient)
+    against torch.nn.Linear under the same autocast: outputs and gradients within bf16 rounding of torch's (torch rounds db to
+    bf16 before the fp32 cast; ours is an fp32 sum)."""
+    from models.transformer import Linear
+    torch.manual_seed(3)
+    ours = Linear(256, 384).cuda()
+    ref = torch.nn.Linear(256, 384).cuda()
+    ref.load_state_dict(ours.state_dict())
+    x = torch.randn(3, 200, 256, device="cuda")
+    xo = x.clone().requires_grad_(True); xr = x.clone().requires_grad_(True)
+    gy = torch.randn(3, 200, 384, device="cuda")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yo = ours(xo); yr = ref(xr)
+    assert yo.dtype == torch.bfloat16 and yo.grad_fn.__class__.__name__.startswith("_LinearBf16")
+    (yo.float() * gy).sum().backward(); (yr.float() * gy).sum().backward()
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    assert rel(yo, yr) < 4e-3
+    assert rel(xo.grad, xr.grad) < 4e-3
+    assert ours.weight.grad.dtype == torch.float32 and rel(ours.weight.grad, ref.weight.grad) < 4e-3
+    assert rel(ours.bias.grad, ref.bias.grad) < 4e-3
+    # against exact fp64 products of the bf16-rounded operands: the fp32 column sum is tighter than torch's bf16 reduction
+    xb, gb = x.bfloat16().double().reshape(-1, 256), gy.bfloat16().double().reshape(-1, 384)
+    assert rel(ours.weight.grad, gb.t() @ xb) < 4e-3 and rel(ours.bias.grad, gb.sum(0)) < 1e-6
+    # outside autocast the layer is nn.Linear
+    y32 = ours(x)
+    assert y32.dtype == torch.float32 and not y32.grad_fn.__class__.__name__.startswith("_LinearBf16")
