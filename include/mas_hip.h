@@ -205,6 +205,14 @@ int mas_layernorm_bwd(const void* x, const void* dy, const float* gamma, const f
                       float* dgamma, float* dbeta, int in_dtype, int out_dtype, int rows, int D,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* mas_layernorm_bwd_add: mas_layernorm_bwd with dx = (LayerNorm input gradient) + dx_add -- dx_add [rows][D] in in_dtype is the
+ *   gradient that reached x along its skip connection (x feeds the pre-LayerNorm AND the residual of the block's sandwich
+ *   LayerNorm, reference models/transformer.py:197-210): one pass instead of the backward plus a separate add.  dx_add NULL =
+ *   mas_layernorm_bwd; dx_add may alias dx.                                                                                  */
+int mas_layernorm_bwd_add(const void* x, const void* dy, const float* gamma, const float* mean_rstd, const void* dx_add, void* dx,
+                          float* dgamma, float* dbeta, int in_dtype, int out_dtype, int rows, int D,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* mas_colsum: out[c] = sum over rows of x[r][c] (fp32 accumulation, fixed summation order: bitwise run-to-run deterministic).
  *   The bias gradient of the transformer's Linear layers (torch.nn.Linear in reference models/transformer.py:31,34,125,126:
  *   grad_bias = grad_output.sum(0)) over [B*S, N] activations.  x bf16 or fp32, row stride = cols, cols % 8 == 0 (bf16) / % 4 (fp32).

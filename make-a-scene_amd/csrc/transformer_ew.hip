@@ -174,7 +174,8 @@ __global__ __launch_bounds__(NT) void layernorm_fwd_kernel(const TI* __restrict_
 template <typename TI, typename TO>
 __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const TI* __restrict__ x, const TO* __restrict__ dy,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
-                                                           TI* __restrict__ dx, float* __restrict__ partial, int rows, int D) {
+                                                           TI* __restrict__ dx, float* __restrict__ partial, int rows, int D,
+                                                           const TI* __restrict__ dx_add) {
     constexpr int VEC = 16 / (int)sizeof(TI) < 16 / (int)sizeof(TO) ? 16 / (int)sizeof(TI) : 16 / (int)sizeof(TO);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = D / VEC;
@@ -216,6 +217,12 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const TI* __restrict_
                 float o[VEC];
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) o[e] = rstd * (g[k][e] - m1 - xh[k][e] * m2);
+                if (dx_add) {                                  // the gradient that reached x along its skip connection
+                    float sk[VEC];
+                    ld_n<TI, VEC>(dx_add + (size_t)row * D + c * VEC, sk);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) o[e] += sk[e];
+                }
                 st_n<TI, VEC>(dr + c * VEC, o);
             }
         }
@@ -392,9 +399,9 @@ extern "C" size_t mas_layernorm_bwd_workspace(int rows, int D) {
     return ((size_t)ln_blocks(rows) + LN_SLICES) * 2 * (size_t)D * sizeof(float);      // per-block partials + the stage-1 slices
 }
 
-extern "C" int mas_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, void* dx,
-                                 float* dgamma, float* dbeta, int in_dtype, int out_dtype, int rows, int D,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int mas_layernorm_bwd_add(const void* x, const void* dy, const float* gamma, const float* mean_rstd, const void* dx_add,
+                                     void* dx, float* dgamma, float* dbeta, int in_dtype, int out_dtype, int rows, int D,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
     MAS_ENTER();
     if (!x || !dy || !gamma || !mean_rstd || !dx || !dgamma || !dbeta || !workspace) MAS_FAIL(MAS_EINVAL, "layernorm_bwd: null argument");
     if (int rc = ln_check(in_dtype, out_dtype, rows, D, "layernorm_bwd")) return rc;
@@ -402,7 +409,7 @@ extern "C" int mas_layernorm_bwd(const void* x, const void* dy, const float* gam
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nblk = ln_blocks(rows);
     float* partial = reinterpret_cast<float*>(workspace);
-#define MAS_LN_BWD(TI, TO) hipLaunchKernelGGL((layernorm_bwd_kernel<TI, TO>), dim3(nblk), dim3(NT), 0, s, (const TI*)x, (const TO*)dy, gamma, mean_rstd, (TI*)dx, partial, rows, D)
+#define MAS_LN_BWD(TI, TO) hipLaunchKernelGGL((layernorm_bwd_kernel<TI, TO>), dim3(nblk), dim3(NT), 0, s, (const TI*)x, (const TO*)dy, gamma, mean_rstd, (TI*)dx, partial, rows, D, (const TI*)dx_add)
     if (in_dtype == MAS_BF16 && out_dtype == MAS_BF16) MAS_LN_BWD(bf16_t, bf16_t);
     else if (in_dtype == MAS_BF16) MAS_LN_BWD(bf16_t, float);
     else if (out_dtype == MAS_BF16) MAS_LN_BWD(float, bf16_t);
@@ -413,6 +420,12 @@ extern "C" int mas_layernorm_bwd(const void* x, const void* dy, const float* gam
     hipLaunchKernelGGL(layernorm_param_reduce, dim3(mas_cdiv(D, 32), 1), dim3(NT), 0, s, tmp, LN_SLICES, D, 1, dgamma, dbeta, 0);
     MAS_CHECK_LAUNCH("layernorm_bwd");
     return MAS_OK;
+}
+
+extern "C" int mas_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, void* dx,
+                                 float* dgamma, float* dbeta, int in_dtype, int out_dtype, int rows, int D,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    return mas_layernorm_bwd_add(x, dy, gamma, mean_rstd, nullptr, dx, dgamma, dbeta, in_dtype, out_dtype, rows, D, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t mas_colsum_workspace(int rows, int cols) {

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "mas_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "mas_layernorm_bwd_workspace": (_sz, [_i, _i]),
     "mas_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "mas_layernorm_bwd_add": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "mas_colsum_workspace": (_sz, [_i, _i]),
     "mas_colsum": (_i, [_p, _i, _i, _i, _p, _p, _sz, _p]),
 }

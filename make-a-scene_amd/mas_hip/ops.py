@@ -672,18 +672,55 @@ class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight, mr = ctx.saved_tensors
+        dx, dg, db = _layer_norm_bwd(x, weight, mr, dy.to(ctx.out_dtype).contiguous(), ctx.out_dtype, None)
+        return dx, dg, db, (dy.to(ctx.out_dtype) if ctx.has_res else None), None, None
+
+
+def _layer_norm_bwd(x, weight, mr, dy, out_dtype, dx_add):
+    d = x.shape[-1]
+    rows = x.numel() // d
+    dx = torch.empty_like(x)
+    dg = torch.empty(d, dtype=torch.float32, device=x.device)
+    db = torch.empty(d, dtype=torch.float32, device=x.device)
+    wsb = lib().mas_layernorm_bwd_workspace(rows, d)
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
+    w32 = weight.detach().float().contiguous()
+    check(lib().mas_layernorm_bwd_add(_ptr(x), _ptr(dy), _ptr(w32), _ptr(mr), _ptr(dx_add), _ptr(dx), _ptr(dg), _ptr(db), _DT[x.dtype],
+                                      _DT[out_dtype], rows, d, _ptr(ws), wsb, _stream()), "layernorm_bwd")
+    return dx, dg.to(weight.dtype), db.to(weight.dtype)
+
+
+class _LayerNormFork(torch.autograd.Function):
+    """(LayerNorm(x), x): the pre-LayerNorm of a transformer block together with the skip connection that leaves the same tensor
+    (reference models/transformer.py:197-210: ``x`` feeds ``ln_in`` AND the residual of the sandwich LayerNorm).  As one node the
+    two gradients that come back to x are added inside the LayerNorm backward kernel (``mas_layernorm_bwd_add``) instead of by a
+    separate elementwise pass of the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        _require_cuda(x, "layer_norm")
+        _check_dtype(x, "layer_norm")
         d = x.shape[-1]
         rows = x.numel() // d
-        dy = dy.to(ctx.out_dtype).contiguous()
-        dx = torch.empty_like(x)
-        dg = torch.empty(d, dtype=torch.float32, device=x.device)
-        db = torch.empty(d, dtype=torch.float32, device=x.device)
-        wsb = lib().mas_layernorm_bwd_workspace(rows, d)
-        ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
-        w32 = weight.detach().float().contiguous()
-        check(lib().mas_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(w32), _ptr(mr), _ptr(dx), _ptr(dg), _ptr(db), _DT[x.dtype],
-                                      _DT[ctx.out_dtype], rows, d, _ptr(ws), wsb, _stream()), "layernorm_bwd")
-        return dx, dg.to(weight.dtype), db.to(weight.dtype), (dy if ctx.has_res else None), None, None
+        x = x.contiguous()
+        y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+        mr = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        check(lib().mas_layernorm_fwd(_ptr(x), _ptr(w32), _ptr(b32), None, _ptr(y), _ptr(mr), _DT[x.dtype], _DT[out_dtype], rows, d,
+                                      float(eps), _stream()), "layernorm_fwd")
+        ctx.save_for_backward(x, weight, mr)
+        ctx.out_dtype = out_dtype
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, weight, mr = ctx.saved_tensors
+        if dy is None:                                     # only the skip connection was used
+            return dskip, None, None, None, None
+        if dskip is not None:
+            dskip = dskip.to(x.dtype).contiguous()
+        dx, dg, db = _layer_norm_bwd(x, weight, mr, dy.to(ctx.out_dtype).contiguous(), ctx.out_dtype, dskip)
+        return dx, dg, db, None, None
 
 
 def layer_norm(x, weight, bias, eps=1e-5, residual=None, out_dtype=None):
@@ -699,6 +736,15 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None, out_dtype=None):
     if out_dtype not in _DT:
         raise RuntimeError(f"layer_norm: output dtype {out_dtype} not supported")
     return _LayerNorm.apply(x, weight, bias, residual, eps, out_dtype)
+
+
+def layer_norm_fork(x, weight, bias, eps=1e-5, out_dtype=None):
+    """-> (LayerNorm(x), x): use the second output wherever the block adds x back (see ``_LayerNormFork``)."""
+    if out_dtype is None:
+        out_dtype = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else x.dtype
+    if out_dtype not in _DT:
+        raise RuntimeError(f"layer_norm: output dtype {out_dtype} not supported")
+    return _LayerNormFork.apply(x, weight, bias, eps, out_dtype)
 
 
 # --------------------------------------------------------------------------- #

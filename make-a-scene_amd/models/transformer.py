@@ -18,6 +18,7 @@ axis -2, computes only the new positions and returns full-length outputs -- and 
 cache can have: the logits of cached decoding equal those of the uncached forward (tests/test_gpu_sampling.py, and through
 it the reference's golden logits)."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -31,6 +32,9 @@ def gelu(x):
     return ops.gelu_tanh(x)
 
 
+_LN_FORK = os.environ.get("MAS_LN_FORK", "1") == "1"      # A/B switch: pre-LayerNorm + skip connection as one autograd node
+
+
 class LayerNorm(nn.LayerNorm):
     """nn.LayerNorm parameters / state_dict keys, HIP forward + backward; ``residual`` fuses the ``x + LN(.)`` of the
     sandwich LayerNorms (reference transformer.py:201-203,207-209)."""
@@ -39,6 +43,13 @@ class LayerNorm(nn.LayerNorm):
         if not self.elementwise_affine or len(self.normalized_shape) != 1:
             raise NotImplementedError("libmas_hip LayerNorm: affine, over the last dimension")
         return ops.layer_norm(x, self.weight, self.bias, self.eps, residual)
+
+    def fork(self, x):
+        """-> (LN(x), x): the normalised tensor and the skip connection as outputs of ONE autograd node (their gradients are added
+        inside the LayerNorm backward kernel)."""
+        if not self.elementwise_affine or len(self.normalized_shape) != 1:
+            raise NotImplementedError("libmas_hip LayerNorm: affine, over the last dimension")
+        return ops.layer_norm_fork(x, self.weight, self.bias, self.eps)
 
 
 class Linear(nn.Linear):
@@ -153,15 +164,18 @@ class TransformerLayer(nn.Module):
     def forward(self, x, mask, cache=None, use_cache=False, mlp_cache=False):
         if use_cache:
             return self._forward_cached(x, cache)
-        attn_out, new_cache = self.attn(self.ln_in(self._prescale(x)), mask, False, cache)
+        fork = _LN_FORK and not self.cogview_layernorm_prescale      # (the prescale variant divides x before the LayerNorm: plain path)
+        ln, skip = self.ln_in.fork(x) if fork else (self.ln_in(self._prescale(x)), x)
+        attn_out, new_cache = self.attn(ln, mask, False, cache)
         if self.cogview_sandwich_layernorm:
-            x = self.first_ln_sandwich(self._prescale(attn_out), residual=x)        # x + LN(attn_out), one pass
+            x = self.first_ln_sandwich(self._prescale(attn_out), residual=skip)     # x + LN(attn_out), one pass
         else:
-            x = x + attn_out
-        mlp_out = self.mlp(self.ln_out(self._prescale(x)))
+            x = skip + attn_out
+        ln, skip = self.ln_out.fork(x) if fork else (self.ln_out(self._prescale(x)), x)
+        mlp_out = self.mlp(ln)
         if self.cogview_sandwich_layernorm:
-            return self.second_ln_sandwich(mlp_out, residual=x), new_cache
-        return x + mlp_out, new_cache
+            return self.second_ln_sandwich(mlp_out, residual=skip), new_cache
+        return skip + mlp_out, new_cache
 
     def _forward_cached(self, x, cache):
         """Full sequence in, full sequence out, only the positions past the cache computed (reference transformer.py:170-210

@@ -288,3 +288,39 @@ def test_linear_bf16_node_vs_autocast_nn_linear():
     # outside autocast the layer is nn.Linear
     y32 = ours(x)
     assert y32.dtype == torch.float32 and not y32.grad_fn.__class__.__name__.startswith("_LinearBf16")
+
+
+@pytest.mark.parametrize("in_dtype,out_dtype", [(torch.float32, torch.bfloat16), (torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16)])
+def test_layer_norm_fork_adds_the_skip_gradient_in_kernel(in_dtype, out_dtype):
+    """ops.layer_norm_fork -> (LN(x), x) as one node (mas_layernorm_bwd_add): values and all gradients equal torch's LayerNorm plus
+    a separate skip connection, for every dtype pair the transformer uses; an unused output is handled."""
+    from mas_hip import ops
+    torch.manual_seed(5)
+    d = 256
+    x = torch.randn(4, 37, d, device="cuda").to(in_dtype)
+    w = (1 + 0.1 * torch.randn(d, device="cuda")).requires_grad_(True)
+    b = (0.1 * torch.randn(d, device="cuda")).requires_grad_(True)
+    ga = torch.randn(4, 37, d, device="cuda"); gs = torch.randn(4, 37, d, device="cuda")
+    xo = x.clone().requires_grad_(True)
+    y, skip = ops.layer_norm_fork(xo, w, b, 1e-5, out_dtype)
+    assert y.dtype == out_dtype and skip.dtype == in_dtype and torch.equal(skip, xo)
+    ((y.float() * ga).sum() + (skip.float() * gs).sum()).backward()
+    xr = x.float().clone().requires_grad_(True); wr = w.detach().clone().requires_grad_(True); br = b.detach().clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (d,), wr, br, 1e-5)
+    ga_r = ga.to(out_dtype).float() if out_dtype != torch.float32 else ga          # the kernel sees dy in out_dtype
+    gs_r = gs.to(in_dtype).float()
+    ((yr * ga_r).sum() + (xr * gs_r).sum()).backward()
+    rel = lambda a, c: float((a.double() - c.double()).norm() / c.double().norm())
+    tol = 1e-5 if in_dtype == torch.float32 and out_dtype == torch.float32 else 1e-2
+    assert rel(y, yr) < tol and rel(xo.grad, xr.grad) < tol and rel(w.grad, wr.grad) < tol and rel(b.grad, br.grad) < tol
+    # only one of the two outputs used
+    xo2 = x.clone().requires_grad_(True)
+    y2, s2 = ops.layer_norm_fork(xo2, w, b, 1e-5, out_dtype)
+    (s2.float() * gs).sum().backward()
+    assert rel(xo2.grad, gs_r) < 1e-6
+    xo3 = x.clone().requires_grad_(True)
+    y3, _ = ops.layer_norm_fork(xo3, w, b, 1e-5, out_dtype)
+    (y3.float() * ga).sum().backward()
+    xr3 = x.float().clone().requires_grad_(True)
+    (torch.nn.functional.layer_norm(xr3, (d,), w.detach(), b.detach(), 1e-5) * ga_r).sum().backward()
+    assert rel(xo3.grad, xr3.grad) < tol

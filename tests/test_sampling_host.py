@@ -1,5 +1,5 @@
 """Host logic of the KV-cached sampling path on CPU: the cache bookkeeping of SelfAttention /
-TransformerLayer / Transformer / MakeAScene.generate, with the four HIP operators they call replaced by torch-CPU stand-ins
+TransformerLayer / Transformer / MakeAScene.generate, with the HIP operators they call replaced by torch-CPU stand-ins
 (TEST ONLY -- the product path has no CPU fallback; the real kernels run in tests/test_gpu_sampling.py).  Pins the only
 behaviour a cache can have: teacher-forced cached decoding reproduces the logits of the uncached forward, which
 tests/test_oracle_golden.py / test_gpu_transformer.py pin to the reference's golden logits."""
@@ -48,6 +48,7 @@ def _cpu_ops(monkeypatch):
     monkeypatch.setattr(ops, "causal_attention", causal_attention)
     monkeypatch.setattr(ops, "attention_decode", attention_decode)
     monkeypatch.setattr(ops, "layer_norm", layer_norm)
+    monkeypatch.setattr(ops, "layer_norm_fork", lambda x, w, b_, eps=1e-5, out_dtype=None: (layer_norm(x, w, b_, eps), x))
     monkeypatch.setattr(ops, "gelu_tanh", gelu)
 
 
