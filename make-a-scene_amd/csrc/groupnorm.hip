@@ -276,25 +276,23 @@ __global__ __launch_bounds__(NT) void gn_bwd_finalize(const float* __restrict__ 
     }
 }
 
-// sum nsum over n -> dgamma, dbeta
-__global__ __launch_bounds__(NT) void gn_bwd_param_reduce(const float* __restrict__ nsum, int N, int C,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * NT + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int n = 0; n < N; ++n) { a += (double)nsum[((size_t)n * C + c) * 2 + 0]; b += (double)nsum[((size_t)n * C + c) * 2 + 1]; }
-    if (dgamma) dgamma[c] = (float)a;
-    if (dbeta) dbeta[c] = (float)b;
-}
-
 // backward stage 3: elementwise dx = c1*du + k2*x + k3 (+ dres)
 template <typename T>
 __global__ __launch_bounds__(NT) void gn_bwd_apply(const T* __restrict__ x, const T* __restrict__ da, const T* __restrict__ dres,
                                                    T* __restrict__ dx, int HW, int C, int act, const float* __restrict__ ss,
-                                                   const float* __restrict__ coef, long long units_per_n) {
+                                                   const float* __restrict__ coef, long long units_per_n,
+                                                   const float* __restrict__ nsum, int N, float* __restrict__ dgamma, float* __restrict__ dbeta) {
     constexpr int EPU = 16 / (int)sizeof(T);
     const int upp = C / EPU;
     const int n = blockIdx.y;
+    if (blockIdx.y == 0 && (dgamma || dbeta)) {     // dgamma / dbeta = sum over n of nsum (the former gn_bwd_param_reduce launch: 9 us of
+        for (int c = blockIdx.x * NT + threadIdx.x; c < C; c += gridDim.x * NT) {        // dependent launch latency per GroupNorm)
+            double a = 0.0, b = 0.0;
+            for (int m = 0; m < N; ++m) { a += (double)nsum[((size_t)m * C + c) * 2 + 0]; b += (double)nsum[((size_t)m * C + c) * 2 + 1]; }
+            if (dgamma) dgamma[c] = (float)a;
+            if (dbeta) dbeta[c] = (float)b;
+        }
+    }
     const size_t base = (size_t)n * HW * C;
     // NT % upp == 0 (checked by the host): the channel unit of a thread is loop invariant, so the five
     // per-channel coefficients live in registers and the loop is a pure 3-stream pass
@@ -426,19 +424,15 @@ extern "C" int mas_gn_bwd(const void* x, const void* da, const void* dres, int d
     MAS_CHECK_LAUNCH("gn_bwd_partial");
     hipLaunchKernelGGL(gn_bwd_finalize, dim3(N), dim3(NT), (size_t)2 * C * sizeof(double), s, partial, HW, C, G, nsplit, gamma, mean_rstd, coef, nsum);
     MAS_CHECK_LAUNCH("gn_bwd_finalize");
-    if (dgamma || dbeta) {
-        hipLaunchKernelGGL(gn_bwd_param_reduce, dim3(mas_cdiv(C, NT)), dim3(NT), 0, s, nsum, N, C, dgamma, dbeta);
-        MAS_CHECK_LAUNCH("gn_bwd_param_reduce");
-    }
     const long long units_per_n = (long long)HW * C / epu;
     int gx = (int)((units_per_n + NT - 1) / NT);
     const int cap = mas_cdiv(2048, N) > 0 ? mas_cdiv(2048, N) : 1;
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     if (dtype == MAS_BF16)
-        hipLaunchKernelGGL(gn_bwd_apply<bf16_t>, dim3(gx, N), dim3(NT), 0, s, (const bf16_t*)x, (const bf16_t*)da, (const bf16_t*)dres, (bf16_t*)dx, HW, C, act, scale_shift, coef, units_per_n);
+        hipLaunchKernelGGL(gn_bwd_apply<bf16_t>, dim3(gx, N), dim3(NT), 0, s, (const bf16_t*)x, (const bf16_t*)da, (const bf16_t*)dres, (bf16_t*)dx, HW, C, act, scale_shift, coef, units_per_n, nsum, N, dgamma, dbeta);
     else
-        hipLaunchKernelGGL(gn_bwd_apply<float>, dim3(gx, N), dim3(NT), 0, s, (const float*)x, (const float*)da, (const float*)dres, (float*)dx, HW, C, act, scale_shift, coef, units_per_n);
+        hipLaunchKernelGGL(gn_bwd_apply<float>, dim3(gx, N), dim3(NT), 0, s, (const float*)x, (const float*)da, (const float*)dres, (float*)dx, HW, C, act, scale_shift, coef, units_per_n, nsum, N, dgamma, dbeta);
     MAS_CHECK_LAUNCH("gn_bwd_apply");
     return MAS_OK;
 }

@@ -1,0 +1,8 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+cd $R
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py tests/test_gpu_parity_r2.py -m gpu -q --timeout 600 2>&1 | tail -3
+J='import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], j["ms_per_step"])'
+for rep in 1 2; do timeout 600 python bench.py --no-cpu-baseline 2> /dev/null | python -c "$J"; done
+timeout 100 python tools/kbench.py gn_bwd --n 32 --c 128 --hw 256 | grep "^gn_bwd"
+timeout 100 python tools/kbench.py gn_bwd --n 32 --c 512 --hw 16 | grep "^gn_bwd"
