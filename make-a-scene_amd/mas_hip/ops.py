@@ -3,7 +3,7 @@
 Activations are torch tensors of LOGICAL shape [N,C,H,W] in ``channels_last`` memory
 format (== the NHWC buffers the kernels expect), dtype bf16 or fp32.  Parameters stay
 ordinary fp32 OIHW ``nn.Parameter``s (state_dict compatible with the reference); the
-bf16 / NHWC-packed copies are a cache keyed on ``Parameter._version``.
+bf16 / NHWC-packed copies are a cache keyed on the parameter's stamp (in-place version, storage, optimizer steps: ``_param_stamp``).
 """
 from __future__ import annotations
 
@@ -68,10 +68,41 @@ def _empty_nhwc(n, c, h, w, dtype, device):
 # --------------------------------------------------------------------------- #
 # packed-weight cache
 # --------------------------------------------------------------------------- #
+# Validity of every derived copy of a parameter (packed conv weights, bf16 Linear shadows): ``(Parameter._version, data_ptr,
+# optimizer generation)``.  ``_version`` alone is NOT enough: the fused optimizers (``torch.optim.Adam(fused=True)`` and friends)
+# update parameters through a multi-tensor kernel that does not bump it (measured on this torch build: version 0 -> 0 with the
+# data changed), so a process-wide optimizer post-step hook counts, per parameter, the optimizer steps that touched it.
+_param_generation = {}
+
+
+def _note_optimizer_step(optimizer, *_args, **_kwargs):
+    for group in optimizer.param_groups:
+        for p in group["params"]:
+            _param_generation[id(p)] = _param_generation.get(id(p), 0) + 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _register_post_hook
+    _register_post_hook(_note_optimizer_step)
+except ImportError:                                   # older torch: fall back to wrapping Optimizer.step once
+    _orig_opt_step = torch.optim.Optimizer.step
+
+    def _step_and_note(self, *a, **k):
+        out = _orig_opt_step(self, *a, **k)
+        _note_optimizer_step(self)
+        return out
+
+    torch.optim.Optimizer.step = _step_and_note
+
+
+def _param_stamp(p: torch.Tensor):
+    return (p._version, p.data_ptr(), _param_generation.get(id(p), 0))
+
+
 class _PackCache:
-    """bf16/NHWC-packed copies of conv parameters, valid while ``Parameter._version`` is unchanged
-    (the optimizer's in-place update bumps it).  Only ``nn.Parameter`` objects are cached (held by
-    weak reference); temporaries (e.g. the concatenated q|k|v weight) are packed on every call."""
+    """bf16/NHWC-packed copies of conv parameters, valid while the parameter's stamp (``_param_stamp``: in-place version, storage,
+    optimizer steps) is unchanged.  Only ``nn.Parameter`` objects are cached (held by weak reference); temporaries (e.g. the
+    concatenated q|k|v weight) are packed on every call."""
 
     def __init__(self):
         self.store = {}
@@ -83,7 +114,7 @@ class _PackCache:
         if not isinstance(w, torch.nn.Parameter):
             return pack_conv_weight(w.detach(), transpose, dtype, layout)
         key = (id(w), transpose, dtype, layout)
-        ver = (w._version, w.data_ptr())
+        ver = _param_stamp(w)
         hit = self.store.get(key)
         if hit is not None and hit[0]() is w and hit[1] == ver:
             return hit[2]
@@ -96,10 +127,11 @@ _pack_cache = _PackCache()
 
 
 def invalidate_weight_cache() -> None:
-    """Drops every cached packed weight.  The cache is validated by ``(Parameter._version, data_ptr)``, which an in-place
-    write THROUGH ``.data`` (``w.data.copy_(ema)``, ``w.data.normal_()``, weight clipping) does not change: call this after
+    """Drops every cached packed weight / bf16 shadow.  The caches are validated by ``_param_stamp`` (``Parameter._version``,
+    ``data_ptr``, optimizer steps seen by the global post-step hook), which an in-place write THROUGH ``.data`` (``w.data.copy_(ema)``, ``w.data.normal_()``, weight clipping) does not change: call this after
     such a write.  ``models.modules.Conv2d`` calls it from ``load_state_dict`` and on every train()/eval() switch."""
     _pack_cache.clear()
+    _bf16_shadows.clear()
 
 
 def pack_conv_weight(w: torch.Tensor, transpose: bool, dtype: torch.dtype, layout: int = WLAYOUT_K64) -> torch.Tensor:
@@ -784,6 +816,47 @@ def _mm_to_fp32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return torch.mm(a, b).float()
 
 
+class _Bf16Shadows:
+    """bf16 copies of the fp32 parameters of every registered Linear layer, refreshed TOGETHER: the first layer that finds its copy
+    stale (an optimizer step or an in-place write changed its stamp) recasts every stale parameter in one multi-tensor launch
+    (``torch._foreach_copy_``) instead of ~200 small cast kernels per step; between optimizer steps (gradient accumulation over
+    micro-batches) nothing is recast at all.  Same validity rule as the packed conv weights: writes through ``.data`` need
+    ``invalidate_weight_cache()``."""
+
+    def __init__(self):
+        self.params = {}                             # id -> (weakref, [version, data_ptr], bf16 copy)
+
+    def clear(self):
+        self.params.clear()
+
+    def register(self, p: torch.nn.Parameter):
+        k = id(p)
+        if k not in self.params:
+            self.params[k] = [weakref.ref(p, lambda _r, k=k: self.params.pop(k, None)), None, None]
+
+    def get(self, p: torch.nn.Parameter) -> torch.Tensor:
+        self.register(p)
+        ent = self.params[id(p)]
+        if ent[1] == _param_stamp(p) and ent[2] is not None and ent[2].device == p.device:
+            return ent[2]
+        srcs, dsts = [], []
+        for e in list(self.params.values()):
+            q = e[0]()
+            if q is None or not q.is_cuda or q.device != p.device or q.dtype != torch.float32:
+                continue
+            if e[1] != _param_stamp(q) or e[2] is None or e[2].device != q.device:
+                if e[2] is None or e[2].shape != q.shape or e[2].device != q.device:
+                    e[2] = torch.empty(q.shape, dtype=torch.bfloat16, device=q.device)
+                e[1] = _param_stamp(q)
+                srcs.append(q.detach()); dsts.append(e[2])
+        if dsts:
+            torch._foreach_copy_(dsts, srcs)
+        return ent[2]
+
+
+_bf16_shadows = _Bf16Shadows()
+
+
 class _LinearBf16(torch.autograd.Function):
     """y = x W^T + b with bf16 operands / fp32 accumulation (what ``torch.autocast(bfloat16)`` makes of nn.Linear, reference
     models/transformer.py:31,34,125,126), as ONE autograd node: forward and the two backward products are the library GEMMs,
@@ -796,8 +869,11 @@ class _LinearBf16(torch.autograd.Function):
             k = x.shape[-1]
             x2 = x.reshape(-1, k)
             x2 = x2 if x2.dtype == torch.bfloat16 else x2.to(torch.bfloat16)
-            wb = weight.detach().to(torch.bfloat16)
-            y = torch.addmm(bias.detach().to(torch.bfloat16), x2, wb.t())
+            if isinstance(weight, torch.nn.Parameter) and isinstance(bias, torch.nn.Parameter) and weight.dtype == torch.float32:
+                wb, bb = _bf16_shadows.get(weight), _bf16_shadows.get(bias)
+            else:
+                wb, bb = weight.detach().to(torch.bfloat16), bias.detach().to(torch.bfloat16)
+            y = torch.addmm(bb, x2, wb.t())
         ctx.save_for_backward(x2, wb)
         ctx.in_shape, ctx.in_dtype = x.shape, x.dtype
         return y.view(*x.shape[:-1], weight.shape[0])

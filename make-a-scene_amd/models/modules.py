@@ -56,7 +56,8 @@ class Conv2d(nn.Conv2d):
         ph, pw = self.padding
         return (ph, ph, pw, pw)
 
-    # The packed bf16/NHWC weight images are cached on (Parameter._version, data_ptr); writes THROUGH ``.data`` change
+    # The packed bf16/NHWC weight images are cached on ops._param_stamp (Parameter._version, data_ptr, optimizer steps -- fused
+    # optimizers do not bump _version, a global optimizer post-step hook covers them); writes THROUGH ``.data`` change
     # neither.  The two places such writes normally surround -- loading a checkpoint and switching train()/eval() (EMA
     # swap-in) -- drop the cache; any other ``.data`` write needs ``mas_hip.ops.invalidate_weight_cache()``.
     def _load_from_state_dict(self, *args, **kwargs):

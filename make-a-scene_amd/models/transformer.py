@@ -57,6 +57,16 @@ class Linear(nn.Linear):
     in) the layer is one autograd node around the library GEMMs with a fp32 weight gradient and the HIP column-sum bias gradient
     (``ops.linear_bf16``); in every other mode it is nn.Linear."""
 
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.bias is not None:
+            ops._bf16_shadows.register(self.weight)
+            ops._bf16_shadows.register(self.bias)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        ops.invalidate_weight_cache()
+
     def forward(self, x):
         if (x.is_cuda and self.bias is not None and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
                 and self.weight.dtype == torch.float32 and self.in_features % 8 == 0 and self.out_features % 8 == 0):

@@ -91,3 +91,16 @@ def test_no_cpu_fallback():
     m = VQBASE(**cfg)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.rand(1, 3, 16, 16))
+
+
+def test_optimizer_steps_are_part_of_the_parameter_stamp():
+    """fused optimizers do not bump Parameter._version; the stamp that validates packed weights / bf16 shadows also counts optimizer
+    steps through a process-wide post-step hook (CPU-checkable half of tests/test_gpu_parity_r2.py's fused-Adam test)."""
+    import torch
+    from mas_hip import ops
+    p, q = torch.nn.Parameter(torch.randn(3, 3)), torch.nn.Parameter(torch.randn(3))
+    p.grad, q.grad = torch.randn(3, 3), torch.randn(3)
+    opt = torch.optim.SGD([p], lr=0.1)
+    sp, sq = ops._param_stamp(p), ops._param_stamp(q)
+    opt.step()
+    assert ops._param_stamp(p)[2] == sp[2] + 1 and ops._param_stamp(q) == sq        # only the optimizer's own parameters are marked

@@ -294,3 +294,36 @@ def test_weight_cache_invalidation():
     with torch.no_grad():
         conv.weight.add_(1.0)                           # ordinary in-place update (what an optimizer does): version bump
     assert relerr(conv(x), F.conv2d(x.cpu(), new_w.cpu() + 1.0, conv.bias.detach().cpu(), padding=1)) < 2e-4
+
+
+@pytest.mark.parametrize("opt_kw", [dict(fused=True), dict(foreach=True), dict(foreach=False, fused=False)])
+def test_packed_weights_follow_every_optimizer_flavour(opt_kw):
+    """torch.optim.Adam(fused=True) updates parameters WITHOUT bumping Parameter._version (measured); the packed-weight cache and the
+    bf16 Linear shadows must still refresh after its step (global optimizer post-step hook): the convolution and the Linear layer after
+    one step equal torch's on the UPDATED fp32 parameters, and differ from the outputs before the step."""
+    import torch.nn.functional as F
+    from mas_hip import ops
+    from models.modules import Conv2d
+    from models.transformer import Linear
+    ops.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(11)
+    conv = Conv2d(64, 128, 3, 1, 1).cuda()
+    lin = Linear(64, 64).cuda()
+    x = torch.randn(2, 64, 32, 32, device="cuda")
+    xl = torch.randn(7, 64, device="cuda")
+    opt = torch.optim.Adam(list(conv.parameters()) + list(lin.parameters()), lr=0.05, **opt_kw)
+
+    def outs():
+        y = conv(x)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            z = lin(xl)
+        return y, z
+    y0, z0 = outs()
+    (y0.float().square().mean() + z0.float().square().mean()).backward()
+    opt.step(); opt.zero_grad(set_to_none=True)
+    y1, z1 = outs()
+    ref_y = F.conv2d(x.bfloat16().float(), conv.weight.detach().bfloat16().float(), conv.bias.detach(), padding=1)
+    ref_z = F.linear(xl.bfloat16().float(), lin.weight.detach().bfloat16().float(), lin.bias.detach().bfloat16().float())
+    rel = lambda a, b: float((a.float() - b).norm() / b.norm())
+    assert rel(y1, ref_y) < 1e-2 and rel(z1, ref_z) < 1e-2, (rel(y1, ref_y), rel(z1, ref_z))
+    assert rel(y0, ref_y) > 5e-2 and rel(z0, ref_z) > 5e-2              # the step really moved the outputs

@@ -324,3 +324,33 @@ def test_layer_norm_fork_adds_the_skip_gradient_in_kernel(in_dtype, out_dtype):
     xr3 = x.float().clone().requires_grad_(True)
     (torch.nn.functional.layer_norm(xr3, (d,), w.detach(), b.detach(), 1e-5) * ga_r).sum().backward()
     assert rel(xo3.grad, xr3.grad) < tol
+
+
+def test_linear_bf16_shadow_weights_follow_the_optimizer():
+    """The bf16 copies of the Linear parameters are refreshed together when an optimizer step (or any in-place write that bumps
+    ``_version``) made them stale, reused between steps, and dropped by invalidate_weight_cache()."""
+    from mas_hip import ops
+    from models.transformer import Linear
+    torch.manual_seed(9)
+    a, b = Linear(64, 64).cuda(), Linear(64, 128).cuda()
+    x = torch.randn(5, 64, device="cuda")
+    opt = torch.optim.SGD(list(a.parameters()) + list(b.parameters()), lr=0.5)
+    def run():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return b(a(x)).float()
+    y0 = run()
+    sa = ops._bf16_shadows.get(a.weight)
+    assert torch.equal(sa, a.weight.detach().bfloat16()) and ops._bf16_shadows.get(a.weight) is sa      # reused while the version stands
+    y0.square().mean().backward()
+    opt.step()
+    y1 = run()
+    assert not torch.equal(y0, y1)
+    for lin in (a, b):
+        assert torch.equal(ops._bf16_shadows.get(lin.weight), lin.weight.detach().bfloat16())
+        assert torch.equal(ops._bf16_shadows.get(lin.bias), lin.bias.detach().bfloat16())
+    ref = torch.nn.functional.linear(torch.nn.functional.linear(x.bfloat16(), a.weight.bfloat16(), a.bias.bfloat16()), b.weight.bfloat16(), b.bias.bfloat16())
+    assert float((y1 - ref.float()).abs().max()) < 2e-2 * float(ref.float().abs().max())
+    with torch.no_grad():
+        a.weight.data.mul_(2.0)                      # a write through .data: invisible to the version check
+    ops.invalidate_weight_cache()
+    assert torch.equal(ops._bf16_shadows.get(a.weight), a.weight.detach().bfloat16())
