@@ -77,6 +77,17 @@ int    mas_conv_weight_layout(const MasConvDesc* d);
 int    mas_pack_conv_weight_layout(const float* w_oihw, void* packed, int Cout, int Cin, int ks,
                                    int transpose, int dtype, int layout, void* stream);
 
+/* Batched packing: every item of a device-resident table in ONE launch (a training step repacks ~160 weight images after the
+ * optimizer step; one launch instead of 160 dependent 8-us launches).  The table is built by the caller: item i covers work-groups
+ * [first_block, first_block + n_blocks) of the grid, n_blocks = mas_pack_batch_blocks(...) for its shape, items in ascending
+ * first_block order, total_blocks = their sum.  Same images as mas_pack_conv_weight_layout (K32: bf16 3x3 only).               */
+typedef struct MasPackItem {
+    const float* w_oihw; void* packed;
+    int Cout, Cin, ks, transpose, dtype, layout, first_block, n_blocks;
+} MasPackItem;
+int    mas_pack_batch_blocks(int Cout, int Cin, int ks, int transpose, int dtype, int layout);
+int    mas_pack_conv_weight_batch(const MasPackItem* items_device, int n_items, int total_blocks, void* stream);
+
 /* ---- GroupNorm statistics (replaces the reduction half of torch.nn.GroupNorm,
  * modules.py:40-41).  x: [N,HW,C] NHWC.  Outputs:
  *   mean_rstd [N][G][2] fp32, scale_shift [N][C][2] fp32 with

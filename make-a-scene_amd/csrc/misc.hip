@@ -36,12 +36,12 @@ constexpr int NT = 256;
 // holds CK = 128/sizeof(T) consecutive K elements as eight 16-byte slots and slot position sp stores logical
 // slot sp ^ ((row>>1)&7) (the bank-conflict swizzle of conv_fwd.hip).  See mas_hip.h for the two modes.
 template <typename T>
-__global__ __launch_bounds__(NT) void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin,
-                                                         int ks, int transpose, int rows_pad, int n_chunks) {
+__device__ __forceinline__ void pack_weight_body(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int ks, int transpose,
+                                                 int rows_pad, int n_chunks, long long first, long long stride) {
     constexpr int EPU = 16 / (int)sizeof(T), CK = 128 / (int)sizeof(T);
     const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
     const long long total = (long long)ks * ks * n_chunks * rows_pad * CK;
-    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+    for (long long i = first; i < total; i += stride) {
         const int pos = (int)(i % CK);
         const int row = (int)((i / CK) % rows_pad);
         const int t = (int)((i / ((long long)CK * rows_pad)) % (ks * ks));
@@ -58,15 +58,20 @@ __global__ __launch_bounds__(NT) void pack_weight_kernel(const float* __restrict
         out[i] = (T)v;
     }
 }
+template <typename T>
+__global__ __launch_bounds__(NT) void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin,
+                                                         int ks, int transpose, int rows_pad, int n_chunks) {
+    pack_weight_body<T>(w, out, Cout, Cin, ks, transpose, rows_pad, n_chunks, (long long)blockIdx.x * NT + threadIdx.x, (long long)gridDim.x * NT);
+}
 
 // MAS_WLAYOUT_K32 (bf16): [chunk32][tap][row][64 B]; slot position sp stores logical slot sp ^ ((row>>2)&3); inside every
 // 128-row tile the rows are PERMUTED: LDS row 32 i + l holds filter row 4 l + i (conv3x3_wide.hip: a lane then owns 4 consecutive
 // output channels, one per accumulator tile, and stores them with one 8-byte store)
-__global__ __launch_bounds__(NT) void pack_weight_k32_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin,
-                                                             int ks, int transpose, int rows_pad, int n_chunks) {
+__device__ __forceinline__ void pack_weight_k32_body(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int ks, int transpose,
+                                                     int rows_pad, int n_chunks, long long first, long long stride) {
     const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
     const long long total = (long long)ks * ks * n_chunks * rows_pad * 32;
-    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+    for (long long i = first; i < total; i += stride) {
         const int pos = (int)(i % 32);
         const int row = (int)((i / 32) % rows_pad);
         const int t = (int)((i / (32LL * rows_pad)) % (ks * ks));
@@ -82,6 +87,32 @@ __global__ __launch_bounds__(NT) void pack_weight_k32_kernel(const float* __rest
         }
         out[i] = (bf16_t)v;
     }
+}
+__global__ __launch_bounds__(NT) void pack_weight_k32_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin,
+                                                             int ks, int transpose, int rows_pad, int n_chunks) {
+    pack_weight_k32_body(w, out, Cout, Cin, ks, transpose, rows_pad, n_chunks, (long long)blockIdx.x * NT + threadIdx.x, (long long)gridDim.x * NT);
+}
+
+// Every stale packed weight of a step in ONE launch (the per-weight launches are ~8 us each of dependent-launch latency, ~160 per
+// VQ-IMG step): work-group b looks its item up in the block-offset table (items sorted by first_block) and packs its share.
+__global__ __launch_bounds__(NT) void pack_weight_batch_kernel(const MasPackItem* __restrict__ items, int n_items) {
+    int lo = 0, hi = n_items - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {                                 // last item with first_block <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    const MasPackItem it = items[lo];
+    const long long first = (long long)(b - it.first_block) * NT + threadIdx.x, stride = (long long)it.n_blocks * NT;
+    const int rows = it.transpose ? it.Cin : it.Cout, cols = it.transpose ? it.Cout : it.Cin;
+    const int rows_pad = (rows + 127) / 128 * 128;
+    auto cdiv = [](int a, int d) { return (a + d - 1) / d; };
+    if (it.layout == MAS_WLAYOUT_K32)
+        pack_weight_k32_body(it.w_oihw, (bf16_t*)it.packed, it.Cout, it.Cin, it.ks, it.transpose, rows_pad, cdiv(cols, 32), first, stride);
+    else if (it.dtype == MAS_BF16)
+        pack_weight_body<bf16_t>(it.w_oihw, (bf16_t*)it.packed, it.Cout, it.Cin, it.ks, it.transpose, rows_pad, cdiv(cols, 64), first, stride);
+    else
+        pack_weight_body<float>(it.w_oihw, (float*)it.packed, it.Cout, it.Cin, it.ks, it.transpose, rows_pad, cdiv(cols, 32), first, stride);
 }
 
 template <typename T>
@@ -214,6 +245,24 @@ extern "C" int mas_pack_conv_weight_layout(const float* w_oihw, void* packed, in
     hipLaunchKernelGGL(pack_weight_k32_kernel, dim3(grid_for(total)), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), w_oihw,
                        (bf16_t*)packed, Cout, Cin, ks, transpose, rows_pad, n_chunks);
     MAS_CHECK_LAUNCH("pack_conv_weight_k32");
+    return MAS_OK;
+}
+
+extern "C" int mas_pack_batch_blocks(int Cout, int Cin, int ks, int transpose, int dtype, int layout) {
+    if (Cout <= 0 || Cin <= 0 || ks < 1 || ks > 4) return 0;
+    const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
+    const int ck = layout == MAS_WLAYOUT_K32 ? 32 : (dtype == MAS_BF16 ? 64 : 32);
+    const long long total = (long long)ks * ks * mas_cdiv(cols, ck) * mas_roundup(rows, 128) * ck;
+    long long b = (total + NT * 8 - 1) / (NT * 8);                     // >= 8 elements per thread
+    if (b > 512) b = 512;
+    return b < 1 ? 1 : (int)b;
+}
+
+extern "C" int mas_pack_conv_weight_batch(const MasPackItem* items_device, int n_items, int total_blocks, void* stream) {
+    MAS_ENTER();
+    if (!items_device || n_items <= 0 || total_blocks <= 0) MAS_FAIL(MAS_EINVAL, "pack_conv_weight_batch: empty batch");
+    hipLaunchKernelGGL(pack_weight_batch_kernel, dim3((unsigned)total_blocks), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), items_device, n_items);
+    MAS_CHECK_LAUNCH("pack_conv_weight_batch");
     return MAS_OK;
 }
 

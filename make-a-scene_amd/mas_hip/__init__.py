@@ -28,6 +28,12 @@ class ConvDesc(C.Structure):
         "in_dtype", "out_dtype", "act", "upsample", "w_layout")]
 
 
+class PackItem(C.Structure):
+    """Mirror of ``MasPackItem`` (include/mas_hip.h): one entry of the batched weight-pack table."""
+    _fields_ = [("w_oihw", C.c_void_p), ("packed", C.c_void_p)] + [(n, C.c_int32) for n in (
+        "Cout", "Cin", "ks", "transpose", "dtype", "layout", "first_block", "n_blocks")]
+
+
 _p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _SIGNATURES = {
     "mas_abi_version": (C.c_int, []),
@@ -36,6 +42,8 @@ _SIGNATURES = {
     "mas_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "mas_conv_weight_layout": (_i, [C.POINTER(ConvDesc)]),
     "mas_pack_conv_weight_layout": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mas_pack_batch_blocks": (_i, [_i, _i, _i, _i, _i, _i]),
+    "mas_pack_conv_weight_batch": (_i, [_p, _i, _i, _p]),
     "mas_gn_stats_workspace": (_sz, [_i, _i]),
     "mas_gn_stats": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _sz, _p]),
     "mas_gn_bwd_workspace": (_sz, [_i, _i]),

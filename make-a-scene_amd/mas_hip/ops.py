@@ -14,7 +14,7 @@ from typing import Optional
 
 import torch
 
-from . import ACT_AFFINE, ACT_AFFINE_SILU, ACT_NONE, BF16, F32, WLAYOUT_K64, ConvDesc, check, lib
+from . import ACT_AFFINE, ACT_AFFINE_SILU, ACT_NONE, BF16, F32, WLAYOUT_K64, ConvDesc, PackItem, check, lib
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 _state = {"compute_dtype": torch.bfloat16 if os.environ.get("MAS_COMPUTE_DTYPE", "bf16") == "bf16" else torch.float32}
@@ -99,6 +99,9 @@ def _param_stamp(p: torch.Tensor):
     return (p._version, p.data_ptr(), _param_generation.get(id(p), 0))
 
 
+_PACK_BATCH = os.environ.get("MAS_PACK_BATCH", "1") == "1"
+
+
 class _PackCache:
     """bf16/NHWC-packed copies of conv parameters, valid while the parameter's stamp (``_param_stamp``: in-place version, storage,
     optimizer steps) is unchanged.  Only ``nn.Parameter`` objects are cached (held by weak reference); temporaries (e.g. the
@@ -106,21 +109,64 @@ class _PackCache:
 
     def __init__(self):
         self.store = {}
+        self._table = None
+        self._table_sig = None
 
     def clear(self):
         self.store.clear()
+        self._table = self._table_sig = None
 
     def get(self, w: torch.Tensor, transpose: bool, dtype: torch.dtype, layout: int = WLAYOUT_K64) -> torch.Tensor:
         if not isinstance(w, torch.nn.Parameter):
             return pack_conv_weight(w.detach(), transpose, dtype, layout)
         key = (id(w), transpose, dtype, layout)
-        ver = _param_stamp(w)
         hit = self.store.get(key)
-        if hit is not None and hit[0]() is w and hit[1] == ver:
+        if hit is not None and hit[0]() is w and hit[1] == _param_stamp(w):
             return hit[2]
-        packed = pack_conv_weight(w.detach(), transpose, dtype, layout)
-        self.store[key] = (weakref.ref(w, lambda _r, k=key: self.store.pop(k, None)), ver, packed)
-        return packed
+        if hit is None or hit[0]() is not w or hit[2].device != w.device:
+            n = lib().mas_packed_weight_elems(w.shape[0], w.shape[1], w.shape[2])
+            self.store[key] = [weakref.ref(w, lambda _r, k=key: self.store.pop(k, None)), None, torch.empty(n, dtype=dtype, device=w.device)]
+        self._refresh_stale(w.device)
+        return self.store[key][2]
+
+    def _refresh_stale(self, device):
+        """Repacks EVERY stale entry on ``device`` in one launch (``mas_pack_conv_weight_batch``): after an optimizer step all of a
+        model's images are stale at once, and one launch replaces ~160 dependent 8-us launches per VQ-IMG step.  The packed
+        buffers are refreshed in place (nothing saves them for backward: the backward asks the cache again)."""
+        items, first = [], 0
+        for (wid, transpose, dtype, layout), ent in self.store.items():
+            w = ent[0]()
+            if w is None or w.device != device or ent[1] == _param_stamp(w):
+                continue
+            cout, cin, ks, _ = w.shape
+            nb = lib().mas_pack_batch_blocks(cout, cin, ks, int(transpose), _DT[dtype], int(layout))
+            if nb <= 0:
+                raise RuntimeError(f"pack_conv_weight: unsupported weight shape {tuple(w.shape)}")
+            wf = w.detach()
+            if wf.dtype != torch.float32 or not wf.is_contiguous():
+                wf = wf.contiguous().float()
+                ent.append(wf)                                 # keep the temporary alive until the launch has been issued
+            items.append(PackItem(wf.data_ptr(), ent[2].data_ptr(), cout, cin, ks, int(transpose), _DT[dtype], int(layout), first, nb))
+            first += nb
+            ent[1] = _param_stamp(w)
+        if not items:
+            return
+        if not _PACK_BATCH:                                      # A/B switch: one launch per image
+            for it in items:
+                check(lib().mas_pack_conv_weight_layout(it.w_oihw, it.packed, it.Cout, it.Cin, it.ks, it.transpose, it.dtype, it.layout,
+                                                        _stream()), "pack_conv_weight")
+            for ent in self.store.values():
+                del ent[3:]
+            return
+        arr = (PackItem * len(items))(*items)
+        raw = bytes(memoryview(arr))
+        sig = (device.index, raw)
+        if self._table_sig != sig:                               # pointers and shapes repeat step after step: one upload, then reuse
+            self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+            self._table_sig = sig
+        check(lib().mas_pack_conv_weight_batch(_ptr(self._table), len(items), first, _stream()), "pack_conv_weight_batch")
+        for ent in self.store.values():
+            del ent[3:]
 
 
 _pack_cache = _PackCache()
