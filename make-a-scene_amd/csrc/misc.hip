@@ -35,27 +35,36 @@ constexpr int NT = 256;
 // K loop are consecutive in memory: the stream kernel addresses step t at t * rows_pad * 128), where a 128-byte row
 // holds CK = 128/sizeof(T) consecutive K elements as eight 16-byte slots and slot position sp stores logical
 // slot sp ^ ((row>>1)&7) (the bank-conflict swizzle of conv_fwd.hip).  See mas_hip.h for the two modes.
+// One thread per 16-byte slot (8 bf16 / 4 fp32 consecutive K elements of one row and tap): 32-bit index arithmetic, two runtime
+// divisions per slot, one 16-byte store.  (A thread per (chunk, row, slot position) looping over the taps reads the OIHW source in
+// contiguous runs but leaves too few threads in flight: 2.5 ms instead of 0.6 ms for the 160 images of a VQ-IMG step.)
 template <typename T>
 __device__ __forceinline__ void pack_weight_body(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int ks, int transpose,
                                                  int rows_pad, int n_chunks, long long first, long long stride) {
     constexpr int EPU = 16 / (int)sizeof(T), CK = 128 / (int)sizeof(T);
     const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
-    const long long total = (long long)ks * ks * n_chunks * rows_pad * CK;
-    for (long long i = first; i < total; i += stride) {
-        const int pos = (int)(i % CK);
-        const int row = (int)((i / CK) % rows_pad);
-        const int t = (int)((i / ((long long)CK * rows_pad)) % (ks * ks));
-        const int ch = (int)(i / ((long long)CK * rows_pad * ks * ks));
-        const int sp = pos / EPU, e = pos % EPU;
-        const int col = ch * CK + ((sp ^ ((row >> 1) & 7)) * EPU) + e;
-        const int kh = t / ks, kw = t % ks;
-        float v = 0.0f;
-        if (row < rows && col < cols) {
-            if (!transpose) v = w[(((size_t)row * Cin + col) * ks + kh) * ks + kw];
-            // rows = input channels (the dgrad's "Cout"), cols = output channels (its "Cin"), taps flipped
-            else v = w[(((size_t)col * Cin + row) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)];
+    const unsigned kk = (unsigned)(ks * ks);
+    const unsigned total = kk * (unsigned)n_chunks * (unsigned)rows_pad * 8u;       // slots
+    for (unsigned u = (unsigned)first; u < total; u += (unsigned)stride) {
+        const unsigned sp = u & 7u, r_ = u >> 3;
+        const unsigned q = r_ / (unsigned)rows_pad, row = r_ - q * (unsigned)rows_pad;
+        const unsigned ch = q / kk, t = q - ch * kk;
+        const int kh = (int)t / ks, kw = (int)t - kh * ks;
+        const int col0 = (int)ch * CK + (int)((sp ^ ((row >> 1) & 7u)) * EPU);
+        u32x4 o;
+        T* ov = reinterpret_cast<T*>(&o);
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) {
+            const int col = col0 + e;
+            float v = 0.0f;
+            if ((int)row < rows && col < cols) {
+                if (!transpose) v = w[(((size_t)row * Cin + col) * ks + kh) * ks + kw];
+                // rows = input channels (the dgrad's "Cout"), cols = output channels (its "Cin"), taps flipped
+                else v = w[(((size_t)col * Cin + row) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)];
+            }
+            ov[e] = (T)v;
         }
-        out[i] = (T)v;
+        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(out) + (size_t)u * 16) = o;
     }
 }
 template <typename T>
@@ -70,22 +79,28 @@ __global__ __launch_bounds__(NT) void pack_weight_kernel(const float* __restrict
 __device__ __forceinline__ void pack_weight_k32_body(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int ks, int transpose,
                                                      int rows_pad, int n_chunks, long long first, long long stride) {
     const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
-    const long long total = (long long)ks * ks * n_chunks * rows_pad * 32;
-    for (long long i = first; i < total; i += stride) {
-        const int pos = (int)(i % 32);
-        const int row = (int)((i / 32) % rows_pad);
-        const int t = (int)((i / (32LL * rows_pad)) % (ks * ks));
-        const int ch = (int)(i / (32LL * rows_pad * ks * ks));
-        const int sp = pos / 8, e = pos % 8;
-        const int col = ch * 32 + ((sp ^ ((row >> 2) & 3)) * 8) + e;
-        const int frow = (row & ~127) + 4 * (row & 31) + ((row & 127) >> 5);      // filter row stored at LDS row `row`
-        const int kh = t / ks, kw = t % ks;
-        float v = 0.0f;
-        if (frow < rows && col < cols) {
-            if (!transpose) v = w[(((size_t)frow * Cin + col) * ks + kh) * ks + kw];
-            else v = w[(((size_t)col * Cin + frow) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)];
+    const unsigned kk = (unsigned)(ks * ks);
+    const unsigned total = kk * (unsigned)n_chunks * (unsigned)rows_pad * 4u;       // 16-byte slots of the 64-byte rows
+    for (unsigned u = (unsigned)first; u < total; u += (unsigned)stride) {
+        const unsigned sp = u & 3u, r_ = u >> 2;
+        const unsigned q = r_ / (unsigned)rows_pad, row = r_ - q * (unsigned)rows_pad;
+        const unsigned ch = q / kk, t = q - ch * kk;
+        const int kh = (int)t / ks, kw = (int)t - kh * ks;
+        const int col0 = (int)ch * 32 + (int)((sp ^ ((row >> 2) & 3u)) * 8);
+        const int frow = (int)((row & ~127u) + 4u * (row & 31u) + ((row & 127u) >> 5));      // filter row stored at LDS row `row`
+        u32x4 o;
+        bf16_t* ov = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int col = col0 + e;
+            float v = 0.0f;
+            if (frow < rows && col < cols) {
+                if (!transpose) v = w[(((size_t)frow * Cin + col) * ks + kh) * ks + kw];
+                else v = w[(((size_t)col * Cin + frow) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)];
+            }
+            ov[e] = (bf16_t)v;
         }
-        out[i] = (bf16_t)v;
+        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(out) + (size_t)u * 16) = o;
     }
 }
 __global__ __launch_bounds__(NT) void pack_weight_k32_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin,
@@ -252,8 +267,8 @@ extern "C" int mas_pack_batch_blocks(int Cout, int Cin, int ks, int transpose, i
     if (Cout <= 0 || Cin <= 0 || ks < 1 || ks > 4) return 0;
     const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
     const int ck = layout == MAS_WLAYOUT_K32 ? 32 : (dtype == MAS_BF16 ? 64 : 32);
-    const long long total = (long long)ks * ks * mas_cdiv(cols, ck) * mas_roundup(rows, 128) * ck;
-    long long b = (total + NT * 8 - 1) / (NT * 8);                     // >= 8 elements per thread
+    const long long total = (long long)ks * ks * mas_cdiv(cols, ck) * mas_roundup(rows, 128) * (layout == MAS_WLAYOUT_K32 ? 4 : 8);
+    long long b = (total + NT - 1) / NT;                               // one 16-byte slot per thread
     if (b > 512) b = 512;
     return b < 1 ? 1 : (int)b;
 }
