@@ -134,7 +134,7 @@ class _PackCache:
         model's images are stale at once, and one launch replaces ~160 dependent 8-us launches per VQ-IMG step.  The packed
         buffers are refreshed in place (nothing saves them for backward: the backward asks the cache again)."""
         items, first = [], 0
-        for (wid, transpose, dtype, layout), ent in self.store.items():
+        for (_wid, transpose, dtype, layout), ent in list(self.store.items()):     # (a weakref callback may pop entries meanwhile)
             w = ent[0]()
             if w is None or w.device != device or ent[1] == _param_stamp(w):
                 continue
@@ -155,7 +155,7 @@ class _PackCache:
             for it in items:
                 check(lib().mas_pack_conv_weight_layout(it.w_oihw, it.packed, it.Cout, it.Cin, it.ks, it.transpose, it.dtype, it.layout,
                                                         _stream()), "pack_conv_weight")
-            for ent in self.store.values():
+            for ent in list(self.store.values()):
                 del ent[3:]
             return
         arr = (PackItem * len(items))(*items)
@@ -165,7 +165,7 @@ class _PackCache:
             self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
             self._table_sig = sig
         check(lib().mas_pack_conv_weight_batch(_ptr(self._table), len(items), first, _stream()), "pack_conv_weight_batch")
-        for ent in self.store.values():
+        for ent in list(self.store.values()):
             del ent[3:]
 
 
