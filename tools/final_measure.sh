@@ -9,6 +9,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 600 python bench.py --workload transformer > $O/bench_transformer.json 2> $O/bench_transformer.err
 timeout 600 python bench.py --workload e2e > $O/bench_e2e.json 2> $O/bench_e2e.err
+[ -x tools/probes/mfma_peak ] || bash tools/probes/build.sh > /dev/null 2>&1
 KB="timeout 100 python tools/kbench.py"
 {
   for act in 0 2; do $KB conv_fwd --n 32 --c 128 --hw 256 --act $act | tail -1; done
