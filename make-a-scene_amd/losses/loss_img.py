@@ -4,10 +4,16 @@ obtained with ``torch.autograd.grad(..., retain_graph=True)`` THROUGH the HIP au
 
 The discriminator runs on the MI355X kernels (``losses.discriminator``).  The two terms of the reference that need pretrained
 networks at absolute paths -- LPIPS-VGG16 (``/home/ubuntu/.../vgg.pth``, lpips.py:15) and the face-embedding loss
-(face_loss.py:76) -- are pluggable here: ``perceptual_loss="lpips"`` builds ``losses.lpips_with_object.LPIPSWithObject`` on the
-HIP convolutions (weights from ``MAS_LPIPS_CKPT``), a callable is used as given, ``None`` (default) contributes 0; ``face_loss`` is a
-callable or None (its face-embedding network is not part of this repository).  The arithmetic below is the reference's line for line.  ``forward`` keeps the reference's signature and return shapes
+(face_loss.py:76) -- are pluggable here.  ``perceptual_loss="lpips"`` (the DEFAULT, as the reference's constructor always builds
+it, loss_img.py:45) is ``losses.lpips_with_object.LPIPSWithObject`` on the HIP convolutions (weights from ``MAS_LPIPS_CKPT`` /
+``MAS_VGG16_CKPT``; missing weights are reported loudly by ``LPIPS.load_from_pretrained``); a callable is used as given; an
+explicit ``None`` opts out.  ``face_loss``: the reference always builds ``FaceLoss()`` (loss_img.py:48) -- a pretrained
+face-embedding network that is not part of this repository (out of scope) -- so the default here
+(``"reference"``) logs ONCE that the face term is absent from the objective and contributes 0; pass a callable to supply it, or
+``None`` to opt out silently.  The arithmetic below is the reference's line for line.  ``forward`` keeps the reference's signature and return shapes
 (optimizer_idx 0 -> ``loss, (nll_loss, object_loss, face_loss)``; 1 -> ``d_loss``)."""
+import warnings
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -32,8 +38,10 @@ def vanilla_d_loss(logits_real, logits_fake):
 
 
 class VQLPIPSWithDiscriminator(nn.Module):
+    _face_warned = False
+
     def __init__(self, disc_start, codebook_weight=1.0, pixelloss_weight=1.0, disc_factor=1.0, disc_weight=1.0, perceptual_weight=1.0,
-                 perceptual_loss=None, face_loss=None):
+                 perceptual_loss="lpips", face_loss="reference"):
         super().__init__()
         self.codebook_weight = codebook_weight
         self.pixel_weight = pixelloss_weight
@@ -42,6 +50,16 @@ class VQLPIPSWithDiscriminator(nn.Module):
             perceptual_loss = LPIPSWithObject().eval()
         self.perceptual_loss = perceptual_loss        # callable(images, reconstructions, bbox_obj) -> per-sample map, or None
         self.perceptual_weight = perceptual_weight
+        if isinstance(face_loss, str):
+            if face_loss != "reference":
+                raise ValueError("face_loss: a callable, None, or 'reference' (the default)")
+            if not VQLPIPSWithDiscriminator._face_warned:
+                VQLPIPSWithDiscriminator._face_warned = True
+                warnings.warn("VQLPIPSWithDiscriminator: the reference adds FaceLoss() (losses/face_loss.py: a pretrained face-embedding "
+                              "network, not part of this repository) to the generator objective; it is ABSENT here and contributes 0 "
+                              "-- pass face_loss=<callable(images, reconstructions, bbox_face)> to supply it, face_loss=None to "
+                              "silence this message")
+            face_loss = None
         self.face_loss = face_loss                    # callable(images, reconstructions, bbox_face) -> scalar, or None
         self.discriminator = Discriminator().apply(weights_init)
         self.discriminator_iter_start = disc_start

@@ -10,8 +10,10 @@ are the reference's own torch expressions (elementwise and reduction passes).
 
 What the reference does at construction and this module cannot: it downloads ``vgg.pth`` and takes torchvision's pretrained VGG16
 (lpips.py:10-15,55,101).  There is no network here: weights come from ``MAS_LPIPS_CKPT`` (a state_dict with the keys above, e.g.
-``LPIPS().state_dict()`` saved from the reference), or from the reference's path if that file exists; otherwise the module keeps
-its random initialisation and says so once -- the loss is then a perceptual distance in name only."""
+``LPIPS().state_dict()`` saved from the reference), or from the reference's path if that file exists, plus ``MAS_VGG16_CKPT``
+(torchvision's VGG16 state_dict) for the backbone when the first file holds the heads only -- as the reference's ``vgg.pth``
+does.  Every tensor still at its random initialisation afterwards is named in a warning (``LPIPS.unloaded``;
+``MAS_LPIPS_STRICT=1`` raises instead) -- the loss is then a perceptual distance in name only."""
 import os
 import warnings
 
@@ -103,15 +105,52 @@ class LPIPS(nn.Module):
         for param in self.parameters():
             param.requires_grad = False
 
+    # torchvision vgg16().features index of each convolution -> (slice, index inside the slice) (lpips.py:103-108: features[0:4],
+    # [4:9], [9:16], [16:23], [23:30])
+    _TV_CONVS = {0: ("slice1", 0), 2: ("slice1", 2), 5: ("slice2", 1), 7: ("slice2", 3), 10: ("slice3", 1), 12: ("slice3", 3),
+                 14: ("slice3", 5), 17: ("slice4", 1), 19: ("slice4", 3), 21: ("slice4", 5), 24: ("slice5", 1), 26: ("slice5", 3),
+                 28: ("slice5", 5)}
+
     def load_from_pretrained(self, name="vgg_lpips"):
+        """The reference fills this module from TWO sources: torchvision's pretrained VGG16 for the backbone (lpips.py:101) and
+        ``vgg.pth`` for the five ``lin<k>`` heads (lpips.py:55-57, ``strict=False``) -- that file alone leaves the 13 backbone
+        convolutions untouched.  Here: ``MAS_LPIPS_CKPT`` (or the reference's ``vgg.pth`` path) may hold either the whole module's
+        state_dict or the heads only; ``MAS_VGG16_CKPT`` may hold torchvision's ``vgg16().state_dict()`` / ``vgg16().features
+        .state_dict()`` for the backbone.  Whatever is still at its random initialisation afterwards is reported LOUDLY, by name
+        (``self.unloaded``); ``MAS_LPIPS_STRICT=1`` turns that report into an error."""
+        want = set(self.state_dict().keys()) - {"scaling_layer.shift", "scaling_layer.scale"}
+        loaded = set()
         for path in CKPT_PATHS:
             if path and os.path.exists(path):
-                self.load_state_dict(torch.load(path, map_location=torch.device("cpu")), strict=False)
-                return
-        if not LPIPS._warned:
+                sd = torch.load(path, map_location=torch.device("cpu"))
+                res = self.load_state_dict(sd, strict=False)
+                loaded |= want - set(res.missing_keys)
+                break
+        tv_path = os.environ.get("MAS_VGG16_CKPT", "")
+        if tv_path and os.path.exists(tv_path):
+            tv = torch.load(tv_path, map_location=torch.device("cpu"))
+            mine = self.state_dict()
+            for idx, (sl, j) in self._TV_CONVS.items():
+                for leaf in ("weight", "bias"):
+                    src = tv.get(f"features.{idx}.{leaf}", tv.get(f"{idx}.{leaf}"))
+                    key = f"vgg.{sl}.{j}.{leaf}"
+                    if src is not None and tuple(src.shape) == tuple(mine[key].shape):
+                        mine[key].copy_(src)
+                        loaded.add(key)
+        self.unloaded = sorted(want - loaded)
+        if not self.unloaded:
+            return
+        backbone = [k for k in self.unloaded if k.startswith("vgg.")]
+        heads = [k for k in self.unloaded if k.startswith("lin")]
+        msg = ("LPIPS: %d of %d tensors keep their RANDOM initialisation (backbone: %d of 26 -- set MAS_VGG16_CKPT to torchvision's "
+               "vgg16 state_dict, or MAS_LPIPS_CKPT to a full state_dict of the reference's LPIPS module; heads: %d of 5 -- "
+               "MAS_LPIPS_CKPT / vgg.pth); the perceptual term is NOT a perceptual distance until they are loaded.  Missing: %s"
+               % (len(self.unloaded), len(want), len(backbone), len(heads), ", ".join(self.unloaded[:6]) + (" ..." if len(self.unloaded) > 6 else "")))
+        if os.environ.get("MAS_LPIPS_STRICT", "0") == "1":
+            raise RuntimeError(msg)
+        if loaded or not LPIPS._warned:       # a PARTIAL load (e.g. vgg.pth alone: heads without backbone) is reported every time
             LPIPS._warned = True
-            warnings.warn("LPIPS: no checkpoint (set MAS_LPIPS_CKPT to a state_dict of the reference's LPIPS module); keeping the random "
-                          "initialisation -- the perceptual term is not meaningful until weights are loaded")
+            warnings.warn(msg)
 
     def forward(self, real_x, fake_x):
         b = real_x.shape[0]

@@ -75,10 +75,16 @@ def _empty_nhwc(n, c, h, w, dtype, device):
 _param_generation = {}
 
 
+_param_generation_refs = {}
+
+
 def _note_optimizer_step(optimizer, *_args, **_kwargs):
     for group in optimizer.param_groups:
         for p in group["params"]:
-            _param_generation[id(p)] = _param_generation.get(id(p), 0) + 1
+            k = id(p)
+            if k not in _param_generation_refs:           # the counter dies with the parameter (ids are reused by CPython)
+                _param_generation_refs[k] = weakref.ref(p, lambda _r, k=k: (_param_generation.pop(k, None), _param_generation_refs.pop(k, None)))
+            _param_generation[k] = _param_generation.get(k, 0) + 1
 
 
 try:
@@ -100,6 +106,13 @@ def _param_stamp(p: torch.Tensor):
 
 
 _PACK_BATCH = os.environ.get("MAS_PACK_BATCH", "1") == "1"
+# debugging aid for writes the stamp cannot see (``w.data.copy_(...)`` without invalidate_weight_cache()): every cache hit compares a
+# checksum of the live parameter with the one taken when its image was packed (one device sync per conv call: never on by default)
+_CACHE_CHECK = os.environ.get("MAS_WEIGHT_CACHE_CHECK", "0") == "1"
+
+
+def _checksum(w: torch.Tensor) -> float:
+    return float(w.detach().double().sum())
 
 
 class _PackCache:
@@ -109,19 +122,48 @@ class _PackCache:
 
     def __init__(self):
         self.store = {}
+        self.derived = {}                            # images of tensors DERIVED from several parameters (AttnBlock's q|k|v stack)
+        self.sums = {}                               # MAS_WEIGHT_CACHE_CHECK=1 only
         self._table = None
         self._table_sig = None
 
     def clear(self):
         self.store.clear()
+        self.derived.clear()
         self._table = self._table_sig = None
 
-    def get(self, w: torch.Tensor, transpose: bool, dtype: torch.dtype, layout: int = WLAYOUT_K64) -> torch.Tensor:
+    def drop(self, w: torch.Tensor):
+        """forget every image made from parameter ``w`` (its module was switched train()/eval() or reloaded)"""
+        k = id(w)
+        for key in [key for key in self.store if key[0] == k]:
+            self.store.pop(key, None)
+        for key in [key for key in self.derived if k in key[0]]:
+            self.derived.pop(key, None)
+
+    def get_derived(self, w: torch.Tensor, sources, transpose: bool, dtype: torch.dtype, layout: int) -> torch.Tensor:
+        """``w`` is a function of the parameters ``sources`` only (e.g. their concatenation): its packed image is valid while all
+        of their stamps are unchanged."""
+        key = (tuple(id(p) for p in sources), transpose, dtype, layout)
+        stamp = tuple(_param_stamp(p) for p in sources)
+        hit = self.derived.get(key)
+        if hit is not None and hit[1] == stamp and all(r() is p for r, p in zip(hit[0], sources)) and hit[2].device == w.device:
+            return hit[2]
+        packed = pack_conv_weight(w.detach(), transpose, dtype, layout)
+        refs = tuple(weakref.ref(p, lambda _r, k=key: self.derived.pop(k, None)) for p in sources)
+        self.derived[key] = (refs, stamp, packed)
+        return packed
+
+    def get(self, w: torch.Tensor, transpose: bool, dtype: torch.dtype, layout: int = WLAYOUT_K64, sources=None) -> torch.Tensor:
         if not isinstance(w, torch.nn.Parameter):
+            if sources is not None:
+                return self.get_derived(w, sources, transpose, dtype, layout)
             return pack_conv_weight(w.detach(), transpose, dtype, layout)
         key = (id(w), transpose, dtype, layout)
         hit = self.store.get(key)
         if hit is not None and hit[0]() is w and hit[1] == _param_stamp(w):
+            if _CACHE_CHECK and self.sums.get(key) != _checksum(w):
+                raise RuntimeError("packed-weight cache: parameter of shape %s changed without a version bump / optimizer step (a write "
+                                   "through .data?) -- call mas_hip.ops.invalidate_weight_cache() after such writes" % (tuple(w.shape),))
             return hit[2]
         if hit is None or hit[0]() is not w or hit[2].device != w.device:
             n = lib().mas_packed_weight_elems(w.shape[0], w.shape[1], w.shape[2])
@@ -133,8 +175,9 @@ class _PackCache:
         """Repacks EVERY stale entry on ``device`` in one launch (``mas_pack_conv_weight_batch``): after an optimizer step all of a
         model's images are stale at once, and one launch replaces ~160 dependent 8-us launches per VQ-IMG step.  The packed
         buffers are refreshed in place (nothing saves them for backward: the backward asks the cache again)."""
-        items, first = [], 0
-        for (_wid, transpose, dtype, layout), ent in list(self.store.items()):     # (a weakref callback may pop entries meanwhile)
+        items, first, fresh = [], 0, []
+        for key, ent in list(self.store.items()):                                  # (a weakref callback may pop entries meanwhile)
+            _wid, transpose, dtype, layout = key
             w = ent[0]()
             if w is None or w.device != device or ent[1] == _param_stamp(w):
                 continue
@@ -148,13 +191,17 @@ class _PackCache:
                 ent.append(wf)                                 # keep the temporary alive until the launch has been issued
             items.append(PackItem(wf.data_ptr(), ent[2].data_ptr(), cout, cin, ks, int(transpose), _DT[dtype], int(layout), first, nb))
             first += nb
-            ent[1] = _param_stamp(w)
+            ent[1] = None                                      # not valid until the launch below has been accepted
+            fresh.append((ent, _param_stamp(w)))
+            if _CACHE_CHECK:
+                self.sums[key] = _checksum(w)
         if not items:
             return
         if not _PACK_BATCH:                                      # A/B switch: one launch per image
-            for it in items:
+            for it, (ent, stamp) in zip(items, fresh):
                 check(lib().mas_pack_conv_weight_layout(it.w_oihw, it.packed, it.Cout, it.Cin, it.ks, it.transpose, it.dtype, it.layout,
                                                         _stream()), "pack_conv_weight")
+                ent[1] = stamp
             for ent in list(self.store.values()):
                 del ent[3:]
             return
@@ -165,6 +212,8 @@ class _PackCache:
             self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
             self._table_sig = sig
         check(lib().mas_pack_conv_weight_batch(_ptr(self._table), len(items), first, _stream()), "pack_conv_weight_batch")
+        for ent, stamp in fresh:                                 # (a failed launch raised above: the entries stay invalid)
+            ent[1] = stamp
         for ent in list(self.store.values()):
             del ent[3:]
 
@@ -172,10 +221,21 @@ class _PackCache:
 _pack_cache = _PackCache()
 
 
+def drop_weight_cache_of(*params) -> None:
+    """Drops the packed images / bf16 shadows made from these parameters only (``Conv2d`` / ``Linear`` call it for their own
+    parameters on load_state_dict and on a train()/eval() switch -- not the whole process's cache per child module)."""
+    for p in params:
+        if p is not None:
+            _pack_cache.drop(p)
+            _bf16_shadows.drop(p)
+
+
 def invalidate_weight_cache() -> None:
     """Drops every cached packed weight / bf16 shadow.  The caches are validated by ``_param_stamp`` (``Parameter._version``,
     ``data_ptr``, optimizer steps seen by the global post-step hook), which an in-place write THROUGH ``.data`` (``w.data.copy_(ema)``, ``w.data.normal_()``, weight clipping) does not change: call this after
-    such a write.  ``models.modules.Conv2d`` calls it from ``load_state_dict`` and on every train()/eval() switch."""
+    such a write (``MAS_WEIGHT_CACHE_CHECK=1`` makes every conv-weight hit compare a checksum of the parameter against the one taken at
+    pack time and raise on a mismatch: a debugging aid for exactly this).  ``models.modules.Conv2d`` drops ITS OWN entries
+    (``drop_weight_cache_of``) from ``load_state_dict`` and on every train()/eval() switch."""
     _pack_cache.clear()
     _bf16_shadows.clear()
 
@@ -196,10 +256,12 @@ def pack_conv_weight(w: torch.Tensor, transpose: bool, dtype: torch.dtype, layou
 class ConvWeight:
     """An UNPACKED conv weight handed to ``conv_fwd_raw``: packed there (through the cache when it is an nn.Parameter) in the
     layout the library prefers for that convolution (``mas_conv_weight_layout``)."""
-    __slots__ = ("w", "transpose")
+    __slots__ = ("w", "transpose", "sources")
 
-    def __init__(self, w: torch.Tensor, transpose: bool = False):
-        self.w, self.transpose = w, bool(transpose)
+    def __init__(self, w: torch.Tensor, transpose: bool = False, sources=None):
+        # sources: the nn.Parameters a non-Parameter ``w`` was built from (their concatenation, say): its packed image is then cached
+        # on THEIR stamps instead of being re-packed on every call
+        self.w, self.transpose, self.sources = w, bool(transpose), sources
 
 
 # --------------------------------------------------------------------------- #
@@ -284,7 +346,7 @@ def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stri
     d = _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, x.dtype, out_dtype, act, upsample)
     if isinstance(wp, ConvWeight):
         d.w_layout = _preferred_layout(d)
-        wp = _pack_cache.get(wp.w, wp.transpose, x.dtype, d.w_layout)
+        wp = _pack_cache.get(wp.w, wp.transpose, x.dtype, d.w_layout, wp.sources)
     partial, rows = None, 0
     if want_stats and _stats_state["on"]:
         key = tuple(getattr(d, f) for f, _ in ConvDesc._fields_)
@@ -396,7 +458,8 @@ class _NormActConv(torch.autograd.Function):
         mr = ss = None
         if act != ACT_NONE:
             mr, ss = gn_stats(x, gn_w.detach().float(), gn_b.detach().float(), cfg["groups"], cfg["eps"], xpart, xrows)
-        wp = ConvWeight(weight, False)
+        ctx.w_sources = getattr(weight, "_mas_sources", None)      # (the saved tensor comes back as another Python object)
+        wp = ConvWeight(weight, False, ctx.w_sources)
         b32 = bias.detach().float() if bias is not None else None
         res = nhwc(residual, cd) if residual is not None else None
         y, ypart, yrows = conv_fwd_raw(x, ss, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, cfg["out_dtype"],
@@ -424,7 +487,7 @@ class _NormActConv(torch.autograd.Function):
             dw, db = conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, need_b)
             dw = dw.to(weight.dtype) if need_w else None
         if need_x or need_gn:
-            wt = ConvWeight(weight, True)
+            wt = ConvWeight(weight, True, ctx.w_sources)
             hl, wl = (2 * h, 2 * w) if ups else (h, w)
             if stride == 1:
                 d_in, hd, wd = dy, ho, wo
@@ -874,6 +937,11 @@ class _Bf16Shadows:
 
     def clear(self):
         self.params.clear()
+
+    def drop(self, p):
+        ent = self.params.get(id(p))
+        if ent is not None:
+            ent[1] = None
 
     def register(self, p: torch.nn.Parameter):
         k = id(p)

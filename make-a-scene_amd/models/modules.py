@@ -59,14 +59,14 @@ class Conv2d(nn.Conv2d):
     # The packed bf16/NHWC weight images are cached on ops._param_stamp (Parameter._version, data_ptr, optimizer steps -- fused
     # optimizers do not bump _version, a global optimizer post-step hook covers them); writes THROUGH ``.data`` change
     # neither.  The two places such writes normally surround -- loading a checkpoint and switching train()/eval() (EMA
-    # swap-in) -- drop the cache; any other ``.data`` write needs ``mas_hip.ops.invalidate_weight_cache()``.
+    # swap-in) -- drop this layer's images; any other ``.data`` write needs ``mas_hip.ops.invalidate_weight_cache()``.
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)
-        ops.invalidate_weight_cache()
+        ops.drop_weight_cache_of(self.weight, self.bias)
 
     def train(self, mode: bool = True):
         if mode != self.training:
-            ops.invalidate_weight_cache()
+            ops.drop_weight_cache_of(self.weight, self.bias)       # this layer's images only (not the process-wide cache per child)
         return super().train(mode)
 
     def forward(self, x, residual=None, upsample=False):
@@ -166,6 +166,7 @@ class AttnBlock(nn.Module):
     def forward(self, x):
         c = self.in_channels
         w_qkv = torch.cat([self.q.weight, self.k.weight, self.v.weight], dim=0)
+        w_qkv._mas_sources = (self.q.weight, self.k.weight, self.v.weight)     # its packed images are cached on these three stamps
         b_qkv = torch.cat([self.q.bias, self.k.bias, self.v.bias], dim=0)
         qkv = ops.norm_act_conv(x, w_qkv, b_qkv, self.norm.weight, self.norm.bias, None, stride=1, padding=(0, 0, 0, 0),
                                 act=ACT_AFFINE, groups=self.norm.num_groups, eps=self.norm.eps)

@@ -65,13 +65,33 @@ class Linear(nn.Linear):
 
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)
-        ops.invalidate_weight_cache()
+        ops.drop_weight_cache_of(self.weight, self.bias)
 
     def forward(self, x):
         if (x.is_cuda and self.bias is not None and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
                 and self.weight.dtype == torch.float32 and self.in_features % 8 == 0 and self.out_features % 8 == 0):
             return ops.linear_bf16(x, self.weight, self.bias)
         return super().forward(x)
+
+
+def _kv_backing(t, b, d):
+    """[B, cap, D] buffer behind a cached k / v entry [B, H, L, hd].  The entries this module returns are views of such a buffer
+    (``t._base``); anything else -- a clone, a contiguous copy, an index_select over the batch (beam reorder) -- has lost it and is
+    laid out [B, H, L, hd]: the buffer is rebuilt from its contents (capacity = L) instead of being reinterpreted."""
+    base = t._base
+    if base is not None and base.dim() == 3 and base.shape[0] == b and base.shape[2] == d and base.is_contiguous() \
+            and t.data_ptr() == base.data_ptr() and t.stride(2) == d:
+        return base
+    return t.permute(0, 2, 1, 3).reshape(b, t.shape[2], d).contiguous()
+
+
+def _row_backing(t, b, d):
+    """[B, cap, D] buffer behind a cached [B, L, D] row view (attention outputs / layer outputs so far), or a copy of its rows"""
+    base = t._base
+    if base is not None and base.dim() == 3 and base.shape[0] == b and base.shape[2] == d and base.is_contiguous() \
+            and t.data_ptr() == base.data_ptr():
+        return base
+    return t.contiguous()
 
 
 class SelfAttention(nn.Module):
@@ -117,13 +137,14 @@ class SelfAttention(nn.Module):
             vbuf = torch.empty_like(kbuf)
             obuf = torch.empty_like(kbuf)
         else:
-            kbuf, vbuf, obuf = (t._base if t._base is not None else t for t in cache)   # the buffers behind the views
-            kbuf, vbuf = kbuf.view(b, -1, d), vbuf.view(b, -1, d)
-            if kbuf.shape[1] < s_tot:                                                  # grow geometrically, copy once
+            # the [B, cap, D] buffers behind the views; an entry that is NOT such a view any more (cloned, made contiguous,
+            # index_select'ed for a beam / batch reorder) is rebuilt from its [B, H, L, hd] / [B, L, D] contents
+            kbuf, vbuf = (_kv_backing(t, b, d) for t in cache[:2])
+            obuf = _row_backing(cache[2], b, d)
+            if kbuf.shape[1] < s_tot or obuf.shape[1] < s_tot or vbuf.shape[1] != kbuf.shape[1]:                                                  # grow geometrically, copy once
                 cap = max(2 * kbuf.shape[1], s_tot)
                 grow = lambda t: torch.cat([t[:, :past], torch.empty((b, cap - past, d), dtype=t.dtype, device=t.device)], dim=1)
-                kbuf, vbuf, obuf = grow(kbuf), grow(vbuf), grow(obuf.view(b, -1, d))
-            obuf = obuf.view(b, -1, d)
+                kbuf, vbuf, obuf = grow(kbuf), grow(vbuf), grow(obuf)
         kbuf[:, past:s_tot] = qkv[..., d:2 * d]
         vbuf[:, past:s_tot] = qkv[..., 2 * d:]
         q = qkv[..., :d]
@@ -208,12 +229,13 @@ class TransformerLayer(nn.Module):
         mlp_out = self.mlp(self.ln_out(self._prescale(h)))
         y_new = self.second_ln_sandwich(mlp_out, residual=h) if self.cogview_sandwich_layernorm else h + mlp_out
         if cache is None:
-            ybuf = torch.empty((x.shape[0], kv[0]._base.view(x.shape[0], -1, x.shape[-1]).shape[1], x.shape[-1]), dtype=y_new.dtype,
+            ybuf = torch.empty((x.shape[0], _kv_backing(kv[0], x.shape[0], x.shape[-1]).shape[1], x.shape[-1]), dtype=y_new.dtype,
                                device=x.device)
         else:
-            ybuf = cache[3]._base if cache[3]._base is not None else cache[3]
-            if ybuf.shape[1] < x.shape[1]:
-                ybuf = torch.cat([ybuf[:, :past], torch.empty((x.shape[0], 2 * ybuf.shape[1] - past, x.shape[-1]), dtype=ybuf.dtype,
+            ybuf = _row_backing(cache[3], x.shape[0], x.shape[-1])
+            if ybuf.shape[1] < x.shape[1]:                        # same growth rule as the attention's buffers
+                cap = max(2 * ybuf.shape[1], x.shape[1])
+                ybuf = torch.cat([ybuf[:, :past], torch.empty((x.shape[0], cap - past, x.shape[-1]), dtype=ybuf.dtype,
                                                               device=x.device)], dim=1)
         ybuf[:, past:x.shape[1]] = y_new
         return ybuf[:, :x.shape[1]], kv + (ybuf[:, :x.shape[1]],)

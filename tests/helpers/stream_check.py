@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Runs in a child process of tests/test_gpu_stream.py with MAS_CONV_STREAM_MIN_TILES_PER_CU=0 (the knob is read once per
 process), so that SMALL shapes take the stream-scheduled 3x3 kernel (conv3x3_stream.hip) and can be compared with a CPU
-fp32 convolution of the same bf16-rounded operands.  Prints one line per case and exits non-zero on a mismatch."""
+fp32 convolution of the same bf16-rounded operands.  Prints one line per case and exits non-zero on a mismatch.
+
+`stream_check.py multi` (run with MAS_CONV_WGS_PER_CU=1: one work-group per CU): more 16x16-pixel tiles than work-groups, so every
+work-group walks several tiles (deferred stores of the previous tile, next-tile plan and prefetch); tiles > grid is asserted."""
 import os
 import sys
 
@@ -25,9 +28,25 @@ CASES = [
     (2, 128, 40, 24, 128, (1, 1, 1, 1), False, 2, False),     # GroupNorm+SiLU prologue
     (3, 256, 20, 36, 128, (1, 1, 1, 1), False, 2, True),      # prologue, two pairs, residual
     (2, 128, 18, 18, 256, (1, 1, 1, 1), False, 1, False),     # affine-only prologue, two cout tiles
-    (40, 128, 32, 32, 128, (1, 1, 1, 1), False, 2, True),     # many tiles: every work-group walks several (deferred stores, next-tile prefetch)
+    (40, 128, 32, 32, 128, (1, 1, 1, 1), False, 2, True),     # 160 tiles = 160 work-groups, ONE tile each (the multi-tile walk is MULTI_CASES' job)
     (40, 128, 32, 32, 128, (1, 1, 1, 1), False, 0, False),
 ]
+# more tiles than work-groups under MAS_CONV_WGS_PER_CU=1: tiles = n * ceil(ho/16) * ceil(wo/16) * cout/128
+MULTI_CASES = [
+    (40, 128, 48, 64, 128, (1, 1, 1, 1), False, 2, True),     # 480 tiles, prologue + residual, a new image at every step of the walk
+    (40, 128, 48, 64, 128, (1, 1, 1, 1), False, 0, False),    # 480 tiles, plain
+    (24, 128, 24, 32, 128, (1, 1, 1, 1), True, 0, False),     # Upsample fold (48 x 64 output), 288 tiles
+    (8, 128, 48, 64, 384, (1, 1, 1, 1), False, 2, False),     # three cout tiles: c0 changes between the tiles a work-group walks
+    (8, 256, 45, 60, 384, (1, 1, 1, 1), False, 0, True),      # ragged tiles, two chunk pairs, residual, 288 tiles
+    (1, 128, 272, 272, 128, (1, 1, 1, 1), False, 2, True),    # 289 tiles of ONE image: the walk stays inside an image
+]
+
+
+def n_tiles(case):
+    n, cin, h, w, cout, pad4, ups, act, has_res = case
+    hl, wl = (2 * h, 2 * w) if ups else (h, w)
+    ho, wo = hl + pad4[0] + pad4[1] - 2, wl + pad4[2] + pad4[3] - 2
+    return n * ((ho + 15) // 16) * ((wo + 15) // 16) * (cout // 128)
 
 
 def silu(u):
@@ -36,7 +55,17 @@ def silu(u):
 
 def main():
     bad = 0
-    for case in CASES:
+    multi = len(sys.argv) > 1 and sys.argv[1] == "multi"
+    cases = MULTI_CASES if multi else CASES
+    if multi:
+        wgs = int(os.environ.get("MAS_CONV_WGS_PER_CU", "0"))
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        assert wgs == 1, "run `stream_check.py multi` with MAS_CONV_WGS_PER_CU=1"
+        for case in cases:
+            assert n_tiles(case) > wgs * cus, (case, n_tiles(case), wgs * cus)
+        print(f"multi-tile mode: grid {wgs * cus} work-groups, tiles per case {[n_tiles(c) for c in cases]}", flush=True)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    for case in cases:
         n, cin, h, w, cout, pad4, ups, act, has_res = case
         g = torch.Generator(device="cpu").manual_seed(hash(case) % 2**31)
         x = torch.randn(n, cin, h, w, generator=g).bfloat16()

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Runs in a child process of tests/test_gpu_wide.py with MAS_CONV_WIDE_MIN_TILES_PER_CU=0 (read once per process), so that
 SMALL shapes take the wide 3x3 kernel (conv3x3_wide.hip: 16x32-pixel tiles, 32-channel chunks, K32 weight image) and can be
-compared with a CPU fp32 convolution of the same bf16-rounded operands.  Prints one line per case; exits non-zero on a mismatch."""
+compared with a CPU fp32 convolution of the same bf16-rounded operands.  Prints one line per case; exits non-zero on a mismatch.
+
+`wide_check.py multi` (run with MAS_CONV_WGS_PER_CU=1: the grid is then ONE work-group per CU): shapes with MORE tiles than
+work-groups, so every work-group really walks 2-3 tiles through the persistent loop bench.py's B=32 launches run (next-tile plan,
+LDS-parked output offsets, double-buffered scale/shift table, cross-tile patch / weight DMA, the vmcnt(32) wait for the previous
+tile's stores).  The launch geometry is asserted (tiles > grid), not assumed."""
 import os
 import sys
 
@@ -26,10 +31,29 @@ CASES = [
     (2, 128, 40, 64, 128, (1, 1, 1, 1), False, 2, False, False),   # GroupNorm+SiLU prologue
     (3, 256, 20, 36, 128, (1, 1, 1, 1), False, 2, True, False),    # prologue, four pairs, residual
     (2, 128, 18, 34, 256, (1, 1, 1, 1), False, 1, False, False),   # affine-only prologue, two cout tiles
-    (40, 128, 32, 32, 128, (1, 1, 1, 1), False, 2, True, False),   # many tiles: every work-group walks several (next-tile prefetch)
+    (40, 128, 32, 32, 128, (1, 1, 1, 1), False, 2, True, False),   # 80 tiles = 80 work-groups, ONE tile each (the multi-tile walk is MULTI_CASES' job)
     (40, 128, 32, 32, 128, (1, 1, 1, 1), False, 0, False, False),
     (2, 256, 32, 64, 128, (1, 1, 1, 1), False, 0, False, True),    # data-gradient packing (in/out swapped, taps flipped): Cout 256 -> Cin 128
 ]
+
+# more tiles than work-groups (grid = 1 work-group per CU under MAS_CONV_WGS_PER_CU=1): tiles = n * ceil(ho/16) * ceil(wo/32) * cout/128
+MULTI_CASES = [
+    (40, 128, 64, 96, 128, (1, 1, 1, 1), False, 2, True, False),   # 480 tiles; consecutive tiles of a work-group lie in DIFFERENT images: ss_stage(nt.n, ss_sel ^ 1)
+    (40, 128, 64, 96, 128, (1, 1, 1, 1), False, 0, False, False),  # 480 tiles, plain
+    (24, 128, 32, 48, 128, (1, 1, 1, 1), True, 0, False, False),   # Upsample fold, 288 tiles
+    (8, 128, 64, 96, 384, (1, 1, 1, 1), False, 2, False, False),   # three cout tiles: c0 changes between the tiles a work-group walks (256 % 3 != 0)
+    (8, 128, 60, 90, 384, (1, 1, 1, 1), False, 0, True, False),    # the same with ragged tile rows / columns and the residual
+    (2, 128, 272, 512, 128, (1, 1, 1, 1), False, 2, True, False),  # 272 tiles per image: consecutive tiles in the SAME image for some work-groups, a new image for others; 3 tiles for 32 of them
+    (24, 256, 64, 96, 128, (1, 1, 1, 1), False, 1, False, True),   # data-gradient packing + affine-only prologue, four chunk pairs, 288 tiles
+    (24, 128, 62, 94, 128, (2, 2, 2, 2), False, 0, False, False),  # pad 2 (64 x 96 output), 288 tiles
+]
+
+
+def n_tiles(case):
+    n, cin, h, w, cout, pad4, ups, act, has_res, tr = case
+    hl, wl = (2 * h, 2 * w) if ups else (h, w)
+    ho, wo = hl + pad4[0] + pad4[1] - 2, wl + pad4[2] + pad4[3] - 2
+    return n * ((ho + 15) // 16) * ((wo + 31) // 32) * (cout // 128)
 
 
 def silu(u):
@@ -38,7 +62,19 @@ def silu(u):
 
 def main():
     bad = 0
-    for case in CASES:
+    multi = len(sys.argv) > 1 and sys.argv[1] == "multi"
+    cases = MULTI_CASES if multi else CASES
+    if multi:
+        # launch geometry (conv3x3_wide.hip launch_wide): grid = min(tiles, MAS_CONV_WGS_PER_CU * CUs)
+        wgs = int(os.environ.get("MAS_CONV_WGS_PER_CU", "0"))
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        assert wgs == 1, "run `wide_check.py multi` with MAS_CONV_WGS_PER_CU=1"
+        grid = wgs * cus
+        for case in cases:
+            assert n_tiles(case) > grid, (case, n_tiles(case), grid)
+        print(f"multi-tile mode: grid {grid} work-groups, tiles per case {[n_tiles(c) for c in cases]}", flush=True)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    for case in cases:
         n, cin, h, w, cout, pad4, ups, act, has_res, tr = case
         g = torch.Generator(device="cpu").manual_seed(hash(case) % 2**31)
         x = torch.randn(n, cin, h, w, generator=g).bfloat16()

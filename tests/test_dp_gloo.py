@@ -245,3 +245,59 @@ def test_grad_reducer_accumulation_and_misuse(tmp_path):
     for step in range(2):
         for k in exp:
             assert np.allclose(got[f"s{step}.{k}"], exp[k], rtol=1e-5, atol=1e-6), (step, k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# codebook re-initialisation across ranks (reference models/modules.py:487-499; ours models/modules.py Codebook._reinit_from_reservoir)
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_kmeans(points, n_clusters, **_kw):
+    """CPU stand-in for models.kmeans.kmeans_fit (whose assignment step is the HIP VQ kernel): a few Lloyd iterations from RANDOM
+    initial points drawn from the process's own RNG -- i.e. rank-dependent, as the reference's per-rank KMeans is"""
+    pts = points.detach().float()
+    cent = pts[torch.randperm(pts.shape[0])[:n_clusters]].clone()
+    for _ in range(5):
+        idx = torch.cdist(pts, cent).argmin(1)
+        for c in range(n_clusters):
+            sel = pts[idx == c]
+            cent[c] = sel.mean(0) if len(sel) else 0.0
+    return cent
+
+
+def _reinit_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    sys.path.insert(0, os.path.join(ROOT, "make-a-scene_amd"))
+    import models.kmeans as KM
+    from models.modules import Codebook
+    seen = {}
+
+    def spy(points, n_clusters, **kw):
+        seen["pool"] = points.detach().clone()
+        return _cpu_kmeans(points, n_clusters, **kw)
+    KM.kmeans_fit = spy
+    torch.manual_seed(100 + rank)                                       # per-rank RNG stream: different reservoirs AND different k-means inits
+    cb = Codebook(16, 8, beta=0.25, init_steps=4, reservoir_size=64)
+    cb.reservoir = torch.randn(64, 8) + rank                            # this rank's latents
+    before = cb.embedding.weight.detach().clone()
+    cb._reinit_from_reservoir()
+    torch.save(dict(pool=seen["pool"], cent=cb.embedding.weight.detach().clone(), before=before, res=cb.reservoir.clone()),
+               os.path.join(out, f"reinit{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_codebook_reinit_is_identical_on_both_ranks(tmp_path):
+    """every rank clusters the all-gathered reservoir (reference modules.py:490-495) -- from its OWN random initial
+    centroids, so without a broadcast the replicas' codebooks would differ.  After `_reinit_from_reservoir` both ranks hold rank
+    0's centroids, computed on the concatenation of both reservoirs in rank order."""
+    out = str(tmp_path)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_reinit_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(out, f"reinit{r}.pt")) for r in (0, 1))
+    pool = torch.cat([r0["res"], r1["res"]], dim=0)
+    assert torch.equal(r0["pool"], pool) and torch.equal(r1["pool"], pool)          # both clustered the same gathered pool
+    assert torch.equal(r0["cent"], r1["cent"])                                      # identical codebooks after the re-init
+    assert not torch.equal(r0["cent"], r0["before"])
+    assert float((r0["cent"].mean(0) - pool.mean(0)).abs().max()) < 1.0            # centroids live where the pooled data lives

@@ -140,7 +140,7 @@ def test_vqgan_loss_adaptive_weight_and_requires_grad_dance():
         m.load_state_dict(O.synth_state_dict(cfg["ddconfig"], 64, 32, seed=0), strict=True)
         m = m.to(dev).train()
         m.quantize.q_counter = m.quantize.q_re_end
-        loss_fn = VQLPIPSWithDiscriminator(disc_start=5, disc_weight=0.8).to(dev)
+        loss_fn = VQLPIPSWithDiscriminator(disc_start=5, disc_weight=0.8, perceptual_loss=None, face_loss=None).to(dev)   # L1 + GAN only: what the oracle restates
         sd_d = LO.synth_disc_state_dict(seed=3)
         loss_fn.discriminator.load_state_dict(sd_d, strict=True)
         img = O.synth_image_batch(2, 3, 64, seed=4).to(dev)
@@ -244,9 +244,9 @@ def test_vqgan_loss_with_lpips_term():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         torch.manual_seed(0)
-        lf = VQLPIPSWithDiscriminator(disc_start=0, perceptual_loss="lpips").cuda()
+        lf = VQLPIPSWithDiscriminator(disc_start=0).cuda()                  # default construction
         torch.manual_seed(0)
-        l0 = VQLPIPSWithDiscriminator(disc_start=0).cuda()
+        l0 = VQLPIPSWithDiscriminator(disc_start=0, perceptual_loss=None).cuda()
     l0.load_state_dict({k: v for k, v in lf.state_dict().items() if not k.startswith("perceptual_loss.")})
     rs = np.random.RandomState(4)
     img = torch.from_numpy(rs.rand(2, 3, 64, 64).astype(np.float32)).cuda()

@@ -102,6 +102,10 @@ def test_img256_bf16_vs_reference_golden(golden_dir):
     assert e_dec < 5e-2 and l2_dec < 4e-2
     assert abs(float(loss) - float(g["loss"])) < 3e-2 * abs(float(g["loss"]))
     assert e_gd < 1e-1
+    # total gradient norm: measured 11.11 vs 11.19 (0.7 %).  The first encoder layer's gradient (e_ge, printed) differs by tens of
+    # percent END TO END because ~5 % of the codes differ downstream of the bf16 latents; with the reference's dL/dz injected the
+    # same gradient is held to 5e-2 rel-L2 (tests/test_gpu_parity_r3.py::test_img256_bf16_encoder_backward_with_reference_dz)
+    assert abs(tot - float(g["gradnorm_total"])) < 2e-2 * float(g["gradnorm_total"])
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
 
 
@@ -112,12 +116,14 @@ def _silu(u):
     return u * torch.sigmoid(u)
 
 
-def test_dominant_conv_real_shape_vs_cpu_fp32():
-    """128->128 3x3 at 256x256, bf16 (45 % of a step).  N=2 so the launch takes the 16x16-pixel / 512-thread geometry
-    (chosen when it yields >= 2 tiles per CU) -- the one bench.py's roofline line times.  Forward (plain and with the
-    GroupNorm+SiLU loader), data gradient and weight/bias gradient (plain and with the loader) against F.conv2d /
-    autograd in fp32 on the CPU, given the same bf16-rounded operands.  Outputs are bf16: tolerance 1e-2 of max|ref|
-    (0.4 % rounding of the largest value + fp32 accumulation order); fp32 weight gradients: 2e-3."""
+def test_stream_conv_real_shape_k64_vs_cpu_fp32():
+    """128->128 3x3 at 256x256, bf16, N=2, with a PRE-PACKED K64 weight image: the call therefore stays on the kernels that read
+    K64 -- conv3x3_stream.hip (16x16-pixel tiles, 512 of them, one per work-group) -- NOT on the wide kernel bench.py's B=32
+    launches take (that one, through the default dispatch and with several tiles per work-group, is
+    tests/test_gpu_parity_r3.py::test_dominant_conv_wide_real_shape_vs_cpu_fp32).  Forward (plain and with the GroupNorm+SiLU
+    loader), data gradient and weight/bias gradient (plain and with the loader) against F.conv2d / autograd in fp32 on the
+    CPU, given the same bf16-rounded operands.  Outputs are bf16: tolerance 1e-2 of max|ref| (0.4 % rounding of the largest
+    value + fp32 accumulation order); fp32 weight gradients: 2e-3."""
     from mas_hip import ops
     dev = _dev()
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))

@@ -1,7 +1,8 @@
 """conv3x3_stream.hip (the stream-scheduled 3x3 / stride-1 / bf16 kernel that carries the FLOPs) against a CPU fp32
 convolution at SMALL shapes: ragged tiles, several pairs / cout tiles, upsample fold, pad 2, residual, GroupNorm(+SiLU)
-prologue, many tiles per work-group -- in both epilogue modes (deferred stores = default, immediate stores).
-The real-shape check of the same kernel is tests/test_gpu_parity_r2.py::test_dominant_conv_real_shape_vs_cpu_fp32."""
+prologue -- in both epilogue modes (deferred stores = default, immediate stores) --, and the same with more tiles than
+work-groups (`test_stream_kernel_persistent_multi_tile_walk_vs_cpu`).  The real-shape check of the same kernel is
+tests/test_gpu_parity_r2.py::test_stream_conv_real_shape_k64_vs_cpu_fp32 (a K64 pre-packed image keeps the launch on this kernel)."""
 import os
 import subprocess
 import sys
@@ -23,6 +24,19 @@ def test_stream_kernel_small_shapes_vs_cpu(mode):
     print(r.stdout[-4000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("ok   ") >= 12
+
+
+@pytest.mark.parametrize("mode", ["3", "1"])
+def test_stream_kernel_persistent_multi_tile_walk_vs_cpu(mode):
+    """one work-group per CU, 288-480 tiles per launch: every work-group walks 2 tiles (asserted from the launch geometry)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, MAS_CONV_STREAM=mode, MAS_CONV_STREAM_MIN_TILES_PER_CU="0", MAS_CONV_WGS_PER_CU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "stream_check.py"), "multi"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    print(r.stdout[-4000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok   ") >= 6 and "multi-tile mode" in r.stdout
 
 
 def test_stream_kernel_is_the_one_that_runs():

@@ -1,7 +1,8 @@
 """conv3x3_wide.hip (16x32-pixel tiles, 32-channel chunks, wave tile 128 couts x 64 pixels, K32 weight image) against a CPU fp32
 convolution at SMALL shapes: ragged tiles, several pairs / cout tiles, upsample fold, pad 2, residual, GroupNorm(+SiLU) prologue,
-many tiles per work-group, data-gradient packing.  The real-shape check of the same kernel is
-tests/test_gpu_parity_r2.py::test_dominant_conv_real_shape_vs_cpu_fp32 (the dispatch picks it there)."""
+data-gradient packing (one tile per work-group), and -- `test_wide_kernel_persistent_multi_tile_walk_vs_cpu` -- the same
+features with MORE tiles than work-groups (the persistent next-tile path bench.py's B=32 launches run).  The real-shape check of
+the same kernel through the default dispatch is tests/test_gpu_parity_r3.py::test_dominant_conv_wide_real_shape_vs_cpu_fp32."""
 import os
 import subprocess
 import sys
@@ -22,6 +23,20 @@ def test_wide_kernel_small_shapes_vs_cpu():
     print(r.stdout[-4000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("ok   ") >= 13
+
+
+def test_wide_kernel_persistent_multi_tile_walk_vs_cpu():
+    """one work-group per CU (MAS_CONV_WGS_PER_CU=1) and 288-544 tiles per launch, so every work-group walks
+    2-3 tiles: next-tile plan, LDS-parked output offsets, double-buffered scale/shift table (same image / new image), cout-tile
+    change mid-walk, cross-tile DMA, vmcnt(32) store wait.  The helper asserts tiles > grid from the launch geometry."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, MAS_CONV_WIDE_MIN_TILES_PER_CU="0", MAS_CONV_WIDE_ANY_WIDTH="1", MAS_CONV_WGS_PER_CU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "wide_check.py"), "multi"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    print(r.stdout[-4000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok   ") >= 8 and "multi-tile mode" in r.stdout
 
 
 def test_weight_layout_query_and_k64_is_always_accepted():

@@ -195,3 +195,57 @@ def test_lpips_oracle_vs_reference_golden(golden_dir):
     m.load_state_dict(sd, strict=True)
     assert not any(p.requires_grad for p in m.parameters())
     assert isinstance(losses.LPIPSWithObject(), losses.LPIPS)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round-3 fixtures (tests/golden/make_golden_r3.py): the oracle reproduces what the GPU tests will be held to
+# ---------------------------------------------------------------------------------------------------------------------
+def test_img256_encoder_backward_fixture_matches_oracle(golden_dir):
+    """vq_img256_bwd.npz: dL/dz at the output of quant_conv and the encoder gradients of the reference's 256x256 B=1 run."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    from r3_spec import ENC_GRADS
+    g = np.load(os.path.join(golden_dir, "vq_img256_bwd.npz"))
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    x = O.synth_image_batch(1, 3, 256, seed=1)
+    sd = O.synth_state_dict(IMG_DD, 8192, 256, seed=1)
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    taps = {}
+    dec, q_loss, idx, z = O.vqbase_forward(sd, x, IMG_DD, training=True, taps=taps)
+    taps["z"].retain_grad()
+    O.recon_vq_loss(x, dec, q_loss).backward()
+    dz = taps["z"].grad
+    assert float((dz - torch.from_numpy(g["dz"])).abs().max()) < 2e-3 * float(np.abs(g["dz"]).max())
+    for k, sl in ENC_GRADS.items():
+        got, ref = sd[k].grad.numpy()[sl], g["grad:" + k]
+        assert got.shape == ref.shape, k
+        assert float(np.abs(got - ref).max()) < 5e-3 * float(np.abs(ref).max()) + 1e-9, k
+    enc = np.sqrt(sum(float((v.grad.double() ** 2).sum()) for k, v in sd.items()
+                      if (k.startswith("encoder.") or k.startswith("quant_conv.")) and v.grad is not None))
+    assert abs(enc - float(g["gradnorm_encoder"])) < 1e-3 * enc
+
+
+def test_transformer_w1024_fixture_matches_oracle(golden_dir):
+    """transformer_w1024.npz: MakeAScene at config 4's width (2 layers, d=1024, 16 heads, S=1536, B=1), logits + loss + gradients."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    from r3_spec import LOGITS_SUB, TR1024, TR_GRADS
+    g = np.load(os.path.join(golden_dir, "transformer_w1024.npz"))
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    sd = TO.synth_transformer_state_dict(TR1024, seed=9)
+    for k, v in sd.items():
+        if v.is_floating_point() and k != "transformer.mask":
+            v.requires_grad_(True)
+    text, seg, img = TO.synth_tokens(TR1024, batch=1, seed=9)
+    logits = TO.make_a_scene_forward(sd, TR1024, text, seg, img)
+    assert tuple(logits.shape) == (1, 1024, 8192)
+    loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), img.reshape(-1))
+    loss.backward()
+    amax = float(g["logits_absmax"])
+    assert float(np.abs(logits.detach().numpy()[LOGITS_SUB] - g["logits_sub"]).max()) < 1e-4 * amax
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    for k, sl in TR_GRADS.items():
+        got, ref = sd[k].grad.numpy()[sl], g["grad:" + k]
+        assert float(np.abs(got - ref).max()) < 2e-3 * float(np.abs(ref).max()) + 1e-12, k

@@ -112,3 +112,37 @@ def test_generate_sampling_modes(monkeypatch):
         _, lg0 = m.generate(text, seg, cond_scale=0.0, img_tokens=img, return_logits=True)
         _, lgu = m.generate(torch.zeros_like(text), seg, img_tokens=img, return_logits=True)
         assert float((lg0 - lgu).abs().max()) < 1e-4 * float(lgu.abs().max())
+
+
+def test_cache_entries_that_are_no_longer_views_still_decode_correctly(monkeypatch):
+    """a cache entry that was cloned / made contiguous / index_select'ed (beam or batch reorder) has lost its backing
+    buffer (``_base`` None, layout [B, H, L, hd]); it must be rebuilt from its contents, not reinterpreted as [B, L, H*hd] --
+    and a multi-token extend past twice the capacity must not overflow the layer-output buffer."""
+    _cpu_ops(monkeypatch)
+    m, text, seg, img = _tiny()
+    with torch.no_grad():
+        emb = m._prompt_embeddings(text, seg)
+        step = lambda toks: m.image_token_embedding(toks) + m.get_image_pos_embeddings(toks)
+        ref_out, ref_cache = m.transformer(emb, None, cache={}, use_cache=True)
+        nxt = torch.cat([emb, step(img[:, :1])], dim=1)
+        ref2, _ = m.transformer(nxt, None, cache=ref_cache, use_cache=True)
+        # the same with every cache entry detached from its buffer, in three different ways
+        _, cache = m.transformer(emb, None, cache={}, use_cache=True)
+        perm = torch.tensor([0, 1])
+        broken = {i: (c[0].clone(), c[1].contiguous(), c[2].index_select(0, perm), c[3].clone()) for i, c in cache.items()}
+        assert all(t._base is None for c in broken.values() for t in c)
+        got2, cache2 = m.transformer(nxt, None, cache=broken, use_cache=True)
+        assert float((got2 - ref2).abs().max()) < 1e-5 * float(ref2.abs().max())
+        # batch reorder: swapping the two samples' cache entries swaps the outputs
+        swap = torch.tensor([1, 0])
+        _, cache = m.transformer(emb, None, cache={}, use_cache=True)
+        swapped = {i: tuple(t.index_select(0, swap) for t in c) for i, c in cache.items()}
+        got3, _ = m.transformer(nxt.index_select(0, swap), None, cache=swapped, use_cache=True)
+        assert float((got3 - ref2.index_select(0, swap)).abs().max()) < 1e-5 * float(ref2.abs().max())
+        # a multi-token extend far past 2x the capacity (12 -> 28 positions in one call)
+        many = torch.cat([emb, step(img)], dim=1)
+        full, _ = m.transformer(many, None, cache={}, use_cache=True)
+        _, cache = m.transformer(emb, None, cache={}, use_cache=True)
+        got4, cache4 = m.transformer(many, None, cache=cache, use_cache=True)
+        assert got4.shape == (2, 16, 64) and cache4[0][3].shape == (2, 28, 64)
+        assert float((got4 - full[:, 12:]).abs().max()) < 1e-5 * float(full.abs().max())
