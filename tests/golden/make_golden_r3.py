@@ -7,7 +7,10 @@
   L1 + q_loss; the script asserts its z / loss equal the committed fixture's) with what the encoder-backward parity test needs:
   ``dz`` = dL/dz at the output of ``quant_conv`` (reference models/vqvae.py:21-22), and the reference's gradients of a few
   encoder parameters.  Injecting the REFERENCE's dz into our encoder backward separates kernel error from the codebook-index
-  flips bf16 latents cause downstream.
+  flips bf16 latents cause downstream.  ``refbf16_l2:<key>`` / ``refbf16_max:<key>``: the deviation of the
+  reference's OWN encoder gradients under ``torch.autocast("cpu", bfloat16)`` from its fp32 ones, same dz -- the yardstick for
+  what bf16 storage costs this 23-layer backward (GroupNorm's mean-subtraction cancels most of each gradient, so rounding
+  noise is amplified towards the first layers: 3 % at quant_conv, 10 % at encoder.model.0).
 * ``transformer_w1024.npz`` -- MakeAScene (reference models/transformer.py:275-378) at BASELINE config 4's WIDTH: 2 layers,
   d=1024, 16 heads (head_dim 64), 256 text + 256 seg + 1024 image tokens (S=1536), vocabularies of config 4, B=1, fp32:
   sub-sampled logits, the loss and sub-sampled gradients (LN / GELU / Linear / colsum at d=1024, rows=1536).
@@ -64,6 +67,17 @@ def img256_bwd():
         out["grad:" + k] = names[k].grad.numpy()[sl].copy()
     enc_norm = np.sqrt(sum(float((p.grad.double() ** 2).sum()) for n, p in model.named_parameters()
                            if (n.startswith("encoder.") or n.startswith("quant_conv.")) and p.grad is not None))
+    # yardstick: the REFERENCE's own encoder under torch.autocast(bfloat16) on CPU (bf16 convolutions, fp32 GroupNorm: PyTorch's
+    # autocast policy), same weights, same input, same injected dz -- how far a bf16 run of the reference is from its own fp32 run
+    model.zero_grad(set_to_none=True)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        zb = model.quant_conv(model.encoder(x))
+    zb.backward(z.grad.to(zb.dtype))
+    for k, sl in ENC_GRADS.items():
+        gb, gf = names[k].grad.double().numpy()[sl], out["grad:" + k].astype(np.float64)
+        out["refbf16_l2:" + k] = np.linalg.norm(gb - gf) / np.linalg.norm(gf)
+        out["refbf16_max:" + k] = np.abs(gb - gf).max() / np.abs(gf).max()
+        print("  reference bf16-autocast vs fp32  %-36s rel-L2 %.3e max-rel %.3e" % (k, out["refbf16_l2:" + k], out["refbf16_max:" + k]))
     np.savez_compressed(os.path.join(HERE, "vq_img256_bwd.npz"), gradnorm_encoder=enc_norm, torch_version=torch.__version__, **out)
     print("vq_img256_bwd.npz: |dz| max %.3e, encoder gradient norm %.5f" % (float(np.abs(out["dz"]).max()), enc_norm))
 

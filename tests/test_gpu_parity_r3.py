@@ -5,8 +5,9 @@
   GN+SiLU+residual, the data-gradient packing, and the LDS-DMA weight gradient, against F.conv2d / autograd in fp32 on the CPU;
 * VQBASE (conf/img_config.yaml block) in bf16 at B=16 -- the smallest batch at which the 256x256 layers take the multi-tile walk --
   against oracle/vq_oracle.py on the same batch (latents, index agreement, decoder fed the oracle's z_q);
-* the encoder BACKWARD with the reference's own dL/dz injected at quant_conv's output (tests/golden/vq_img256_bwd.npz), B=1 and
-  the image replicated 16x (the benched wide-dgrad / wgrad-dma paths): kernel error without the index flips of bf16 latents;
+* the encoder BACKWARD with the reference's own dL/dz injected at quant_conv's output (tests/golden/vq_img256_bwd.npz), in fp32,
+  in bf16 at B=1 and with the image replicated 16x (the benched wide-dgrad / wgrad-dma paths): kernel error without the index
+  flips of bf16 latents, measured against the reference's OWN bf16-autocast deviation;
 * MakeAScene at config 4's width (2 layers, d=1024, 16 heads, S=1536) against the reference's fp32 output
   (tests/golden/transformer_w1024.npz), in fp32 and under bf16 autocast.
 """
@@ -182,38 +183,44 @@ def test_img256_bf16_multi_tile_batch_vs_oracle():
 # --------------------------------------------------------------------------------------------------------------
 # 3. encoder backward under the REFERENCE's dL/dz
 # --------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("copies", [1, 16])
-def test_img256_bf16_encoder_backward_with_reference_dz(golden_dir, copies):
-    """dL/dz recorded from the reference's own backward (vq_img256_bwd.npz) is injected at quant_conv's output of OUR bf16
+@pytest.mark.parametrize("mode,copies", [("fp32", 1), ("bf16", 1), ("bf16", 16)])
+def test_img256_encoder_backward_with_reference_dz(golden_dir, mode, copies):
+    """dL/dz recorded from the reference's own backward (vq_img256_bwd.npz) is injected at quant_conv's output of OUR
     encoder: what differs from the reference's encoder gradients is then kernel / storage error only -- not the different codes
     a 1 % latent perturbation selects downstream (the 45 % seen on encoder.model.0.weight end to end in round 2).
     copies=16: the same image 16 times (BatchNorm's batch statistics are those of one copy; every parameter gradient is 16x the
     reference's), which moves the 256x256 / 128x128 layers onto the kernels and the multi-tile walk bench.py times.
-    Tolerances (bf16 storage of every activation and activation gradient across 23 layers, fp32 accumulation): rel-L2 of each
-    recorded gradient < 5e-2, max-rel < 1e-1, encoder gradient norm within 2 %."""
+    fp32 (exact-fp32 MFMA kernels): every recorded gradient within 5e-3 rel-L2 / 1e-2 max-rel -- the kernels are right.
+    bf16: GroupNorm's backward subtracts the group means, so most of each gradient cancels and rounding noise is amplified
+    layer by layer towards the input (measured rel-L2: 3.0e-2 at quant_conv.0 ... 1.0e-1 at encoder.model.0.weight, 1.3e-1 at its
+    bias).  The yardstick is the reference ITSELF under torch.autocast(bfloat16) on the CPU, recorded in the fixture
+    (3.8e-2 ... 1.0e-1, 1.2e-1): each of our gradients must be within 1.5x of the reference's own bf16 deviation (floor 5e-2),
+    and the encoder gradient norm within 2 % of the fp32 reference."""
     sys.path.insert(0, golden_dir)
     from r3_spec import ENC_GRADS
     from oracle.vq_oracle import synth_image_batch
     dev = _dev()
     g = np.load(os.path.join(golden_dir, "vq_img256_bwd.npz"))
-    m = _build(IMG, 1, torch.bfloat16)
+    m = _build(IMG, 1, torch.float32 if mode == "fp32" else torch.bfloat16)
     x = synth_image_batch(1, 3, 256, seed=1).repeat(copies, 1, 1, 1).to(dev)
     z = m.quant_conv(m.encoder(x))
     z.backward(torch.from_numpy(g["dz"]).repeat(copies, 1, 1, 1).to(dev))
     torch.cuda.synchronize()
     params = dict(m.named_parameters())
-    worst_l2 = worst_max = 0.0
+    bad = []
     for k, sl in ENC_GRADS.items():
         got = params[k].grad.detach().float().cpu()[sl] / copies
         e2, em = rel_l2(got, g["grad:" + k]), relerr(got, g["grad:" + k])
-        print("  copies=%d %-36s rel-L2 %.3e max-rel %.3e" % (copies, k, e2, em))
-        worst_l2, worst_max = max(worst_l2, e2), max(worst_max, em)
+        r2, rm = float(g["refbf16_l2:" + k]), float(g["refbf16_max:" + k])
+        lim2, limm = (5e-3, 1e-2) if mode == "fp32" else (max(1.5 * r2, 5e-2), max(1.5 * rm, 5e-2))
+        print("  %s copies=%d %-36s rel-L2 %.3e max-rel %.3e   (reference's own bf16 autocast: %.3e / %.3e)" % (mode, copies, k, e2, em, r2, rm))
+        if e2 > lim2 or em > limm:
+            bad.append((k, e2, em, lim2, limm))
     enc = np.sqrt(sum(float((p.grad.double() ** 2).sum()) for n_, p in m.named_parameters()
                       if (n_.startswith("encoder.") or n_.startswith("quant_conv.")) and p.grad is not None)) / copies
-    print("encoder backward under the reference dz (copies=%d): worst rel-L2 %.3e, worst max-rel %.3e, gradient norm %.5f vs %.5f"
-          % (copies, worst_l2, worst_max, enc, float(g["gradnorm_encoder"])))
-    assert worst_l2 < 5e-2 and worst_max < 1e-1
-    assert abs(enc - float(g["gradnorm_encoder"])) < 2e-2 * float(g["gradnorm_encoder"])
+    print("encoder backward under the reference dz (%s, copies=%d): gradient norm %.5f vs %.5f" % (mode, copies, enc, float(g["gradnorm_encoder"])))
+    assert not bad, bad
+    assert abs(enc - float(g["gradnorm_encoder"])) < (2e-3 if mode == "fp32" else 2e-2) * float(g["gradnorm_encoder"])
 
 
 # --------------------------------------------------------------------------------------------------------------
