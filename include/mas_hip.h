@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAS_ABI_VERSION 2
+#define MAS_ABI_VERSION 3
 
 enum { MAS_OK = 0, MAS_EINVAL = -1, MAS_EUNSUPPORTED = -2, MAS_ELAUNCH = -3, MAS_EWORKSPACE = -4 };
 enum { MAS_F32 = 0, MAS_BF16 = 1 };
@@ -131,12 +131,27 @@ int mas_conv_fwd_stats(const MasConvDesc* d, const void* x, const float* scale_s
 int mas_gn_stats_from_partials(const float* partial, int N, int HW, int C, int G, int rows, float eps, const float* gamma,
                                const float* beta, float* mean_rstd, float* scale_shift, void* stream);
 
+/* Activation side output: mas_conv_fwd_act is mas_conv_fwd (act != NONE) that ALSO writes the activated input it forms in its loader,
+ * act_out [N,H,W,Cin] in_dtype = act(x * scale + shift) rounded to in_dtype -- exactly the operand the weight gradient of the same
+ * convolution needs (autograd of modules.py:121-128 + the F.conv2d that follows), so that mas_conv_wgrad can run on act_out with
+ * act = NONE instead of recomputing GroupNorm+SiLU in its loader.  Every pixel is written by exactly one tile (deterministic).
+ * Supported iff mas_conv_act_out_supported(d) != 0 (bf16 3x3 stride-1 "same" convolutions on the wide kernel; act_out < 2 GiB);
+ * act_out == NULL makes it mas_conv_fwd.                                                                                            */
+int mas_conv_act_out_supported(const MasConvDesc* d);
+int mas_conv_fwd_act(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed,
+                     const float* bias, const void* residual, void* y, void* act_out, void* stream);
+
 /* ---- convolution weight gradient  (autograd of the F.conv2d sites above)
  *   dw [Cout][ks][ks][Cin] fp32 (caller zero-fills; accumulated with fp32 atomics),
  *   dbias [Cout] fp32 or NULL (same).  x / scale_shift / act as in mas_conv_fwd
  *   (the activated input is recomputed in the loader, never stored).                   */
 int mas_conv_wgrad(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy,
                    float* dw, float* dbias, void* stream);
+/* Commit of a weight gradient: acc = the zero-initialised accumulator handed to mas_conv_wgrad as dw ([Cout][ks][ks][Cin] fp32,
+ * immediately followed by [Cout] bias sums when dbias != NULL) -> dw_oihw [Cout][Cin][ks][ks] (nn.Conv2d.weight.grad's layout),
+ * dbias [Cout]; acc is zeroed again while it is read, so ONE scratch per stream serves every convolution of a step without fill
+ * launches (the caller still owns it).                                                                                              */
+int mas_wgrad_commit(float* acc, float* dw_oihw, float* dbias, int Cout, int Cin, int ks, void* stream);
 
 /* ---- vector quantiser  (replaces Codebook.forward's distance / argmin / gather / loss,
  * modules.py:501-509; never materialises d[M,K]).

@@ -32,6 +32,7 @@ struct WideParams {
     unsigned long long* dbg;                   // -DW_TIMELINE builds only
     const unsigned char* x; const float* ss; const unsigned char* w; const float* bias; const unsigned char* res; unsigned char* y;
     float* stats;                              // optional [N][tiles_h * tiles_w][Cout][2]: per-tile sum / sum of squares of the bf16 OUTPUT (the consumer's GroupNorm statistics)
+    unsigned char* act_out;                    // optional [N,H,W,Cin] bf16 (ACT only): the activated input, written once per pixel as a side output
     int N, H, W, Cin, Ho, Wo, Cout;
     int Hl, Wl, pad_top, pad_left, upsample, act;
     int n_chunks, Cout_pad, tiles_h, tiles_w, n_ct;
@@ -81,8 +82,14 @@ __device__ __forceinline__ void w_wait_barrier(int n) {   // n is a compile-time
 
 // ACT: GroupNorm(+SiLU) prologue (in-place activation of the raw patch).  RES: residual add in the epilogue.
 // STATS: per-tile sum / sum of squares of the output channels (the consumer's GroupNorm statistics) written to p.stats.
-template <bool ACT, bool RES, bool STATS>
+// AOUT (ACT only): the activated input a = act(x * scale + shift), bf16, is also written to p.act_out -- every in-image pixel by
+//        exactly one tile (the tile whose OUTPUT pixels it lies under; cout tile 0 only).  The weight gradient of the same
+//        convolution then reads `a` with a prologue-free loader instead of recomputing GroupNorm+SiLU on x (conv_wgrad_dma.hip:
+//        0.655 ms plain vs 0.79 ms with the prologue at 128->128 @256^2).  The values pass through this thread's registers on
+//        their way back to LDS anyway: the side output costs two VALU and one 16-byte store per slot.
+template <bool ACT, bool RES, bool STATS, bool AOUT = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
+    static_assert(ACT || !AOUT, "the activation side output needs the prologue");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const wbuf = smem + W_WBUF;
     unsigned char* const patch = smem + W_PBUF;
@@ -97,6 +104,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(RES ? p.res : p.y), 0, RES ? out_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.w), 0,
                                                                            (unsigned)(9 * p.n_chunks * p.Cout_pad * 64), 0x00020000);
+
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(AOUT ? p.act_out : p.y, 0,
+                                                                           AOUT ? (unsigned)((size_t)p.N * img_bytes) : 0u, 0x00020000);
+    const int img_b = (int)img_bytes;           // (AOUT: N * img_bytes < 2^31, checked by the host)
 
     // ---- tiles: persistent work-group, static stride.  Divisions by the (runtime) tile-grid extents are multiply-high by
     //      host-made reciprocals: hipcc's generic 32-bit division keeps ~10 SGPRs of loop-invariant temporaries alive per
@@ -181,7 +192,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
             sc[2 * q4] = v[0]; sh[2 * q4] = v[1]; sc[2 * q4 + 1] = v[2]; sh[2 * q4 + 1] = v[3];
         }
     };
-    auto p_activate = [&](unsigned inb_mask, int buf) {   // padding pixels were written as zeros by the DMA and stay zero
+    // (side output) rs_a: one descriptor over the whole act_out tensor; a store adds the image's byte offset + the chunk's as its
+    // scalar offset.  aout_soff < 0: this tile does not write (cout tile != 0)
+    auto p_activate = [&](unsigned inb_mask, int buf, const int (&vo_)[W_NSLOT], int aout_soff, __amdgpu_buffer_rsrc_t rs_a) {   // padding pixels were written as zeros by the DMA and stay zero
 #pragma unroll
         for (int k = 0; k < W_NSLOT; ++k) {
             int q, pr, pc;
@@ -198,6 +211,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                 for (int e = 0; e < 8; ++e) tv[e] = (bf16_t)((float)tv[e] * sc[e] + sh[e]);
             }
             *reinterpret_cast<u32x4*>(dst) = v;
+            if constexpr (AOUT) {
+                // interior of the tile (the pixels under this tile's outputs): each image pixel belongs to exactly one tile.
+                // vo_[k] addresses the SOURCE slot sl = (lane & 3) ^ ((q >> 2) & 3) of the pixel inside its image; the activated
+                // values are LOGICAL slot lane & 3: flip the two slot bits back
+                const bool inner = (unsigned)(pr - p.pad_top) < 16u && (unsigned)(pc - p.pad_left) < 32u && aout_soff >= 0;
+                const int so = inner ? (vo_[k] ^ (((q >> 2) & 3) << 4)) : W_OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_a, so, aout_soff < 0 ? 0 : aout_soff, 0);
+            }
         }
     };
 
@@ -252,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
         ss_stage(n_cur, 0);
         W_WAIT_BARRIER(0);                       // the raw patch of chunk 0 has landed for every wave, the table is visible
         ss_fetch(0, 0);
-        p_activate(inb_cur, 0);
+        p_activate(inb_cur, 0, vo, c0_cur == 0 ? n_cur * img_b : -1, rs_a);
     }
     if (p.stagger > 0) {
         const int n = (int)((blockIdx.x * 5u) % 8u) * p.stagger;
@@ -309,26 +330,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                     } else w_wait_barrier(allow);      // one store, older than this stage's weight DMA
                 }
                 if (pair < 2) WTS(2 + 3 * (pair * 6 + s));
-                if (s == 2 && last_pair && has_next) {        // the next tile's plan (used by the chunk-B stages 3, 4); without a next
-                    const Tile nt = decode(next_tile);        // tile the current one is re-fetched, harmlessly
-                    int ob_n[4];
-                    make_plan(nt, vo, inb_nxt, ob_n);
-                    *reinterpret_cast<u32x4*>(smem + W_NEXT + tid * 16) = u32x4{(unsigned)ob_n[0], (unsigned)ob_n[1], (unsigned)ob_n[2], (unsigned)ob_n[3]};
-                    c0_nxt = nt.c0; n_nxt = nt.n;
-                    if constexpr (ACT) ss_stage(nt.n, ss_sel ^ 1);      // visible after the next barrier, first read three stages later
-                    rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.x) + (size_t)nt.n * img_bytes, 0,
-                                                             (unsigned)img_bytes, 0x00020000);
-                }
-                // ---- GroupNorm(+SiLU) in place on the NEXT chunk's raw patch (all of it has landed: allowance 0 above)
-                if constexpr (ACT) {
-                    if (kh == 2) {
-                        if (cb == 0) ss_fetch(ss_sel, ciA + 32);
-                        else if (last_pair) ss_fetch(ss_sel ^ 1, 0);
-                        else ss_fetch(ss_sel, ciA + 64);
-                        p_activate((cb == 1 && last_pair) ? inb_nxt : inb_cur, cb ^ 1);
-                        asm volatile("" ::: "memory");
+                // ---- the next tile's plan, and GroupNorm(+SiLU) in place on the NEXT chunk's raw patch (all of it has landed: allowance 0
+                //      above).  Order: plan first (the shipped schedule) -- except with the activation side output, whose stores of
+                //      chunk B of the last pair still address the CURRENT tile through `vo`
+                auto plan_blk = [&]() {
+                    if (s == 2 && last_pair && has_next) {        // the next tile's plan (used by the chunk-B stages 3, 4); without a next
+                        const Tile nt = decode(next_tile);        // tile the current one is re-fetched, harmlessly
+                        int ob_n[4];
+                        make_plan(nt, vo, inb_nxt, ob_n);
+                        *reinterpret_cast<u32x4*>(smem + W_NEXT + tid * 16) = u32x4{(unsigned)ob_n[0], (unsigned)ob_n[1], (unsigned)ob_n[2], (unsigned)ob_n[3]};
+                        c0_nxt = nt.c0; n_nxt = nt.n;
+                        if constexpr (ACT) ss_stage(nt.n, ss_sel ^ 1);      // visible after the next barrier, first read three stages later
+                        rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.x) + (size_t)nt.n * img_bytes, 0,
+                                                                 (unsigned)img_bytes, 0x00020000);
                     }
-                }
+                };
+                auto act_blk = [&]() {
+                    if constexpr (ACT) {
+                        if (kh == 2) {
+                            if (cb == 0) ss_fetch(ss_sel, ciA + 32);
+                            else if (last_pair) ss_fetch(ss_sel ^ 1, 0);
+                            else ss_fetch(ss_sel, ciA + 64);
+                            const bool nxt = cb == 1 && last_pair;                 // chunk 0 of the NEXT tile (its plan is in `vo` since stage 2)
+                            int aout_soff = -1;
+                            if constexpr (AOUT) {
+                                const int ch_off = cb == 0 ? (ciA + 32) * 2 : (last_pair ? 0 : (ciA + 64) * 2);
+                                aout_soff = (nxt ? c0_nxt : c0_cur) == 0 ? (nxt ? n_nxt : n_cur) * img_b + ch_off : -1;
+                            }
+                            p_activate(nxt ? inb_nxt : inb_cur, cb ^ 1, vo, aout_soff, rs_a);
+                            asm volatile("" ::: "memory");
+                        }
+                    }
+                };
+                if constexpr (AOUT) { act_blk(); plan_blk(); } else { plan_blk(); act_blk(); }
                 // ---- weight DMA for the next stage
                 {
                     const int tn = (s < 5) ? (pair * 2 + (s + 1) / 3) * 9 + ((s + 1) % 3) * 3 : (last_pair ? 0 : (pair + 1) * 18);
@@ -484,9 +518,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
     }
 }
 
-template <bool ACT, bool RES, bool STATS>
+template <bool ACT, bool RES, bool STATS, bool AOUT = false>
 int launch_wide(const WideParams& p, hipStream_t s) {
-    auto kern = conv3x3_wide_kernel<ACT, RES, STATS>;
+    auto kern = conv3x3_wide_kernel<ACT, RES, STATS, AOUT>;
     static mas_devmask_t attr_mask{0};
     unsigned long long attr_bit;
     if (mas_attr_needed(attr_mask, &attr_bit)) {
@@ -529,11 +563,22 @@ bool mas_conv3x3_wide_eligible(const MasConvDesc* d) {
 // rows per image of the statistics table the wide kernel can fill for this convolution (its 16x32-pixel tiles)
 int mas_conv3x3_wide_stat_rows(const MasConvDesc* d) { return mas_cdiv(d->Ho, 16) * mas_cdiv(d->Wo, 32); }
 
+// Can the wide kernel also write the activated input (MasConvDesc.act != NONE) as a side output?
+bool mas_conv3x3_wide_act_out_ok(const MasConvDesc* d) {
+    static const int on = mas_env_int("MAS_CONV_ACT_OUT", 1);
+    if (!on || d->act == MAS_ACT_NONE || d->upsample || !mas_conv3x3_wide_eligible(d)) return false;
+    if (d->Ho != d->H || d->Wo != d->W) return false;                       // "same" convolutions: tile interiors partition the input image
+    return (long long)d->N * d->H * d->W * d->Cin * 2 < 0x7fffffffLL;      // one descriptor + 31-bit offsets over the whole tensor
+}
+
 int mas_conv3x3_wide_launch(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed, const float* bias,
-                            const void* residual, void* y, float* stats, hipStream_t s) {
+                            const void* residual, void* y, float* stats, void* act_out, hipStream_t s) {
     WideParams p;
     p.dbg = nullptr;
     p.stats = stats;
+    p.act_out = (unsigned char*)act_out;
+    if (act_out && (stats || !mas_conv3x3_wide_act_out_ok(d)))
+        MAS_FAIL(MAS_EUNSUPPORTED, "conv3x3_wide: no activation side output for this convolution (mas_conv_act_out_supported == 0, or fused statistics requested)");
 #ifdef W_TIMELINE
     if (const char* e = getenv("MAS_DBG_PTR")) p.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
 #endif
@@ -552,6 +597,7 @@ int mas_conv3x3_wide_launch(const MasConvDesc* d, const void* x, const float* sc
         if (d->act != MAS_ACT_NONE) return residual ? launch_wide<true, true, true>(p, s) : launch_wide<true, false, true>(p, s);
         return residual ? launch_wide<false, true, true>(p, s) : launch_wide<false, false, true>(p, s);
     }
+    if (act_out) return residual ? launch_wide<true, true, false, true>(p, s) : launch_wide<true, false, false, true>(p, s);
     if (d->act != MAS_ACT_NONE) return residual ? launch_wide<true, true, false>(p, s) : launch_wide<true, false, false>(p, s);
     return residual ? launch_wide<false, true, false>(p, s) : launch_wide<false, false, false>(p, s);
 }

@@ -19,9 +19,13 @@ constexpr int MAX_SPLIT = 64;
 // partial layout: [N][split][C][2]
 template <typename T>
 __global__ __launch_bounds__(NT) void gn_stats_partial(const T* __restrict__ x, int HW, int C, int nsplit,
-                                                       float* __restrict__ partial) {
+                                                       float* __restrict__ partial, int rev) {
     constexpr int EPU = 16 / (int)sizeof(T);
-    const int n = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+    // rev: the first-dispatched blocks take the END of the tensor -- the part its producer (which walked it front to back)
+    // touched last and that is most likely still resident in the 256 MiB Infinity Cache; the consumer that follows walks front
+    // to back again and meets what THIS pass touched last (see mas_gn_stats)
+    const int bid = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int n = bid / nsplit, sp = bid % nsplit;
     const int upp = C / EPU;                        // 16-byte units per pixel
     const int tid = threadIdx.x;
     extern __shared__ float red[];                  // [C][2]
@@ -132,9 +136,10 @@ __global__ __launch_bounds__(NT) void gn_stats_finalize(const float* __restrict_
 template <typename T>
 __global__ __launch_bounds__(NT) void gn_bwd_partial(const T* __restrict__ x, const T* __restrict__ da, int HW, int C,
                                                      int G, int nsplit, int act, const float* __restrict__ mean_rstd,
-                                                     const float* __restrict__ ss, float* __restrict__ partial) {
+                                                     const float* __restrict__ ss, float* __restrict__ partial, int rev) {
     constexpr int EPU = 16 / (int)sizeof(T);
-    const int n = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+    const int bid = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;   // (see gn_stats_partial)
+    const int n = bid / nsplit, sp = bid % nsplit;
     const int upp = C / EPU, cpg = C / G;
     const int tid = threadIdx.x;
     extern __shared__ float red[];
@@ -345,6 +350,16 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply(const T* __restrict__ x, cons
     }
 }
 
+// Pass ordering against the Infinity Cache (256 MiB, memory side): the tensors of the 256x256 / 128x128 levels are 134-537 MB, so a
+// pass that re-walks a tensor in the SAME direction as the pass before it finds everything it needs already evicted, while the
+// opposite direction starts on the most recently touched ~quarter.  Convolutions and the backward apply pass walk images front
+// to back; the two reduction passes (statistics, backward partial sums) walk back to front.  MAS_GN_REVERSE=0 restores
+// front-to-back everywhere (A/B knob).
+int gn_reverse() {
+    static const int r = mas_env_int("MAS_GN_REVERSE", 1);
+    return r;
+}
+
 int pick_split(int N, int HW) {
     // enough blocks to fill 256 CUs a few times over, but >= 64 pixels per block
     int s = mas_cdiv(1024, N);
@@ -372,9 +387,9 @@ extern "C" int mas_gn_stats(const void* x, int dtype, int N, int HW, int C, int 
     float* partial = reinterpret_cast<float*>(workspace);
     const size_t lds1 = ((size_t)2 * C + (size_t)NT * epu * 2) * sizeof(float);
     if (dtype == MAS_BF16)
-        hipLaunchKernelGGL(gn_stats_partial<bf16_t>, dim3(N * nsplit), dim3(NT), lds1, s, (const bf16_t*)x, HW, C, nsplit, partial);
+        hipLaunchKernelGGL(gn_stats_partial<bf16_t>, dim3(N * nsplit), dim3(NT), lds1, s, (const bf16_t*)x, HW, C, nsplit, partial, gn_reverse());
     else
-        hipLaunchKernelGGL(gn_stats_partial<float>, dim3(N * nsplit), dim3(NT), lds1, s, (const float*)x, HW, C, nsplit, partial);
+        hipLaunchKernelGGL(gn_stats_partial<float>, dim3(N * nsplit), dim3(NT), lds1, s, (const float*)x, HW, C, nsplit, partial, gn_reverse());
     MAS_CHECK_LAUNCH("gn_stats_partial");
     const size_t lds2 = (size_t)2 * C * sizeof(double) + (size_t)2 * G * sizeof(float);
     hipLaunchKernelGGL(gn_stats_finalize, dim3(N), dim3(NT), lds2, s, partial, HW, C, G, nsplit, eps, gamma, beta, mean_rstd, scale_shift);
@@ -418,9 +433,9 @@ extern "C" int mas_gn_bwd(const void* x, const void* da, const void* dres, int d
     float* nsum = coef + (size_t)N * C * 4;
     const size_t lds1 = ((size_t)2 * C + (size_t)NT * epu * 2) * sizeof(float);
     if (dtype == MAS_BF16)
-        hipLaunchKernelGGL(gn_bwd_partial<bf16_t>, dim3(N * nsplit), dim3(NT), lds1, s, (const bf16_t*)x, (const bf16_t*)da, HW, C, G, nsplit, act, mean_rstd, scale_shift, partial);
+        hipLaunchKernelGGL(gn_bwd_partial<bf16_t>, dim3(N * nsplit), dim3(NT), lds1, s, (const bf16_t*)x, (const bf16_t*)da, HW, C, G, nsplit, act, mean_rstd, scale_shift, partial, gn_reverse());
     else
-        hipLaunchKernelGGL(gn_bwd_partial<float>, dim3(N * nsplit), dim3(NT), lds1, s, (const float*)x, (const float*)da, HW, C, G, nsplit, act, mean_rstd, scale_shift, partial);
+        hipLaunchKernelGGL(gn_bwd_partial<float>, dim3(N * nsplit), dim3(NT), lds1, s, (const float*)x, (const float*)da, HW, C, G, nsplit, act, mean_rstd, scale_shift, partial, gn_reverse());
     MAS_CHECK_LAUNCH("gn_bwd_partial");
     hipLaunchKernelGGL(gn_bwd_finalize, dim3(N), dim3(NT), (size_t)2 * C * sizeof(double), s, partial, HW, C, G, nsplit, gamma, mean_rstd, coef, nsum);
     MAS_CHECK_LAUNCH("gn_bwd_finalize");

@@ -281,6 +281,36 @@ extern "C" int mas_pack_conv_weight_batch(const MasPackItem* items_device, int n
     return MAS_OK;
 }
 
+// ---- weight-gradient commit: acc [Cout][ks][ks][Cin] fp32 (the split-K accumulator mas_conv_wgrad's kernels add into, followed by
+// [Cout] bias sums when dbias != NULL) -> dw in the parameter's own OIHW layout, db; the accumulator is ZEROED on the way out, so the
+// caller keeps ONE persistent scratch per stream instead of a fresh zero-filled tensor (a fill launch) and a permute copy per call
+__global__ __launch_bounds__(256) void wgrad_commit_kernel(float* __restrict__ acc, float* __restrict__ dw, float* __restrict__ db,
+                                                           int Cout, int Cin, int kk, long long npair) {
+    // one thread per (cout, cin) pair: its kk taps are read at stride Cin (consecutive threads = consecutive cin: coalesced) and
+    // written as kk consecutive floats (a wave covers 64 * kk contiguous floats of the OIHW tensor)
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < npair) {
+        const int i = (int)(idx % Cin), o = (int)(idx / Cin);
+        float* src = acc + (long long)o * kk * Cin + i;
+        float* dst = dw + idx * kk;
+        for (int t = 0; t < kk; ++t) { dst[t] = src[(long long)t * Cin]; src[(long long)t * Cin] = 0.0f; }
+    } else if (db && idx < npair + Cout) {
+        float* src = acc + npair * kk + (idx - npair);
+        db[idx - npair] = *src;
+        *src = 0.0f;
+    }
+}
+
+extern "C" int mas_wgrad_commit(float* acc, float* dw_oihw, float* dbias, int Cout, int Cin, int ks, void* stream) {
+    MAS_ENTER();
+    if (!acc || !dw_oihw || Cout <= 0 || Cin <= 0 || ks < 1) MAS_FAIL(MAS_EINVAL, "wgrad_commit: bad argument");
+    const long long npair = (long long)Cout * Cin, tot = npair + (dbias ? Cout : 0);
+    hipLaunchKernelGGL(wgrad_commit_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       acc, dw_oihw, dbias, Cout, Cin, ks * ks, npair);
+    MAS_CHECK_LAUNCH("wgrad_commit");
+    return MAS_OK;
+}
+
 #define MAS_DISPATCH_NHWC(NAME, KERN, TOTAL, ...)                                                                   \
     do {                                                                                                            \
         const int epu_ = dtype == MAS_BF16 ? 8 : 4;                                                                 \

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MAS_HIP_LIB") or os.path.join(_HERE, "libmas_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_AFFINE, ACT_AFFINE_SILU = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 WLAYOUT_K64, WLAYOUT_K32 = 0, 1
 
 
@@ -50,9 +50,12 @@ _SIGNATURES = {
     "mas_gn_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "mas_conv_fwd": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p]),
     "mas_conv_stat_rows": (_i, [C.POINTER(ConvDesc)]),
+    "mas_conv_act_out_supported": (_i, [C.POINTER(ConvDesc)]),
+    "mas_conv_fwd_act": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
     "mas_conv_fwd_stats": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
     "mas_gn_stats_from_partials": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
     "mas_conv_wgrad": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
+    "mas_wgrad_commit": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "mas_vq_workspace": (_sz, [_i, _i]),
     "mas_vq_argmin_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "mas_vq_bwd": (_i, [_p, _p, _p, _p, _p, _f, _i, _i, _i, _p, _p, _p]),

@@ -335,19 +335,39 @@ def _preferred_layout(d: ConvDesc) -> int:
 
 
 _stat_rows_memo = {}
+_act_out_memo = {}
+# Activation side output (mas_conv_fwd_act): the forward convolution of a GroupNorm(+SiLU)-fed layer also writes the activated input
+# it forms in its loader; the weight gradient of that layer then runs prologue-free on it instead of recomputing the activation
+# (conv_wgrad_dma: 0.655 ms vs 0.79 ms at 128->128 @256^2).  Costs one more saved tensor per such layer.  MAS_CONV_ACT_OUT=0: off.
+_ACT_OUT = os.environ.get("MAS_CONV_ACT_OUT", "1") == "1"
 
 
-def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, upsample, out_dtype, want_stats=False):
+def _act_out_supported(d: ConvDesc) -> bool:
+    key = tuple(getattr(d, f) for f, _ in ConvDesc._fields_)
+    ok = _act_out_memo.get(key)
+    if ok is None:
+        fn = getattr(lib(), "mas_conv_act_out_supported", None)
+        ok = _act_out_memo[key] = bool(fn is not None and fn(C.byref(d)))
+    return ok
+
+
+def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, upsample, out_dtype, want_stats=False,
+                 want_act=False):
     """``wp``: a ``ConvWeight`` (packed here in the layout the library prefers for this convolution) or an already packed
     K64 image from ``pack_conv_weight`` (always accepted; the call then stays on the kernels that read K64).
     ``want_stats``: returns (y, partial, rows) -- the per-tile channel sums of y for the GroupNorm that consumes it
-    (``mas_conv_fwd_stats``), or (y, None, 0) when this convolution's kernel has no fused statistics."""
+    (``mas_conv_fwd_stats``), or (y, None, 0) when this convolution's kernel has no fused statistics.
+    ``want_act`` (with a prologue): the result tuple gains a last element, the activated input act(x * scale + shift) in x's dtype
+    and layout as written by the kernel (``mas_conv_fwd_act``), or None when this convolution's kernel has no such side output."""
     y = _empty_nhwc(n, cout, ho, wo, out_dtype, x.device)
     d = _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, x.dtype, out_dtype, act, upsample)
     if isinstance(wp, ConvWeight):
         d.w_layout = _preferred_layout(d)
         wp = _pack_cache.get(wp.w, wp.transpose, x.dtype, d.w_layout, wp.sources)
     partial, rows = None, 0
+    act_out = None
+    if want_act and _ACT_OUT and act != ACT_NONE and not (want_stats and _stats_state["on"]) and _act_out_supported(d):
+        act_out = torch.empty_like(x, memory_format=torch.channels_last)
     if want_stats and _stats_state["on"]:
         key = tuple(getattr(d, f) for f, _ in ConvDesc._fields_)
         rows = _stat_rows_memo.get(key)
@@ -357,7 +377,10 @@ def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stri
             partial = torch.empty(n * rows * cout * 2, dtype=torch.float32, device=x.device)
 
     def launch():
-        if partial is not None:
+        if act_out is not None:
+            check(lib().mas_conv_fwd_act(C.byref(d), _ptr(x), _ptr(ss), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), _ptr(act_out),
+                                         _stream()), "conv_fwd_act")
+        elif partial is not None:
             check(lib().mas_conv_fwd_stats(C.byref(d), _ptr(x), _ptr(ss), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), _ptr(partial),
                                            _stream()), "conv_fwd_stats")
         else:
@@ -368,8 +391,9 @@ def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stri
     else:
         launch()
     if want_stats:
-        return y, partial, (rows if partial is not None else 0)
-    return y
+        res = (y, partial, (rows if partial is not None else 0))
+        return res + (act_out,) if want_act else res
+    return (y, act_out) if want_act else y
 
 
 def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, upsample, want_bias):
@@ -383,22 +407,51 @@ def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ac
         dws, db = conv_wgrad_raw(xs, None, dy, n, ho + 1, wo + 1, 4 * cin, ho, wo, cout, 2, 1, 0, 0, ACT_NONE, False, want_bias)
         dw = dws.view(cout, 2, 2, cin, 2, 2).permute(0, 3, 4, 1, 5, 2).reshape(cout, cin, 4, 4)
         return dw, db
-    nw = cout * ks * ks * cin                       # dw and db share one zero-filled allocation (one fill launch)
-    acc = torch.zeros(nw + (cout if want_bias else 0), dtype=torch.float32, device=x.device)
-    dw = acc[:nw].view(cout, ks, ks, cin)
-    db = acc[nw:] if want_bias else None
+    nw = cout * ks * ks * cin
     d = _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, x.dtype, x.dtype, act, upsample)
+    if not _WGRAD_SCRATCH:                          # A/B switch: the round-2 scheme (a zero-filled tensor + a permute copy per call)
+        acc = torch.zeros(nw + (cout if want_bias else 0), dtype=torch.float32, device=x.device)
+        dw = acc[:nw].view(cout, ks, ks, cin)
+        db = acc[nw:] if want_bias else None
+
+        def launch():
+            check(lib().mas_conv_wgrad(C.byref(d), _ptr(x), _ptr(ss), _ptr(dy), _ptr(dw), _ptr(db), _stream()), "conv_wgrad")
+
+        if _launch_hook is not None:
+            _launch_hook("conv_wgrad", (n, h, w, cin, ho, wo, cout, ks, stride, act, 0), launch)
+        else:
+            launch()
+        if ks == 1:                                 # [cout,1,1,cin] == OIHW memory; a permute would keep odd size-1 strides (DDP warns)
+            return dw.view(cout, cin, 1, 1), db
+        return dw.permute(0, 3, 1, 2).contiguous(), db
+    # The split-K kernels ADD into a zero accumulator.  One persistent scratch per (device, stream), zeroed once, is handed to every
+    # weight-gradient launch; ``mas_wgrad_commit`` moves the sums into a fresh OIHW gradient tensor (+ bias gradient) and zeroes the
+    # scratch again while it reads it: no fill launch and no permute copy per convolution (round 2: 356 fills per VQ-IMG step).
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    acc = _wgrad_scratch.get(key)
+    if acc is None or acc.numel() < nw + cout:
+        acc = _wgrad_scratch[key] = torch.zeros(max(nw + cout, 1 << 22), dtype=torch.float32, device=x.device)
+    dwo = torch.empty((cout, cin, ks, ks), dtype=torch.float32, device=x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
 
     def launch():
-        check(lib().mas_conv_wgrad(C.byref(d), _ptr(x), _ptr(ss), _ptr(dy), _ptr(dw), _ptr(db), _stream()), "conv_wgrad")
+        check(lib().mas_conv_wgrad(C.byref(d), _ptr(x), _ptr(ss), _ptr(dy), _ptr(acc), C.c_void_p(acc.data_ptr() + 4 * nw) if want_bias else None,
+                                   _stream()), "conv_wgrad")
 
-    if _launch_hook is not None:
-        _launch_hook("conv_wgrad", (n, h, w, cin, ho, wo, cout, ks, stride, act, 0), launch)
-    else:
-        launch()
-    if ks == 1:                                     # [cout,1,1,cin] == OIHW memory; a permute would keep odd size-1 strides (DDP warns)
-        return dw.view(cout, cin, 1, 1), db
-    return dw.permute(0, 3, 1, 2).contiguous(), db
+    try:
+        if _launch_hook is not None:
+            _launch_hook("conv_wgrad", (n, h, w, cin, ho, wo, cout, ks, stride, act, 0), launch)
+        else:
+            launch()
+        check(lib().mas_wgrad_commit(_ptr(acc), _ptr(dwo), _ptr(db), cout, cin, ks, _stream()), "wgrad_commit")
+    except Exception:
+        _wgrad_scratch.pop(key, None)               # its all-zero invariant can no longer be assumed
+        raise
+    return dwo, db
+
+
+_WGRAD_SCRATCH = os.environ.get("MAS_WGRAD_SCRATCH", "1") == "1"
+_wgrad_scratch = {}
 
 
 def upsample2x(x):
@@ -462,19 +515,20 @@ class _NormActConv(torch.autograd.Function):
         wp = ConvWeight(weight, False, ctx.w_sources)
         b32 = bias.detach().float() if bias is not None else None
         res = nhwc(residual, cd) if residual is not None else None
-        y, ypart, yrows = conv_fwd_raw(x, ss, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, cfg["out_dtype"],
-                                       want_stats=True)
+        need_wgrad = ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])
+        y, ypart, yrows, a = conv_fwd_raw(x, ss, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, cfg["out_dtype"],
+                                          want_stats=True, want_act=need_wgrad and act != ACT_NONE)
         _stats_state["stash"] = (ypart, yrows) if ypart is not None else None
         ctx.cfg = cfg
         ctx.dims = (n, h, w, cin, ho, wo, cout, ks)
         ctx.has_res = residual is not None
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, weight, gn_w, mr, ss)
+        ctx.save_for_backward(x, weight, gn_w, mr, ss, a)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, gn_w, mr, ss = ctx.saved_tensors
+        x, weight, gn_w, mr, ss, a = ctx.saved_tensors
         cfg = ctx.cfg
         n, h, w, cin, ho, wo, cout, ks = ctx.dims
         cd = cfg["in_dtype"]
@@ -484,7 +538,10 @@ class _NormActConv(torch.autograd.Function):
         need_gn = act != ACT_NONE and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
         dx = dw = db = dgw = dgb = None
         if need_w or need_b:
-            dw, db = conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, need_b)
+            if a is not None:          # the forward left the activated input: prologue-free weight gradient
+                dw, db = conv_wgrad_raw(a, None, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ACT_NONE, ups, need_b)
+            else:
+                dw, db = conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, need_b)
             dw = dw.to(weight.dtype) if need_w else None
         if need_x or need_gn:
             wt = ConvWeight(weight, True, ctx.w_sources)
@@ -546,19 +603,20 @@ class _ResBlock(torch.autograd.Function):
         n, c, h, w = x.shape
         f32 = lambda t: t.detach().float()
         mr1, ss1 = gn_stats(x, f32(n1w), f32(n1b), groups, eps, xpart, xrows)
-        hh, hpart, hrows = conv_fwd_raw(x, ss1, ConvWeight(c1w, False), f32(c1b), None, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU, False,
-                                        cd, want_stats=True)
+        ng = ctx.needs_input_grad
+        hh, hpart, hrows, a1 = conv_fwd_raw(x, ss1, ConvWeight(c1w, False), f32(c1b), None, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU,
+                                            False, cd, want_stats=True, want_act=ng[3] or ng[4])
         mr2, ss2 = gn_stats(hh, f32(n2w), f32(n2b), groups, eps, hpart, hrows)
-        y, ypart, yrows = conv_fwd_raw(hh, ss2, ConvWeight(c2w, False), f32(c2b), x, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU, False,
-                                       cd, want_stats=True)
+        y, ypart, yrows, a2 = conv_fwd_raw(hh, ss2, ConvWeight(c2w, False), f32(c2b), x, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU,
+                                           False, cd, want_stats=True, want_act=ng[7] or ng[8])
         _stats_state["stash"] = (ypart, yrows) if ypart is not None else None
         ctx.groups, ctx.cd = groups, cd
-        ctx.save_for_backward(x, hh, mr1, ss1, mr2, ss2, n1w, c1w, n2w, c2w)
+        ctx.save_for_backward(x, hh, mr1, ss1, mr2, ss2, n1w, c1w, n2w, c2w, a1, a2)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, hh, mr1, ss1, mr2, ss2, n1w, c1w, n2w, c2w = ctx.saved_tensors
+        x, hh, mr1, ss1, mr2, ss2, n1w, c1w, n2w, c2w, a1, a2 = ctx.saved_tensors
         cd, groups = ctx.cd, ctx.groups
         n, c, h, w = x.shape
         dy = nhwc(dy, cd)
@@ -566,13 +624,15 @@ class _ResBlock(torch.autograd.Function):
         geo = (n, h, w, c, h, w, c, 3, 1, 1, 1)
         # conv2 / norm2
         dw2 = db2 = dw1 = db1 = None
-        if ng[7] or ng[8]:
-            dw2, db2 = conv_wgrad_raw(hh, ss2, dy, *geo, ACT_AFFINE_SILU, False, True)
+        if ng[7] or ng[8]:       # (a2 / a1: the activated inputs the forward convolutions left behind -> prologue-free weight gradients)
+            dw2, db2 = conv_wgrad_raw(a2, None, dy, *geo, ACT_NONE, False, True) if a2 is not None else \
+                conv_wgrad_raw(hh, ss2, dy, *geo, ACT_AFFINE_SILU, False, True)
         da2 = conv_fwd_raw(dy, None, ConvWeight(c2w, True), None, None, *geo, ACT_NONE, False, cd)
         dh, dg2w, dg2b = gn_bwd(hh, da2, None, groups, ACT_AFFINE_SILU, n2w.detach().float(), mr2, ss2)
         # conv1 / norm1 (+ the skip connection's gradient, fused into the GroupNorm-backward apply pass)
         if ng[3] or ng[4]:
-            dw1, db1 = conv_wgrad_raw(x, ss1, dh, *geo, ACT_AFFINE_SILU, False, True)
+            dw1, db1 = conv_wgrad_raw(a1, None, dh, *geo, ACT_NONE, False, True) if a1 is not None else \
+                conv_wgrad_raw(x, ss1, dh, *geo, ACT_AFFINE_SILU, False, True)
         dx = dg1w = dg1b = None
         if ng[0] or ng[1] or ng[2]:
             da1 = conv_fwd_raw(dh, None, ConvWeight(c1w, True), None, None, *geo, ACT_NONE, False, cd)

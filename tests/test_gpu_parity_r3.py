@@ -110,10 +110,16 @@ def test_dominant_conv_wide_real_shape_vs_cpu_fp32():
                               n, *geo, 0, False, bf)
         dw0, db0 = ops.conv_wgrad_raw(xd, None, dyd, n, *geo, 0, False, True)
         dw2, db2 = ops.conv_wgrad_raw(xd, ssd, dyd, n, *geo, 2, False, True)
+        # the path the training step takes since round 3: the forward also writes the activated input (mas_conv_fwd_act), the weight
+        # gradient runs prologue-free on it
+        y1a, a_out = ops.conv_fwd_raw(xd, ssd, ops.ConvWeight(wd, False), bd, None, n, *geo, 2, False, bf, want_act=True)
+        assert a_out is not None and torch.equal(y1a, y1)
+        dw3, db3 = ops.conv_wgrad_raw(a_out, None, dyd, n, *geo, 0, False, True)
     finally:
         ops.set_launch_hook(None)
     torch.cuda.synchronize()
-    assert [k for k, _ in seen] == ["conv_fwd"] * 4 + ["conv_wgrad"] * 2
+    assert [k for k, _ in seen] == ["conv_fwd"] * 4 + ["conv_wgrad"] * 2 + ["conv_fwd", "conv_wgrad"]
+    e = relerr(a_out, af); print("activation side output vs CPU silu(gn(x)) in bf16: %.3e" % e); assert e < 1e-2
     ref0 = F.conv2d(xf, w, b, padding=1)
     e = relerr(y0, ref0); print("wide fwd plain, 2 tiles per work-group: %.3e" % e); assert e < 1e-2
     del ref0
@@ -124,7 +130,7 @@ def test_dominant_conv_wide_real_shape_vs_cpu_fp32():
     refd = F.conv2d(dy.float(), w, None, padding=1)                        # `da` convolves dy with the EFFECTIVE filter w
     e = relerr(da, refd); print("wide dgrad packing: %.3e" % e); assert e < 1e-2
     del refd
-    for act, a_in, dw, db in ((0, xf, dw0, db0), (2, af, dw2, db2)):
+    for act, a_in, dw, db in ((0, xf, dw0, db0), (2, af, dw2, db2), (3, af, dw3, db3)):      # 3: prologue-free on the side output
         wr = torch.zeros(c, c, 3, 3, requires_grad=True)
         F.conv2d(a_in, wr, None, padding=1).backward(dy.float())
         e_w, e_b = relerr(dw, wr.grad), relerr(db, dy.float().sum((0, 2, 3)))
@@ -265,3 +271,31 @@ def test_make_a_scene_w1024_vs_reference_golden(golden_dir, mode):
         e = relerr(got, g["grad:" + k])
         print("  grad %-48s max-rel %.3e" % (k, e))
         assert params[k].grad.dtype == torch.float32 and e < tol_g, k
+
+
+# --------------------------------------------------------------------------------------------------------------
+# 5. the persistent weight-gradient scratch (mas_wgrad_commit)
+# --------------------------------------------------------------------------------------------------------------
+def test_wgrad_scratch_is_rezeroed_between_convolutions():
+    """conv_wgrad_raw hands ONE zeroed fp32 scratch per stream to every split-K launch; mas_wgrad_commit moves the sums to an OIHW
+    tensor and zeroes the scratch while reading it.  Three convolutions of different geometry back to back (3x3 on the LDS-DMA
+    kernel, 1x1, 4x4 stride 2 through space-to-depth) against autograd of F.conv2d on the CPU; the scratch is all-zero after each."""
+    from mas_hip import ops
+    dev = _dev()
+    bf = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(7)
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    for (n, cin, h, cout, ks, stride, pad) in ((4, 128, 32, 128, 3, 1, 1), (4, 64, 16, 128, 1, 1, 0), (4, 64, 32, 128, 4, 2, 1),
+                                               (2, 256, 32, 256, 3, 1, 1)):
+        x = torch.randn(n, cin, h, h, generator=g).bfloat16()
+        ho = (h + 2 * pad - ks) // stride + 1
+        dy = torch.randn(n, cout, ho, ho, generator=g).bfloat16()
+        dw, db = ops.conv_wgrad_raw(cl(x), None, cl(dy), n, h, h, cin, ho, ho, cout, ks, stride, pad, pad, 0, False, True)
+        torch.cuda.synchronize()
+        wr = torch.zeros(cout, cin, ks, ks, requires_grad=True)
+        F.conv2d(x.float(), wr, None, stride=stride, padding=pad).backward(dy.float())
+        assert dw.shape == wr.shape and dw.is_contiguous()
+        assert relerr(dw, wr.grad) < 2e-3 and relerr(db, dy.float().sum((0, 2, 3))) < 2e-3, (n, cin, h, cout, ks, stride)
+        for acc in ops._wgrad_scratch.values():
+            assert float(acc.abs().max()) == 0.0
+    assert len(ops._wgrad_scratch) >= 1
