@@ -356,6 +356,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                             if constexpr (AOUT) {
                                 const int ch_off = cb == 0 ? (ciA + 32) * 2 : (last_pair ? 0 : (ciA + 64) * 2);
                                 aout_soff = (nxt ? c0_nxt : c0_cur) == 0 ? (nxt ? n_nxt : n_cur) * img_b + ch_off : -1;
+                                // (without a next tile this stage re-activates the current tile's chunk 0 with a scale/shift table
+                                //  that was never staged -- harmless for the convolution, which never reads it, but not to be stored)
+                                if (nxt && !has_next) aout_soff = -1;
                             }
                             p_activate(nxt ? inb_nxt : inb_cur, cb ^ 1, vo, aout_soff, rs_a);
                             asm volatile("" ::: "memory");

@@ -352,13 +352,14 @@ def _act_out_supported(d: ConvDesc) -> bool:
 
 
 def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, upsample, out_dtype, want_stats=False,
-                 want_act=False):
+                 want_act=None):
     """``wp``: a ``ConvWeight`` (packed here in the layout the library prefers for this convolution) or an already packed
     K64 image from ``pack_conv_weight`` (always accepted; the call then stays on the kernels that read K64).
     ``want_stats``: returns (y, partial, rows) -- the per-tile channel sums of y for the GroupNorm that consumes it
     (``mas_conv_fwd_stats``), or (y, None, 0) when this convolution's kernel has no fused statistics.
-    ``want_act`` (with a prologue): the result tuple gains a last element, the activated input act(x * scale + shift) in x's dtype
-    and layout as written by the kernel (``mas_conv_fwd_act``), or None when this convolution's kernel has no such side output."""
+    ``want_act`` not None: the result tuple gains a last element -- with ``want_act`` true and a prologue, the activated input
+    act(x * scale + shift) in x's dtype and layout as written by the kernel (``mas_conv_fwd_act``); None when ``want_act`` is false or
+    this convolution's kernel has no such side output."""
     y = _empty_nhwc(n, cout, ho, wo, out_dtype, x.device)
     d = _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, x.dtype, out_dtype, act, upsample)
     if isinstance(wp, ConvWeight):
@@ -392,8 +393,8 @@ def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stri
         launch()
     if want_stats:
         res = (y, partial, (rows if partial is not None else 0))
-        return res + (act_out,) if want_act else res
-    return (y, act_out) if want_act else y
+        return res + (act_out,) if want_act is not None else res
+    return (y, act_out) if want_act is not None else y
 
 
 def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, upsample, want_bias):
@@ -517,7 +518,7 @@ class _NormActConv(torch.autograd.Function):
         res = nhwc(residual, cd) if residual is not None else None
         need_wgrad = ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])
         y, ypart, yrows, a = conv_fwd_raw(x, ss, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, cfg["out_dtype"],
-                                          want_stats=True, want_act=need_wgrad and act != ACT_NONE)
+                                          want_stats=True, want_act=bool(need_wgrad and act != ACT_NONE))
         _stats_state["stash"] = (ypart, yrows) if ypart is not None else None
         ctx.cfg = cfg
         ctx.dims = (n, h, w, cin, ho, wo, cout, ks)
@@ -605,10 +606,10 @@ class _ResBlock(torch.autograd.Function):
         mr1, ss1 = gn_stats(x, f32(n1w), f32(n1b), groups, eps, xpart, xrows)
         ng = ctx.needs_input_grad
         hh, hpart, hrows, a1 = conv_fwd_raw(x, ss1, ConvWeight(c1w, False), f32(c1b), None, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU,
-                                            False, cd, want_stats=True, want_act=ng[3] or ng[4])
+                                            False, cd, want_stats=True, want_act=bool(ng[3] or ng[4]))
         mr2, ss2 = gn_stats(hh, f32(n2w), f32(n2b), groups, eps, hpart, hrows)
         y, ypart, yrows, a2 = conv_fwd_raw(hh, ss2, ConvWeight(c2w, False), f32(c2b), x, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU,
-                                           False, cd, want_stats=True, want_act=ng[7] or ng[8])
+                                           False, cd, want_stats=True, want_act=bool(ng[7] or ng[8]))
         _stats_state["stash"] = (ypart, yrows) if ypart is not None else None
         ctx.groups, ctx.cd = groups, cd
         ctx.save_for_backward(x, hh, mr1, ss1, mr2, ss2, n1w, c1w, n2w, c2w, a1, a2)

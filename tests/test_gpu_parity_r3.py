@@ -196,7 +196,8 @@ def test_img256_encoder_backward_with_reference_dz(golden_dir, mode, copies):
     a 1 % latent perturbation selects downstream (the 45 % seen on encoder.model.0.weight end to end in round 2).
     copies=16: the same image 16 times (BatchNorm's batch statistics are those of one copy; every parameter gradient is 16x the
     reference's), which moves the 256x256 / 128x128 layers onto the kernels and the multi-tile walk bench.py times.
-    fp32 (exact-fp32 MFMA kernels): every recorded gradient within 5e-3 rel-L2 / 1e-2 max-rel -- the kernels are right.
+    fp32 (exact-fp32 MFMA kernels): every recorded gradient within 2e-4 rel-L2 / 5e-4 max-rel (measured 1.7e-5 / 1.6e-5) and the
+    gradient norm to 6 digits -- the kernels are right.
     bf16: GroupNorm's backward subtracts the group means, so most of each gradient cancels and rounding noise is amplified
     layer by layer towards the input (measured rel-L2: 3.0e-2 at quant_conv.0 ... 1.0e-1 at encoder.model.0.weight, 1.3e-1 at its
     bias).  The yardstick is the reference ITSELF under torch.autocast(bfloat16) on the CPU, recorded in the fixture
@@ -218,7 +219,7 @@ def test_img256_encoder_backward_with_reference_dz(golden_dir, mode, copies):
         got = params[k].grad.detach().float().cpu()[sl] / copies
         e2, em = rel_l2(got, g["grad:" + k]), relerr(got, g["grad:" + k])
         r2, rm = float(g["refbf16_l2:" + k]), float(g["refbf16_max:" + k])
-        lim2, limm = (5e-3, 1e-2) if mode == "fp32" else (max(1.5 * r2, 5e-2), max(1.5 * rm, 5e-2))
+        lim2, limm = (2e-4, 5e-4) if mode == "fp32" else (max(1.5 * r2, 5e-2), max(1.5 * rm, 5e-2))
         print("  %s copies=%d %-36s rel-L2 %.3e max-rel %.3e   (reference's own bf16 autocast: %.3e / %.3e)" % (mode, copies, k, e2, em, r2, rm))
         if e2 > lim2 or em > limm:
             bad.append((k, e2, em, lim2, limm))
@@ -226,7 +227,7 @@ def test_img256_encoder_backward_with_reference_dz(golden_dir, mode, copies):
                       if (n_.startswith("encoder.") or n_.startswith("quant_conv.")) and p.grad is not None)) / copies
     print("encoder backward under the reference dz (%s, copies=%d): gradient norm %.5f vs %.5f" % (mode, copies, enc, float(g["gradnorm_encoder"])))
     assert not bad, bad
-    assert abs(enc - float(g["gradnorm_encoder"])) < (2e-3 if mode == "fp32" else 2e-2) * float(g["gradnorm_encoder"])
+    assert abs(enc - float(g["gradnorm_encoder"])) < (2e-4 if mode == "fp32" else 2e-2) * float(g["gradnorm_encoder"])
 
 
 # --------------------------------------------------------------------------------------------------------------
