@@ -192,13 +192,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
             sc[2 * q4] = v[0]; sh[2 * q4] = v[1]; sc[2 * q4 + 1] = v[2]; sh[2 * q4 + 1] = v[3];
         }
     };
-    // (side output) rs_a: one descriptor over the whole act_out tensor; a store adds the image's byte offset + the chunk's as its
-    // scalar offset.  aout_soff < 0: this tile does not write (cout tile != 0)
-    auto p_activate = [&](unsigned inb_mask, int buf, const int (&vo_)[W_NSLOT], int aout_soff, __amdgpu_buffer_rsrc_t rs_a) {   // padding pixels were written as zeros by the DMA and stay zero
+    // (side output) the activated values of a stage's 5 slots stay in registers (av) with their store offsets (ao) until the stage's
+    // weight DMA has been issued: the 5 stores then are the YOUNGEST vector-memory operations at the next barrier, whose counted wait
+    // lets them fly on (a store in front of the DMA would have to be acknowledged before the in-order wait for the DMA returns:
+    // measured +0.09 ms per launch).  ALWAYS exactly 5 store instructions per wave (dead slots: out-of-range offset, dropped by the
+    // descriptor's bounds check): the counted waits depend on it.
+    u32x4 av[AOUT ? W_NSLOT : 1];
+    int ao[AOUT ? W_NSLOT : 1];
+    auto p_activate = [&](unsigned inb_mask, int buf, const int (&vo_)[W_NSLOT], bool writer) {   // padding pixels were written as zeros by the DMA and stay zero
 #pragma unroll
         for (int k = 0; k < W_NSLOT; ++k) {
             int q, pr, pc;
             const bool live = slot_pix(k, q, pr, pc) && (k < 4 || wave < 7) && ((inb_mask >> k) & 1u);
+            if constexpr (AOUT) { ao[k] = W_OOB; av[k] = u32x4{0u, 0u, 0u, 0u}; }
             if (!live) continue;
             unsigned char* dst = patch + buf * W_PATCH + q * 64 + (((lane & 3) ^ ((q >> 2) & 3)) << 4);
             u32x4 v = *reinterpret_cast<const u32x4*>(dst);
@@ -215,10 +221,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                 // interior of the tile (the pixels under this tile's outputs): each image pixel belongs to exactly one tile.
                 // vo_[k] addresses the SOURCE slot sl = (lane & 3) ^ ((q >> 2) & 3) of the pixel inside its image; the activated
                 // values are LOGICAL slot lane & 3: flip the two slot bits back
-                const bool inner = (unsigned)(pr - p.pad_top) < 16u && (unsigned)(pc - p.pad_left) < 32u && aout_soff >= 0;
-                const int so = inner ? (vo_[k] ^ (((q >> 2) & 3) << 4)) : W_OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs_a, so, aout_soff < 0 ? 0 : aout_soff, 0);
+                const bool inner = (unsigned)(pr - p.pad_top) < 16u && (unsigned)(pc - p.pad_left) < 32u && writer;
+                av[k] = v;
+                ao[k] = inner ? (vo_[k] ^ (((q >> 2) & 3) << 4)) : W_OOB;
             }
+        }
+    };
+    // rs_a: one descriptor over the whole act_out tensor; soff = the image's byte offset + the chunk's
+    auto aout_store = [&](__amdgpu_buffer_rsrc_t rs_a, int soff) {
+        if constexpr (AOUT) {
+#pragma unroll
+            for (int k = 0; k < W_NSLOT; ++k) __builtin_amdgcn_raw_buffer_store_b128(av[k], rs_a, ao[k], soff, 0);
         }
     };
 
@@ -273,7 +286,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
         ss_stage(n_cur, 0);
         W_WAIT_BARRIER(0);                       // the raw patch of chunk 0 has landed for every wave, the table is visible
         ss_fetch(0, 0);
-        p_activate(inb_cur, 0, vo, c0_cur == 0 ? n_cur * img_b : -1, rs_a);
+        p_activate(inb_cur, 0, vo, c0_cur == 0);
+        aout_store(rs_a, n_cur * img_b);
     }
     if (p.stagger > 0) {
         const int n = (int)((blockIdx.x * 5u) % 8u) * p.stagger;
@@ -323,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                 //      vmcnt allowance = VMEM operations issued AFTER the weight DMA in the previous stage
                 {
                     constexpr int khp = (kh + 2) % 3;         // filter row of the previous stage
-                    constexpr int allow = khp == 0 ? (ACT ? 5 : 3) : (khp == 1 ? (ACT ? 0 : 2) : 0);
+                    constexpr int allow = khp == 0 ? (ACT ? 5 : 3) : (khp == 1 ? (ACT ? 0 : 2) : (AOUT ? 5 : 0));   // khp == 2: the side-output stores
                     if (s == 0 && pair == 0 && stores_in_flight) {
                         w_wait_barrier(32); stores_in_flight = false;
                         if constexpr (STATS) stats_flush();      // the finished tile's statistics: one store, older than this stage's weight DMA
@@ -345,6 +359,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                                                                  (unsigned)img_bytes, 0x00020000);
                     }
                 };
+                int aout_soff = 0;
                 auto act_blk = [&]() {
                     if constexpr (ACT) {
                         if (kh == 2) {
@@ -352,15 +367,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                             else if (last_pair) ss_fetch(ss_sel ^ 1, 0);
                             else ss_fetch(ss_sel, ciA + 64);
                             const bool nxt = cb == 1 && last_pair;                 // chunk 0 of the NEXT tile (its plan is in `vo` since stage 2)
-                            int aout_soff = -1;
+                            // (without a next tile this stage re-activates the current tile's chunk 0 with a scale/shift table that was never
+                            //  staged -- harmless for the convolution, which never reads it, but not to be stored)
+                            const bool writer = AOUT && (nxt ? c0_nxt : c0_cur) == 0 && !(nxt && !has_next);
                             if constexpr (AOUT) {
                                 const int ch_off = cb == 0 ? (ciA + 32) * 2 : (last_pair ? 0 : (ciA + 64) * 2);
-                                aout_soff = (nxt ? c0_nxt : c0_cur) == 0 ? (nxt ? n_nxt : n_cur) * img_b + ch_off : -1;
-                                // (without a next tile this stage re-activates the current tile's chunk 0 with a scale/shift table
-                                //  that was never staged -- harmless for the convolution, which never reads it, but not to be stored)
-                                if (nxt && !has_next) aout_soff = -1;
+                                aout_soff = (nxt ? n_nxt : n_cur) * img_b + ch_off;
                             }
-                            p_activate(nxt ? inb_nxt : inb_cur, cb ^ 1, vo, aout_soff, rs_a);
+                            p_activate(nxt ? inb_nxt : inb_cur, cb ^ 1, vo, writer);
                             asm volatile("" ::: "memory");
                         }
                     }
@@ -373,6 +387,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                     w_issue(tn, c0n, wsel ^ 1);
                 }
                 asm volatile("" ::: "memory");                // VMEM order = source order: the counted waits depend on it
+                if constexpr (AOUT) {
+                    if (kh == 2) { aout_store(rs_a, aout_soff); asm volatile("" ::: "memory"); }   // 5 stores, the youngest VMEM operations of this stage
+                }
                 // ---- patch DMA for the next chunk (3 pieces in the kh = 0 stage, 2 in the kh = 1 stage)
                 if (kh < 2 && !(ACT && kh == 1)) {
                     // plain: 3 + 2 pieces over the kh = 0, 1 stages.  With the prologue all 5 in the kh = 0 stage: the activation that

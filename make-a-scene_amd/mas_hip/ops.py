@@ -516,7 +516,8 @@ class _NormActConv(torch.autograd.Function):
         wp = ConvWeight(weight, False, ctx.w_sources)
         b32 = bias.detach().float() if bias is not None else None
         res = nhwc(residual, cd) if residual is not None else None
-        need_wgrad = ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])
+        # (needs_input_grad reflects requires_grad of the inputs even under torch.no_grad(); cfg["grad"] is the caller's grad mode)
+        need_wgrad = cfg["grad"] and (ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]))
         y, ypart, yrows, a = conv_fwd_raw(x, ss, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, cfg["out_dtype"],
                                           want_stats=True, want_act=bool(need_wgrad and act != ACT_NONE))
         _stats_state["stash"] = (ypart, yrows) if ypart is not None else None
@@ -569,7 +570,7 @@ def norm_act_conv(x, weight, bias, gn_w=None, gn_b=None, residual=None, *, strid
     """padding = (top, bottom, left, right)."""
     cd = in_dtype or compute_dtype()
     cfg = dict(stride=stride, pad_top=padding[0], pad_bottom=padding[1], pad_left=padding[2], pad_right=padding[3], act=act,
-               upsample=bool(upsample), groups=groups, eps=eps, in_dtype=cd, out_dtype=out_dtype or cd)
+               upsample=bool(upsample), groups=groups, eps=eps, in_dtype=cd, out_dtype=out_dtype or cd, grad=torch.is_grad_enabled())
     if cfg["in_dtype"] == torch.float32 and cfg["out_dtype"] != torch.float32:
         raise RuntimeError("conv: fp32 input requires fp32 output")
     # Channel counts that are not a multiple of one 16-byte slot (RGB in/out, the 159 VQ-SEG classes) would take the
@@ -598,7 +599,7 @@ class _ResBlock(torch.autograd.Function):
     streaming pass instead of by a separate elementwise add over the full activation."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, groups, eps, cd, xpart=None, xrows=0):
+    def forward(ctx, x, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, groups, eps, cd, xpart=None, xrows=0, grad=True):
         _require_cuda(x, "resblock")
         x = nhwc(x, cd)
         n, c, h, w = x.shape
@@ -606,10 +607,10 @@ class _ResBlock(torch.autograd.Function):
         mr1, ss1 = gn_stats(x, f32(n1w), f32(n1b), groups, eps, xpart, xrows)
         ng = ctx.needs_input_grad
         hh, hpart, hrows, a1 = conv_fwd_raw(x, ss1, ConvWeight(c1w, False), f32(c1b), None, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU,
-                                            False, cd, want_stats=True, want_act=bool(ng[3] or ng[4]))
+                                            False, cd, want_stats=True, want_act=bool(grad and (ng[3] or ng[4])))
         mr2, ss2 = gn_stats(hh, f32(n2w), f32(n2b), groups, eps, hpart, hrows)
         y, ypart, yrows, a2 = conv_fwd_raw(hh, ss2, ConvWeight(c2w, False), f32(c2b), x, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU,
-                                           False, cd, want_stats=True, want_act=bool(ng[7] or ng[8]))
+                                           False, cd, want_stats=True, want_act=bool(grad and (ng[7] or ng[8])))
         _stats_state["stash"] = (ypart, yrows) if ypart is not None else None
         ctx.groups, ctx.cd = groups, cd
         ctx.save_for_backward(x, hh, mr1, ss1, mr2, ss2, n1w, c1w, n2w, c2w, a1, a2)
@@ -640,13 +641,13 @@ class _ResBlock(torch.autograd.Function):
             dx, dg1w, dg1b = gn_bwd(x, da1, dy, groups, ACT_AFFINE_SILU, n1w.detach().float(), mr1, ss1)
         cast = lambda g, ref: g.to(ref.dtype) if g is not None else None
         return (dx, cast(dg1w, n1w), cast(dg1b, n1w), cast(dw1, c1w), cast(db1, c1w), cast(dg2w, n2w), cast(dg2b, n2w),
-                cast(dw2, c2w), cast(db2, c2w), None, None, None, None, None)
+                cast(dw2, c2w), cast(db2, c2w), None, None, None, None, None, None)
 
 
 def resblock(x, norm1, conv1, norm2, conv2):
     xpart, xrows = _take_stats(x)
     return _attach_stats(_ResBlock.apply(x, norm1.weight, norm1.bias, conv1.weight, conv1.bias, norm2.weight, norm2.bias, conv2.weight,
-                                         conv2.bias, norm1.num_groups, norm1.eps, compute_dtype(), xpart, xrows))
+                                         conv2.bias, norm1.num_groups, norm1.eps, compute_dtype(), xpart, xrows, torch.is_grad_enabled()))
 
 
 # --------------------------------------------------------------------------- #
