@@ -104,7 +104,18 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
 
     // ---- tile cursor: the decode (image, tile row, tile column) is advanced incrementally (no division in the loop) and parks on
     //      the last tile (harmless re-reads at the end)
-    struct TC { int n, h0, w0, idx; };
+    // ud / ux: byte offset of the tile's first dY pixel / of input pixel (h0, w0) (both for channel co0 / ci0), fd / fx: the tile and
+    // its halo lie inside the image -- the DMA offsets of such a tile are `lane constant + ud / ux` (one VALU add per piece); edge
+    // tiles take the general per-lane address code.  (Round 2 recomputed the full address of every piece -- two integer multiplies
+    // and ~20 VALU per piece, 7 pieces per tile -- which made ~150 of the ~320 VALU instructions a wave issues per 72 MFMAs.)
+    struct TC { int n, h0, w0, idx, ud, ux; bool fd, fx; };
+    const int ups = p.upsample ? 1 : 0;
+    auto finish_tc = [&](TC& c) {
+        c.ud = (((c.n * p.Ho + c.h0 + wave) * p.Wo + c.w0) * p.Cout + co0) * 2;
+        c.ux = (((c.n * p.H + (c.h0 >> ups)) * p.W + (c.w0 >> ups)) * p.Cin + ci0) * 2;
+        c.fd = (c.h0 + D_THW <= p.Ho) && (c.w0 + D_TWW <= p.Wo);
+        c.fx = (c.h0 >= p.pad_top) && (c.h0 - p.pad_top + D_PH <= p.Hl) && (c.w0 >= p.pad_left) && (c.w0 - p.pad_left + D_PW <= p.Wl);
+    };
     const int adv_w = (p.nsplit % p.tiles_w) * D_TWW, adv_q = p.nsplit / p.tiles_w;
     const int adv_h = (adv_q % p.tiles_h) * D_THW, adv_n = adv_q / p.tiles_h;
     const int lim_w = p.tiles_w * D_TWW, lim_h = p.tiles_h * D_THW;
@@ -112,6 +123,7 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
         int t = split;
         TC c; c.w0 = (t % p.tiles_w) * D_TWW; t /= p.tiles_w;
         c.h0 = (t % p.tiles_h) * D_THW; c.n = t / p.tiles_h; c.idx = 0;
+        finish_tc(c);
         return c;
     };
     auto next_tile = [&](TC c) {
@@ -120,20 +132,47 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
         c.w0 += adv_w; int cy = c.w0 >= lim_w; c.w0 -= cy ? lim_w : 0;
         c.h0 += adv_h + (cy ? D_THW : 0); cy = c.h0 >= lim_h; c.h0 -= cy ? lim_h : 0;
         c.n += adv_n + cy;
+        finish_tc(c);
         return c;
     };
     auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };   // per-piece address terms are recomputed,
                                                                                        // not kept in registers across the tile loop
+    // lane parts of the fast-path offsets.  dY piece DYK wave + k: pixel row `wave` (SPLIT 1: 16 wave + 4 k + (lane >> 4) < 16 (wave + 1)),
+    // column 4 k + (lane >> 4): lane part = column (lane >> 4), block, slot; + k * 8 Cout bytes per piece.  Patch piece wave + NW k:
+    // pixel P = 8 (wave + NW k) + (lane >> 3) -> (pr, pc) relative to the tile's (h0 - pad_top, w0 - pad_left); with the Upsample fold
+    // (h0, w0 even) the source pixel is ((h0 >> 1) + ((pr - pad_top) >> 1), ...).  Dead lanes (P >= 180) carry the out-of-range marker.
+    static_assert(SPLIT == 1 || true, "");
+    const int dyL = ((lane >> 4) * p.Cout + ((((lane >> 2) & 3) ^ ((lane >> 4) & 3)) * 32) + (lane & 3) * 8) * 2;
+    int xL[XK], prpc[XK];                          // prpc: patch row | patch column << 8 of the lane's pixel (the bounds test of edge tiles)
+#pragma unroll
+    for (int k = 0; k < XK; ++k) {
+        const int P = (wave + NW * k) * 8 + (lane >> 3);
+        const int pr = (P * 3641) >> 16, pc = P - pr * D_PW;
+        prpc[k] = pr | (pc << 8);
+        const int r = (pr - p.pad_top) >> ups, cc = (pc - p.pad_left) >> ups;           // arithmetic shifts: -1 >> 1 == -1
+        const int blk = ((lane >> 2) & 1) ^ ((P >> 1) & 1);
+        xL[k] = (P < D_NPP) ? ((r * p.W + cc) * p.Cin + blk * 32 + (lane & 3) * 8) * 2 : D_OOB;
+    }
+
     // dY: wave w moves pieces DYK w .. DYK w + DYK - 1 (4 pixels x 256 B each); lane -> pixel 4 piece + (lane >> 4), physical 64-byte
     // block (lane >> 2) & 3 holding logical block ^ (pixel & 3), 16-byte slot lane & 3
     auto dy_issue = [&](const TC& c, int buf, int k) {
-        const int lane = fresh_lane();
         const int piece = wave * DYK + k;
-        const int pix = piece * 4 + (lane >> 4);
-        const int ho = c.h0 + (pix >> 4), wo = c.w0 + (pix & 15);
-        const int blk = ((lane >> 2) & 3) ^ (pix & 3);
-        const bool ok = (ho < p.Ho) && (wo < p.Wo);
-        const int vo = ok ? (int)((((size_t)(c.n * p.Ho + ho) * p.Wo + wo) * p.Cout + co0 + blk * 32 + (lane & 3) * 8) * 2) : D_OOB;
+        int vo;
+        if constexpr (SPLIT == 1) {                 // pixel row `wave`, column 4 k + (lane >> 4): lane constant + uniform base
+            vo = dyL + (c.ud + k * 8 * p.Cout);
+            if (!c.fd) {                            // ragged tile (uniform branch): rows / columns past the map read as zeros
+                const bool ok = (c.h0 + wave < p.Ho) && (c.w0 + 4 * k + (lane >> 4) < p.Wo);
+                vo = ok ? vo : D_OOB;
+            }
+        } else {
+            const int lane = fresh_lane();
+            const int pix = piece * 4 + (lane >> 4);
+            const int ho = c.h0 + (pix >> 4), wo = c.w0 + (pix & 15);
+            const int blk = ((lane >> 2) & 3) ^ (pix & 3);
+            const bool ok = (ho < p.Ho) && (wo < p.Wo);
+            vo = ok ? (int)((((size_t)(c.n * p.Ho + ho) * p.Wo + wo) * p.Cout + co0 + blk * 32 + (lane & 3) * 8) * 2) : D_OOB;
+        }
 #ifdef D_ABL_NODMA
         if (p.N != -12345) return;
 #endif
@@ -141,21 +180,14 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
     };
     // patch: wave w moves pieces w, w + NW, .. below 23 (8 pixels x 128 B each); lane -> patch pixel 8 piece + (lane >> 3), physical
     // block (lane >> 2) & 1 holding logical block ^ ((pixel >> 1) & 1), slot lane & 3
-    auto x_pix = [&](int k, const TC& c, int lane, int& P, int& ih, int& iw) -> bool {
-        P = (wave + NW * k) * 8 + (lane >> 3);
-        const int pr = (P * 3641) >> 16, pc = P - pr * D_PW;     // P / 18 for P < 3641
-        ih = c.h0 + pr - p.pad_top; iw = c.w0 + pc - p.pad_left;
-        const bool inb = (P < D_NPP) && (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl);
-        if (p.upsample) { ih >>= 1; iw >>= 1; }
-        return inb;
+    auto x_inb = [&](int k, const TC& c) -> bool {                // is the lane's patch pixel a pixel of the image (else: zero padding)
+        const int pr = prpc[k] & 0xff, pc = prpc[k] >> 8;
+        return (unsigned)(c.h0 - p.pad_top + pr) < (unsigned)p.Hl && (unsigned)(c.w0 - p.pad_left + pc) < (unsigned)p.Wl;
     };
     auto x_issue = [&](const TC& c, int buf, int k) {
         if (wave + NW * k >= 23) return;
-        const int lane = fresh_lane();
-        int P, ih, iw;
-        const bool inb = x_pix(k, c, lane, P, ih, iw);
-        const int blk = ((lane >> 2) & 1) ^ ((P >> 1) & 1);
-        const int vo = inb ? (int)((((size_t)(c.n * p.H + ih) * p.W + iw) * p.Cin + ci0 + blk * 32 + (lane & 3) * 8) * 2) : D_OOB;
+        int vo = xL[k] + c.ux;                      // (dead lanes: the marker stays out of range after the add)
+        if (!c.fx) vo = x_inb(k, c) ? vo : D_OOB;   // edge tile (uniform branch): halo pixels outside the image read as zeros
 #ifdef D_ABL_NODMA
         if (p.N != -12345) return;
 #endif
@@ -179,9 +211,8 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
     };
     auto x_activate = [&](const TC& c, int buf, int k) {
         if (wave + NW * k >= 23) return;
-        const int lane = fresh_lane();
-        int P, ih, iw;
-        if (!x_pix(k, c, lane, P, ih, iw)) return;
+        const int P = (wave + NW * k) * 8 + (lane >> 3);
+        if (P >= D_NPP || !(c.fx || x_inb(k, c))) return;
         const int u = lane & 7;
         unsigned char* dst = xb + buf * D_XP + P * 128 + ((((u >> 2) ^ ((P >> 1) & 1))) << 6) + (u & 3) * 16;
         u32x4 v = *reinterpret_cast<const u32x4*>(dst);
@@ -260,6 +291,9 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
         bf16x8 aw[3], bf[PREFETCH ? 2 : 1][3];
+        int bxo[3][2], xsel = 0;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) { bxo[kw][0] = 2 * D_DY + b_off[kw]; bxo[kw][1] = 2 * D_DY + (b_off[kw] ^ 64); }
         auto kw_needed = [&](int pr, int kw) {                    // does step pr of this wave use the patch fragment kw ?
             bool need = false;
 #pragma unroll
@@ -269,13 +303,22 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
             }
             return need;
         };
-        auto load_b = [&](const unsigned char* xs, int pr) {      // -> bf[PREFETCH ? pr & 1 : 0]
+        // patch fragment addresses: bxo[kw][parity of the patch row] = LDS byte offset of the CURRENT tile's patch buffer + the lane's
+        // swizzled offset; a read is then `base register + compile-time offset` (row * 2304, +512 for the second half) -- round 2
+        // formed every address with two VALU adds (120 per tile).  The bases move to the next buffer of the ring once per tile.
+        auto load_b = [&](int pr) {                               // -> bf[PREFETCH ? pr & 1 : 0], from the buffer bxo points at
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 if (!kw_needed(pr, kw)) continue;
-                const unsigned char* b0 = xs + pr * (D_PW * 128) + (b_off[kw] ^ ((pr & 1) << 6));      // patch pixels (pr, kw + 8g + j)
+                const unsigned char* b0 = smem + bxo[kw][pr & 1] + pr * (D_PW * 128);                  // patch pixels (pr, kw + 8g + j)
                 bf[PREFETCH ? (pr & 1) : 0][kw] = d_tr_frag(b0, b0 + 4 * 128);
             }
+        };
+        auto advance_bases = [&]() {                              // ring of three patch buffers
+            const int dxn = xsel == 2 ? -2 * D_XP : D_XP;
+            xsel = xsel == 2 ? 0 : xsel + 1;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) { bxo[kw][0] += dxn; bxo[kw][1] += dxn; }
         };
         auto load_a = [&](const unsigned char* dys, int pr) {     // -> aw[pr % 3]
             const unsigned char* a0 = dys + pr * (16 * 256) + a_lane;                                 // dY pixels (pr, 8g + j)
@@ -295,7 +338,7 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
 #endif
             }
         };
-        if constexpr (PREFETCH) load_b(xb, 0);
+        if constexpr (PREFETCH) load_b(0);
         load_a(dyb, 0);
         for (int j = 0; j < n_mine; ++j) {
 #ifdef D_TIMELINE
@@ -320,10 +363,11 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
                     DTS(1);
                 }
                 if constexpr (PREFETCH) {
-                    if (pr + 1 < D_PH) load_b(xs, pr + 1);
-                    else load_b(xb + xn * D_XP, 0);               // step 9: row 0 of the next tile
+                    if (pr + 1 < D_PH) load_b(pr + 1);
+                    else { advance_bases(); load_b(0); }          // step 9: row 0 of the next tile (every read of this tile's patch has been issued)
                 } else {
-                    load_b(xs, pr);
+                    load_b(pr);
+                    if (pr == D_PH - 1) advance_bases();
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_kh(pr, 2);                                   // the oldest dY row first: its registers take the next fragment
