@@ -208,13 +208,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
             if (!live) continue;
             unsigned char* dst = patch + buf * W_PATCH + q * 64 + (((lane & 3) ^ ((q >> 2) & 3)) << 4);
             u32x4 v = *reinterpret_cast<const u32x4*>(dst);
-            bf16_t* tv = reinterpret_cast<bf16_t*>(&v);
             if (p.act == MAS_ACT_AFFINE_SILU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) tv[e] = (bf16_t)silu_f((float)tv[e] * sc[e] + sh[e]);
+                for (int q4 = 0; q4 < 4; ++q4) v[q4] = act_pair_bf16<true>(v[q4], f32x2{sc[2 * q4], sc[2 * q4 + 1]}, f32x2{sh[2 * q4], sh[2 * q4 + 1]});
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) tv[e] = (bf16_t)((float)tv[e] * sc[e] + sh[e]);
+                for (int q4 = 0; q4 < 4; ++q4) v[q4] = act_pair_bf16<false>(v[q4], f32x2{sc[2 * q4], sc[2 * q4 + 1]}, f32x2{sh[2 * q4], sh[2 * q4 + 1]});
             }
             *reinterpret_cast<u32x4*>(dst) = v;
             if constexpr (AOUT) {

@@ -578,6 +578,14 @@ template <typename T, typename TO, int KS, int STRIDE>
 int launch_bc(const ConvParams& p, hipStream_t s) {
     if (p.Cout <= 32) return launch<T, TO, KS, STRIDE, 32, 1>(p, s);
     if (p.Cout <= 64) return launch<T, TO, KS, STRIDE, 64, 1>(p, s);
+    // Small maps (the 16x16 level of the encoder / decoder: 512 -> 512 at batch 32 is 256 tiles of 8x16 pixels x 128 couts) leave half
+    // of the chip's 2 x 256 work-group slots empty -- one wave per SIMD, nothing to overlap with; 64-cout tiles double the work-groups
+    // (the packed weight image is row-addressed: any 64-row window of it is a valid tile).  MAS_CONV_BC64=0: always 128.
+    static const int bc64 = mas_env_int("MAS_CONV_BC64", 1);
+    if (bc64) {
+        const long long tiles128 = (long long)p.N * mas_cdiv(p.Ho, 8) * mas_cdiv(p.Wo, TW) * mas_cdiv(p.Cout, 128);
+        if (tiles128 < 2LL * mas_num_cus()) return launch<T, TO, KS, STRIDE, 64, 1>(p, s);
+    }
     return launch<T, TO, KS, STRIDE, 128, 2>(p, s);
 }
 

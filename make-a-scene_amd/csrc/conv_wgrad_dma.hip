@@ -216,14 +216,14 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
         const int u = lane & 7;
         unsigned char* dst = xb + buf * D_XP + P * 128 + ((((u >> 2) ^ ((P >> 1) & 1))) << 6) + (u & 3) * 16;
         u32x4 v = *reinterpret_cast<const u32x4*>(dst);
-        const bool silu = p.act == MAS_ACT_AFFINE_SILU;
+        if (p.act == MAS_ACT_AFFINE_SILU) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {                             // (scale, shift) of channels 2q, 2q+1
-            const f32x4 r = rss[q];
-            float lo = __uint_as_float(v[q] << 16) * r[0] + r[1], hi = __uint_as_float(v[q] & 0xffff0000u) * r[2] + r[3];
-            if (silu) { lo = silu_f(lo); hi = silu_f(hi); }
-            bf16_t pk[2] = {(bf16_t)lo, (bf16_t)hi};
-            v[q] = *reinterpret_cast<const unsigned*>(pk);
+            for (int q = 0; q < 4; ++q)                           // rss[q] = (scale, shift) of channels 2q, 2q+1
+                v[q] = act_pair_bf16<true>(v[q], f32x2{rss[q][0], rss[q][2]}, f32x2{rss[q][1], rss[q][3]});
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                v[q] = act_pair_bf16<false>(v[q], f32x2{rss[q][0], rss[q][2]}, f32x2{rss[q][1], rss[q][3]});
         }
         *reinterpret_cast<u32x4*>(dst) = v;
     };
@@ -285,7 +285,11 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
     auto run = [&](auto HALF_T) {
         constexpr int HALF = decltype(HALF_T)::v;
         constexpr int LO = SPLIT == 1 ? 0 : (HALF ? 5 : 0), HI = SPLIT == 1 ? 9 : (HALF ? 9 : 5);
-        constexpr bool PREFETCH = SPLIT == 1 && !ACT;     // the prologue variant spends those 12 registers on the scale/shift pairs
+#ifdef D_NO_ACT_PREFETCH   // A/B builds: round 2's rule (the prologue variant spent those 12 registers on address temporaries)
+        constexpr bool PREFETCH = SPLIT == 1 && !ACT;
+#else
+        constexpr bool PREFETCH = SPLIT == 1;             // (round 3: the leaner address code freed the 12 registers for the prologue variant too)
+#endif
 #pragma unroll
         for (int t = 0; t < HI - LO; ++t)
 #pragma unroll

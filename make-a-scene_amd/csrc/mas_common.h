@@ -84,6 +84,26 @@ __device__ __forceinline__ typename Vec8<T>::type zero8() {
 
 // v_exp_f32 + v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence: this runs once per staged element
 __device__ __forceinline__ float silu_f(float u) { return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)); }
+// two at a time on the packed-fp32 instructions (v_pk_mul / v_pk_add around the two transcendentals each): bitwise the same values
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ f32x2 silu2_f(f32x2 u) {
+    f32x2 t = u * -1.4426950408889634f;
+    t[0] = __builtin_amdgcn_exp2f(t[0]); t[1] = __builtin_amdgcn_exp2f(t[1]);
+    t = t + 1.0f;
+    t[0] = __builtin_amdgcn_rcpf(t[0]); t[1] = __builtin_amdgcn_rcpf(t[1]);
+    return u * t;
+}
+// one dword of two bf16 -> act(x * scale + shift) -> one dword of two bf16 (round to nearest even: v_cvt_pk_bf16_f32)
+template <bool SILU>
+__device__ __forceinline__ unsigned act_pair_bf16(unsigned w, f32x2 sc, f32x2 sh) {
+    f32x2 x;
+    x[0] = __uint_as_float(w << 16); x[1] = __uint_as_float(w & 0xffff0000u);
+    f32x2 u = x * sc + sh;
+    if constexpr (SILU) u = silu2_f(u);
+    const bf16x2 o = __builtin_convertvector(u, bf16x2);
+    return *reinterpret_cast<const unsigned*>(&o);
+}
 // d silu(u)/du = s*(1+u*(1-s)),  s = sigmoid(u)
 __device__ __forceinline__ float dsilu_f(float u) { float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u)); return s * (1.0f + u * (1.0f - s)); }
 

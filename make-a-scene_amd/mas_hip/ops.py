@@ -337,9 +337,13 @@ def _preferred_layout(d: ConvDesc) -> int:
 _stat_rows_memo = {}
 _act_out_memo = {}
 # Activation side output (mas_conv_fwd_act): the forward convolution of a GroupNorm(+SiLU)-fed layer also writes the activated input
-# it forms in its loader; the weight gradient of that layer then runs prologue-free on it instead of recomputing the activation
-# (conv_wgrad_dma: 0.655 ms vs 0.79 ms at 128->128 @256^2).  Costs one more saved tensor per such layer.  MAS_CONV_ACT_OUT=0: off.
-_ACT_OUT = os.environ.get("MAS_CONV_ACT_OUT", "1") == "1"
+# it forms in its loader; the weight gradient of that layer then runs prologue-free on it instead of recomputing the activation.
+# OFF by default (MAS_CONV_ACT_OUT=1 turns it on).  Measured on one box, VQ-IMG step (profiles/r03_ab_v2.txt): the weight gradients
+# gain 2.3 ms per step (0.73 -> 0.585 ms at 128->128 @256^2), but the 537 MB the producing convolution now also writes cost it
+# +0.10 ms per launch (0.66 -> 0.76 ms, wherever in the stage the stores are issued: with or without a counted wait behind them) =
+# 1.9 ms per step: 67.65 vs 68.06 ms, 0.6 %, for one more saved tensor per layer (12 GB at batch 32) and a dominant-kernel roofline
+# fraction of 0.40 instead of 0.44.  Not worth shipping; kept, tested, as an option.
+_ACT_OUT = os.environ.get("MAS_CONV_ACT_OUT", "0") == "1"
 
 
 def _act_out_supported(d: ConvDesc) -> bool:

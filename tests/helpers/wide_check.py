@@ -110,7 +110,7 @@ def main():
         err = float((y.float().cpu() - ref).abs().max() / ref.abs().max())
         ok = err < 1e-2 and lay == mas_hip.WLAYOUT_K32
         extra = ""
-        if act and not ups and (ho, wo) == (h, w) and os.environ.get("MAS_CONV_ACT_OUT", "1") == "1":
+        if act and not ups and (ho, wo) == (h, w) and os.environ.get("MAS_CONV_ACT_OUT", "0") == "1":
             # activation side output (mas_conv_fwd_act): the same launch also writes a = act(x * scale + shift) in bf16 -- every pixel,
             # once (cout tile 0 only), the convolution result bitwise unchanged
             y2, a_out = ops.conv_fwd_raw(cl(x), ss.to(dev), ops.ConvWeight(param.to(dev), tr), b.to(dev), cl(res) if has_res else None,

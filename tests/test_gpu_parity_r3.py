@@ -71,7 +71,7 @@ def _wide_grid_and_tiles(n, ho, wo, cout):
 # --------------------------------------------------------------------------------------------------------------
 # 1. the dominant launch through the default dispatch, multi-tile walk
 # --------------------------------------------------------------------------------------------------------------
-def test_dominant_conv_wide_real_shape_vs_cpu_fp32():
+def test_dominant_conv_wide_real_shape_vs_cpu_fp32(monkeypatch):
     """128->128 3x3 at 256x256, bf16, N=16, UNPACKED weight (ops.ConvWeight): the library picks the K32 image, i.e.
     conv3x3_wide_kernel, with 2048 tiles on 1024 work-groups.  Tolerances: bf16 outputs 1e-2 of max|ref| (0.4 % rounding of the
     largest value + fp32 accumulation order); fp32 weight / bias gradients 2e-3."""
@@ -110,8 +110,9 @@ def test_dominant_conv_wide_real_shape_vs_cpu_fp32():
                               n, *geo, 0, False, bf)
         dw0, db0 = ops.conv_wgrad_raw(xd, None, dyd, n, *geo, 0, False, True)
         dw2, db2 = ops.conv_wgrad_raw(xd, ssd, dyd, n, *geo, 2, False, True)
-        # the path the training step takes since round 3: the forward also writes the activated input (mas_conv_fwd_act), the weight
-        # gradient runs prologue-free on it
+        # the optional path (MAS_CONV_ACT_OUT=1): the forward also writes the activated input (mas_conv_fwd_act), the weight gradient runs
+        # prologue-free on it
+        monkeypatch.setattr(ops, "_ACT_OUT", True)
         y1a, a_out = ops.conv_fwd_raw(xd, ssd, ops.ConvWeight(wd, False), bd, None, n, *geo, 2, False, bf, want_act=True)
         assert a_out is not None and torch.equal(y1a, y1)
         dw3, db3 = ops.conv_wgrad_raw(a_out, None, dyd, n, *geo, 0, False, True)
