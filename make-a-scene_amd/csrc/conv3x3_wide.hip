@@ -464,6 +464,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                     rv[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, pc < ob_cur[2] ? ob_cur[j] : W_OOB, pc * row_bytes, 0);
                 }
             };
+            // fused statistics: per lane the sum and the sum of squares of its 4 couts over its pixels, as two packed-fp32 pairs each
+            // (v_pk_add_f32 / v_pk_fma_f32: 4 VALU per pixel).  Of the fp32 values BEFORE the bf16 rounding: closer to what
+            // torch.nn.GroupNorm computes on the reference's fp32 activations than the statistics of the stored tensor, and free of
+            // the unpacking the round-2 version paid (12 VALU per pixel, +0.07 ms per launch).
+            f32x2 st_s[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}}, st_q[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
+            if constexpr (STATS) {
+                // ragged tiles only (wave-uniform branch): a pixel outside the map must not count -- its accumulators are set to
+                // -bias, so that (with the residual load of an out-of-range offset returning 0) its value is exactly 0; its store is
+                // dropped by the bounds check anyway.  Full tiles (all but the last row / column of tiles) skip this.
+                if (!__all(ob_cur[2] > 27 && ob_cur[0] != W_OOB && ob_cur[1] != W_OOB)) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int pc = (r & 3) + 8 * (r >> 2);
+                            if (!((pc < ob_cur[2]) && (ob_cur[j] != W_OOB))) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) acc[i][j][r] = -bv[i];
+                            }
+                        }
+                }
+            }
             auto pack = [&](int j, int r) {
                 float v[4];
 #pragma unroll
@@ -472,6 +494,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                     const bf16_t* rb = reinterpret_cast<const bf16_t*>(&rv[r]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] += (float)rb[i];
+                }
+                if constexpr (STATS) {          // (pixels past a ragged edge were zeroed above: they add nothing)
+                    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+                    st_s[0] += a; st_s[1] += b;
+                    st_q[0] = a * a + st_q[0]; st_q[1] = b * b + st_q[1];
                 }
                 u32x2 o;
                 bf16_t* ob = reinterpret_cast<bf16_t*>(&o);
@@ -482,17 +509,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
 #ifndef W_ST_AUX
 #define W_ST_AUX 0
 #endif
-            float st_s[4] = {0.0f, 0.0f, 0.0f, 0.0f}, st_q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             auto store = [&](int j, int r, u32x2 o) {
                 const int pc = (r & 3) + 8 * (r >> 2);
                 const bool ok = (pc < ob_cur[2]) && (ob_cur[j] != W_OOB);
                 __builtin_amdgcn_raw_buffer_store_b64(o, rs_y, ok ? ob_cur[j] : W_OOB, pc * row_bytes, W_ST_AUX);
-                if (STATS && ok) {              // statistics of the ROUNDED values, i.e. of what the consumer will read
-                    const float f0 = __uint_as_float(o[0] << 16), f1 = __uint_as_float(o[0] & 0xffff0000u);
-                    const float f2 = __uint_as_float(o[1] << 16), f3 = __uint_as_float(o[1] & 0xffff0000u);
-                    st_s[0] += f0; st_q[0] += f0 * f0; st_s[1] += f1; st_q[1] += f1 * f1;
-                    st_s[2] += f2; st_q[2] += f2 * f2; st_s[3] += f3; st_q[3] += f3 * f3;
-                }
             };
             if constexpr (RES) {
                 res_load(0);
@@ -517,7 +537,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                 float* sl = reinterpret_cast<float*>(smem + W_STAT) + wave * 256 + (4 * l31) * 2;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float a = st_s[i] + __shfl_xor(st_s[i], 32), b = st_q[i] + __shfl_xor(st_q[i], 32);
+                    const float ss_ = st_s[i >> 1][i & 1], qq_ = st_q[i >> 1][i & 1];
+                    const float a = ss_ + __shfl_xor(ss_, 32), b = qq_ + __shfl_xor(qq_, 32);
                     if (g == 0) { sl[2 * i] = a; sl[2 * i + 1] = b; }
                 }
                 if (tid == 0) { int* meta = reinterpret_cast<int*>(smem + W_STAT + 8 * 128 * 2 * 4); meta[0] = ob_cur[3]; meta[1] = c0_cur; }

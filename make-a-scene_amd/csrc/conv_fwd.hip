@@ -582,7 +582,7 @@ int launch_bc(const ConvParams& p, hipStream_t s) {
     // of the chip's 2 x 256 work-group slots empty -- one wave per SIMD, nothing to overlap with; 64-cout tiles double the work-groups
     // (the packed weight image is row-addressed: any 64-row window of it is a valid tile).  MAS_CONV_BC64=0: always 128.
     static const int bc64 = mas_env_int("MAS_CONV_BC64", 1);
-    if (bc64) {
+    if (bc64 && STRIDE == 1) {                  // (stride 2 measured slower with 64-cout tiles: 0.114 vs 0.083 ms at 512 -> 512 @32^2)
         const long long tiles128 = (long long)p.N * mas_cdiv(p.Ho, 8) * mas_cdiv(p.Wo, TW) * mas_cdiv(p.Cout, 128);
         if (tiles128 < 2LL * mas_num_cus()) return launch<T, TO, KS, STRIDE, 64, 1>(p, s);
     }
