@@ -106,6 +106,12 @@ int    mas_gn_bwd(const void* x, const void* da, const void* dres, int dtype, in
                   int act, const float* gamma, const float* mean_rstd, const float* scale_shift,
                   void* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, void* stream);
 
+/* ---- materialised GroupNorm(+SiLU) output: a [N,HW,C] = act(x * scale + shift), scale_shift [N][C][2] from mas_gn_stats, act
+ * MAS_ACT_AFFINE or MAS_ACT_AFFINE_SILU, rounded to `dtype` exactly as the fused loaders of mas_conv_fwd / mas_conv_wgrad round it
+ * (reference models/modules.py:121-128 as a tensor).  The optional alternative to the fused prologue: one read + one write, after
+ * which the convolution and its weight gradient run prologue-free (act = NONE) on `a`.                                          */
+int mas_gn_act(const void* x, void* a, int dtype, int N, int HW, int C, int act, const float* scale_shift, void* stream);
+
 /* ---- convolution forward  (replaces F.conv2d at modules.py:49,68,93,100,113,145-160,
  * 219,236,345,364 and vqvae.py:15,18, with the GroupNorm-apply/SiLU of modules.py:121-128
  * fused into the input loader and bias / residual add (modules.py:136,191) into the epilogue).

@@ -368,6 +368,59 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply(const T* __restrict__ x, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// materialised activation: a = act(x * scale + shift) in the activation dtype (one read, one write).  The optional alternative to
+// the fused loader prologue (ops.py MAS_GN_MATERIALIZE): the forward convolution AND the weight gradient of a GroupNorm(+SiLU)-fed
+// layer then run prologue-free on `a`.  A thread owns a fixed 16-byte channel unit (scale / shift pairs in registers) and walks
+// pixels, four 16-byte loads in flight.
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_act_kernel(const T* __restrict__ x, T* __restrict__ a, int C, int act, const float* __restrict__ ss,
+                                                    long long units_per_n) {
+    constexpr int EPU = 16 / (int)sizeof(T);
+    const int upp = C / EPU;
+    const int n = blockIdx.y;
+    const size_t base = (size_t)n * (size_t)units_per_n * EPU;
+    const long long u0 = (long long)blockIdx.x * NT + threadIdx.x;
+    const int cu = (int)(u0 % upp);
+    f32x2 sc[EPU / 2], sh[EPU / 2];
+#pragma unroll
+    for (int e = 0; e < EPU / 2; ++e) {
+        const float* q = ss + ((size_t)n * C + cu * EPU + 2 * e) * 2;
+        sc[e] = f32x2{q[0], q[2]}; sh[e] = f32x2{q[1], q[3]};
+    }
+    auto body = [&](u32x4 v, size_t off) {
+        if constexpr (sizeof(T) == 2) {
+            if (act == MAS_ACT_AFFINE_SILU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = act_pair_bf16<true>(v[q], sc[q], sh[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = act_pair_bf16<false>(v[q], sc[q], sh[q]);
+            }
+        } else {
+            float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float u = f[e] * sc[e >> 1][e & 1] + sh[e >> 1][e & 1];
+                f[e] = act == MAS_ACT_AFFINE_SILU ? silu_f(u) : u;
+            }
+        }
+        *reinterpret_cast<u32x4*>(a + off) = v;
+    };
+    const long long stride = (long long)gridDim.x * NT;
+    long long u = u0;
+    for (; u + 3 * stride < units_per_n; u += 4 * stride) {
+        const size_t o0 = base + (size_t)u * EPU, o1 = o0 + (size_t)stride * EPU, o2 = o1 + (size_t)stride * EPU, o3 = o2 + (size_t)stride * EPU;
+        const u32x4 v0 = *reinterpret_cast<const u32x4*>(x + o0), v1 = *reinterpret_cast<const u32x4*>(x + o1);
+        const u32x4 v2 = *reinterpret_cast<const u32x4*>(x + o2), v3 = *reinterpret_cast<const u32x4*>(x + o3);
+        body(v0, o0); body(v1, o1); body(v2, o2); body(v3, o3);
+    }
+    for (; u < units_per_n; u += stride) {
+        const size_t off = base + (size_t)u * EPU;
+        body(*reinterpret_cast<const u32x4*>(x + off), off);
+    }
+}
+
 // Pass ordering against the Infinity Cache (256 MiB, memory side): the tensors of the 256x256 / 128x128 levels are 134-537 MB, so a
 // pass that re-walks a tensor in the SAME direction as the pass before it finds everything it needs already evicted, while the
 // opposite direction starts on the most recently touched ~quarter.  Convolutions and the backward apply pass walk images front
@@ -426,6 +479,29 @@ extern "C" int mas_gn_stats_from_partials(const float* partial, int N, int HW, i
     hipLaunchKernelGGL(gn_stats_finalize, dim3(N), dim3(NT), lds2, reinterpret_cast<hipStream_t>(stream), partial, HW, C, G, rows, eps, gamma, beta,
                        mean_rstd, scale_shift);
     MAS_CHECK_LAUNCH("gn_stats_from_partials");
+    return MAS_OK;
+}
+
+// a [N,HW,C] = act(x * scale + shift) with the per-(sample, channel) scale / shift pairs of mas_gn_stats (act: MAS_ACT_AFFINE or
+// MAS_ACT_AFFINE_SILU), rounded to the activation dtype exactly as the fused conv / wgrad loaders round it
+extern "C" int mas_gn_act(const void* x, void* a, int dtype, int N, int HW, int C, int act, const float* scale_shift, void* stream) {
+    MAS_ENTER();
+    if (!x || !a || !scale_shift) MAS_FAIL(MAS_EINVAL, "gn_act: null argument");
+    if (act != MAS_ACT_AFFINE && act != MAS_ACT_AFFINE_SILU) MAS_FAIL(MAS_EINVAL, "gn_act: bad act %d", act);
+    if (N <= 0 || HW <= 0 || C <= 0) MAS_FAIL(MAS_EINVAL, "gn_act: bad shape");
+    const int epu = dtype == MAS_BF16 ? 8 : 4;
+    if (C % epu || NT % (C / epu)) MAS_FAIL(MAS_EUNSUPPORTED, "gn_act: C=%d: C/%d must divide %d", C, epu, NT);
+    const long long units_per_n = (long long)HW * C / epu;
+    int gx = (int)((units_per_n + NT - 1) / NT);
+    const int cap = mas_cdiv(4096, N) > 0 ? mas_cdiv(4096, N) : 1;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MAS_BF16)
+        hipLaunchKernelGGL(gn_act_kernel<bf16_t>, dim3(gx, N), dim3(NT), 0, s, (const bf16_t*)x, (bf16_t*)a, C, act, scale_shift, units_per_n);
+    else
+        hipLaunchKernelGGL(gn_act_kernel<float>, dim3(gx, N), dim3(NT), 0, s, (const float*)x, (float*)a, C, act, scale_shift, units_per_n);
+    MAS_CHECK_LAUNCH("gn_act");
     return MAS_OK;
 }
 

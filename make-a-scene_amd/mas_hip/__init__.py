@@ -48,6 +48,7 @@ _SIGNATURES = {
     "mas_gn_stats": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _sz, _p]),
     "mas_gn_bwd_workspace": (_sz, [_i, _i]),
     "mas_gn_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "mas_gn_act": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "mas_conv_fwd": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p]),
     "mas_conv_stat_rows": (_i, [C.POINTER(ConvDesc)]),
     "mas_conv_act_out_supported": (_i, [C.POINTER(ConvDesc)]),

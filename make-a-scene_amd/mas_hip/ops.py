@@ -307,6 +307,27 @@ def gn_stats(x: torch.Tensor, gamma, beta, groups: int, eps: float, partial: Opt
     return mr, ss
 
 
+# Materialised activation (mas_gn_act): in TRAINING the GroupNorm(+SiLU) output of a 3x3 layer is written once (one read + one write of
+# the tensor, 0.23 ms at 128 ch @256^2 x 32) and both its consumers -- the forward convolution and, in the backward, the weight
+# gradient -- run prologue-free on it, instead of each recomputing the activation in its loader (+0.18 ms and +0.145 ms at that
+# shape).  Under torch.no_grad() (inference, the encoder-stack line of bench.py) there is no second consumer and the fused loader
+# stays.  MAS_GN_MATERIALIZE=0: fused loaders everywhere (round 2's scheme).  A/B: profiles/r03_ab_v3.txt.
+_MATERIALIZE = os.environ.get("MAS_GN_MATERIALIZE", "1") == "1"
+
+
+def _gn_act_ok(c: int, dtype: torch.dtype) -> bool:
+    epu = 8 if dtype == torch.bfloat16 else 4
+    return c % epu == 0 and 256 % (c // epu) == 0 and getattr(lib(), "mas_gn_act", None) is not None
+
+
+def gn_act(x: torch.Tensor, ss: torch.Tensor, act: int) -> torch.Tensor:
+    """act(x * scale + shift) as a tensor (channels_last, x's dtype): ``mas_gn_act``."""
+    n, c, h, w = x.shape
+    a = torch.empty_like(x, memory_format=torch.channels_last)
+    check(lib().mas_gn_act(_ptr(x), _ptr(a), _DT[x.dtype], n, h * w, c, act, _ptr(ss), _stream()), "gn_act")
+    return a
+
+
 def gn_bwd(x, da, dres, groups, act, gamma, mr, ss):
     n, c, h, w = x.shape
     dx = torch.empty_like(x, memory_format=torch.channels_last)
@@ -522,8 +543,13 @@ class _NormActConv(torch.autograd.Function):
         res = nhwc(residual, cd) if residual is not None else None
         # (needs_input_grad reflects requires_grad of the inputs even under torch.no_grad(); cfg["grad"] is the caller's grad mode)
         need_wgrad = cfg["grad"] and (ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]))
-        y, ypart, yrows, a = conv_fwd_raw(x, ss, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, cfg["out_dtype"],
-                                          want_stats=True, want_act=bool(need_wgrad and act != ACT_NONE))
+        if act != ACT_NONE and need_wgrad and _MATERIALIZE and ks == 3 and not ups and _gn_act_ok(cin, x.dtype):
+            a = gn_act(x, ss, act)                  # both consumers (this convolution, its weight gradient) run prologue-free on it
+            y, ypart, yrows = conv_fwd_raw(a, None, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ACT_NONE, ups,
+                                           cfg["out_dtype"], want_stats=True)
+        else:
+            y, ypart, yrows, a = conv_fwd_raw(x, ss, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups,
+                                              cfg["out_dtype"], want_stats=True, want_act=bool(need_wgrad and act != ACT_NONE))
         _stats_state["stash"] = (ypart, yrows) if ypart is not None else None
         ctx.cfg = cfg
         ctx.dims = (n, h, w, cin, ho, wo, cout, ks)
@@ -610,11 +636,20 @@ class _ResBlock(torch.autograd.Function):
         f32 = lambda t: t.detach().float()
         mr1, ss1 = gn_stats(x, f32(n1w), f32(n1b), groups, eps, xpart, xrows)
         ng = ctx.needs_input_grad
-        hh, hpart, hrows, a1 = conv_fwd_raw(x, ss1, ConvWeight(c1w, False), f32(c1b), None, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU,
-                                            False, cd, want_stats=True, want_act=bool(grad and (ng[3] or ng[4])))
+        mat = _MATERIALIZE and grad and _gn_act_ok(c, x.dtype)
+
+        def conv(inp, ss_, wgt, bia, resid, need_w):
+            """-> (output, statistics table, rows, activated input or None)"""
+            if mat and need_w:
+                a_ = gn_act(inp, ss_, ACT_AFFINE_SILU)
+                return conv_fwd_raw(a_, None, ConvWeight(wgt, False), f32(bia), resid, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_NONE, False, cd,
+                                    want_stats=True) + (a_,)
+            return conv_fwd_raw(inp, ss_, ConvWeight(wgt, False), f32(bia), resid, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU, False,
+                                cd, want_stats=True, want_act=bool(grad and need_w))
+
+        hh, hpart, hrows, a1 = conv(x, ss1, c1w, c1b, None, ng[3] or ng[4])
         mr2, ss2 = gn_stats(hh, f32(n2w), f32(n2b), groups, eps, hpart, hrows)
-        y, ypart, yrows, a2 = conv_fwd_raw(hh, ss2, ConvWeight(c2w, False), f32(c2b), x, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU,
-                                           False, cd, want_stats=True, want_act=bool(grad and (ng[7] or ng[8])))
+        y, ypart, yrows, a2 = conv(hh, ss2, c2w, c2b, x, ng[7] or ng[8])
         _stats_state["stash"] = (ypart, yrows) if ypart is not None else None
         ctx.groups, ctx.cd = groups, cd
         ctx.save_for_backward(x, hh, mr1, ss1, mr2, ss2, n1w, c1w, n2w, c2w, a1, a2)

@@ -301,3 +301,33 @@ def test_wgrad_scratch_is_rezeroed_between_convolutions():
         for acc in ops._wgrad_scratch.values():
             assert float(acc.abs().max()) == 0.0
     assert len(ops._wgrad_scratch) >= 1
+
+
+# --------------------------------------------------------------------------------------------------------------
+# 6. materialised GroupNorm(+SiLU) output (mas_gn_act) == what the fused loaders form
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(3, 128, 40, 24), (2, 32, 9, 7), (4, 512, 16, 16)])
+def test_gn_act_equals_the_fused_prologue(shape, dtype):
+    """a = act(x * scale + shift) written by mas_gn_act (reference models/modules.py:121-128 as a tensor) against fp32 torch on the
+    CPU, and -- the property the training path relies on -- conv(a) with no prologue == conv(x) with the fused prologue, bitwise:
+    both round the activated operand to the activation dtype the same way."""
+    from mas_hip import ops, ACT_AFFINE, ACT_AFFINE_SILU, ACT_NONE
+    dev = _dev()
+    n, c, h, w = shape
+    g = torch.Generator(device="cpu").manual_seed(n * 1000 + c)
+    x = torch.randn(n, c, h, w, generator=g).to(dtype)
+    ss = torch.stack([1.0 + 0.2 * torch.randn(n, c, generator=g), 0.3 * torch.randn(n, c, generator=g)], dim=-1).contiguous()
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    for act in (ACT_AFFINE_SILU, ACT_AFFINE):
+        u = x.float() * ss[..., 0][:, :, None, None] + ss[..., 1][:, :, None, None]
+        ref = (_silu(u) if act == ACT_AFFINE_SILU else u).to(dtype).float()
+        a = ops.gn_act(xd, ss.to(dev), act)
+        assert a.dtype == dtype and a.is_contiguous(memory_format=torch.channels_last)
+        e = relerr(a, ref)
+        assert e < (1e-2 if dtype == torch.bfloat16 else 1e-5), (shape, dtype, act, e)
+        if c % 64 == 0 or dtype == torch.float32:
+            wt = (torch.randn(64, c, 3, 3, generator=g) / (9 * c) ** 0.5).to(dev)
+            y_fused = ops.conv_fwd_raw(xd, ss.to(dev), ops.ConvWeight(wt, False), None, None, n, h, w, c, h, w, 64, 3, 1, 1, 1, act, False, dtype)
+            y_mat = ops.conv_fwd_raw(a, None, ops.ConvWeight(wt, False), None, None, n, h, w, c, h, w, 64, 3, 1, 1, 1, ACT_NONE, False, dtype)
+            assert torch.equal(y_fused, y_mat), (shape, dtype, act)
