@@ -267,10 +267,14 @@ class ConvWeight:
 # --------------------------------------------------------------------------- #
 # raw kernel calls
 # --------------------------------------------------------------------------- #
-# Fused GroupNorm statistics (mas_conv_fwd_stats): OFF by default.  Measured on the VQ-IMG step (gpurun r2_21): the statistics
-# passes shrink by ~1.0 ms but the epilogue of the 20 producing conv launches grows by ~0.07 ms each at this kernel's register
-# pressure (spilled accumulator staging): 69.85 ms with, 69.7 ms without.  MAS_FUSED_GN_STATS=1 turns it on.
-_stats_state = {"on": os.environ.get("MAS_FUSED_GN_STATS", "0") == "1", "stash": None}
+# Fused GroupNorm statistics (mas_conv_fwd_stats): ON by default since round 3 (MAS_FUSED_GN_STATS=0 turns them off).  The wide
+# kernel's epilogue adds, per lane, the sums / sums of squares of its 4 output channels on the packed-fp32 instructions (values
+# before the bf16 rounding) and writes one table row per tile; the consumer's GroupNorm then needs only the finalize launch instead
+# of a pass over the tensor.  Round 2 measured this neutral (the producers were the GroupNorm+SiLU-loader variants of the kernel,
+# 17+ spilled registers: +0.07 ms per launch against the 0.10 ms pass it removes); with the activation materialised in training
+# (MAS_GN_MATERIALIZE) the producers are the prologue-free variants (no spills): +0.016 ms per launch, 64.47 -> 63.73 ms per step
+# (profiles/r03_ab_v4.txt).
+_stats_state = {"on": os.environ.get("MAS_FUSED_GN_STATS", "1") == "1", "stash": None}
 
 
 def _take_stats(x: torch.Tensor):
