@@ -159,6 +159,14 @@ int mas_conv_wgrad(const MasConvDesc* d, const void* x, const float* scale_shift
  * launches (the caller still owns it).                                                                                              */
 int mas_wgrad_commit(float* acc, float* dw_oihw, float* dbias, int Cout, int Cin, int ks, void* stream);
 
+/* ---- CU partitioning (optional; overlap of HBM-bound passes with MFMA-bound kernels).  mas_stream_create_cu_range returns a HIP
+ * stream whose kernels run only on CUs [first, first + count) (hipExtStreamCreateWithCUMask); mas_set_cu_budget(n) makes the
+ * split-K weight-gradient grids size themselves for n CUs instead of the whole chip (0 = all).  Streams are the caller's to
+ * destroy (mas_stream_destroy).                                                                                                 */
+int mas_set_cu_budget(int cus);
+int mas_stream_create_cu_range(int first, int count, void** stream_out);
+int mas_stream_destroy(void* stream);
+
 /* ---- vector quantiser  (replaces Codebook.forward's distance / argmin / gather / loss,
  * modules.py:501-509; never materialises d[M,K]).
  *   z [M][D] fp32 (NHWC latent rows), codebook [K][D] fp32.

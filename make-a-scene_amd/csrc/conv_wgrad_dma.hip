@@ -499,7 +499,7 @@ int mas_conv_wgrad_dma_try(const MasConvDesc* d, const void* x, const float* sca
     // it for N > 1) halves the work-groups so the hardware rebalances at half-round granularity, for 2x the split-K atomics
     // (+3 % of this kernel on an idle GPU).
     static const int oversub = mas_env_int("MAS_WGRAD_OVERSUB", 1);
-    int nsplit = mas_cdiv(mas_num_cus() * (oversub > 0 ? oversub : 1), out_tiles);
+    int nsplit = mas_cdiv(mas_cu_budget() * (oversub > 0 ? oversub : 1), out_tiles);     // (mas_set_cu_budget: a masked stream's share of the chip)
     if (nsplit > p.n_pt) nsplit = p.n_pt;
     if (nsplit < 1) nsplit = 1;
     p.nsplit = nsplit;

@@ -483,6 +483,50 @@ def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ac
 _WGRAD_SCRATCH = os.environ.get("MAS_WGRAD_SCRATCH", "1") == "1"
 _wgrad_scratch = {}
 
+# --------------------------------------------------------------------------- #
+# overlap of the HBM-bound GroupNorm backward with the MFMA-bound weight gradient (ResnetBlock backward)
+# --------------------------------------------------------------------------- #
+# The backward of a ResnetBlock is a chain  dgrad -> GroupNorm backward -> dgrad -> GroupNorm backward  with two weight gradients
+# hanging off it.  A weight gradient owns every CU it runs on (138 KB of LDS, all VGPRs) and leaves HBM mostly idle; a GroupNorm
+# backward streams 2.7 GB and leaves the matrix cores idle.  With MAS_OVERLAP=1 each weight gradient is launched on a CU-masked
+# stream covering 256 - G compute units and the GroupNorm backward that follows the same layer's data gradient on a second masked
+# stream covering the other G (MAS_OVERLAP_GN_CUS, default 112): the pair runs side by side and is joined back into the caller's
+# stream before the node returns.  tools/probes/overlap_probe.py measures the pair in isolation (profiles/r03_overlap_probe.txt).
+_OVERLAP = os.environ.get("MAS_OVERLAP", "0") == "1"
+_overlap_state = {}
+
+
+def _overlap_streams(device):
+    st = _overlap_state.get(device.index)
+    if st is None:
+        import ctypes
+        from . import lib as _lib
+        gcus = int(os.environ.get("MAS_OVERLAP_GN_CUS", "112"))
+        ncu = torch.cuda.get_device_properties(device).multi_processor_count
+        if not 0 < gcus < ncu:
+            raise RuntimeError(f"MAS_OVERLAP_GN_CUS={gcus}: need 0 < G < {ncu}")
+
+        def mk(first, count):
+            p = ctypes.c_void_p()
+            check(_lib().mas_stream_create_cu_range(first, count, ctypes.byref(p)), "stream_create_cu_range")
+            return torch.cuda.ExternalStream(p.value, device=device)
+
+        st = _overlap_state[device.index] = (mk(0, gcus), mk(gcus, ncu - gcus), ncu - gcus)
+    return st
+
+
+class _cu_budget:
+    """weight gradients launched inside size their split-K grids for `cus` compute units (their masked stream's share)"""
+
+    def __init__(self, cus):
+        self.cus = cus
+
+    def __enter__(self):
+        check(lib().mas_set_cu_budget(self.cus), "set_cu_budget")
+
+    def __exit__(self, *exc):
+        check(lib().mas_set_cu_budget(0), "set_cu_budget")
+
 
 def upsample2x(x):
     n, c, h, w = x.shape
@@ -667,21 +711,55 @@ class _ResBlock(torch.autograd.Function):
         dy = nhwc(dy, cd)
         ng = ctx.needs_input_grad
         geo = (n, h, w, c, h, w, c, 3, 1, 1, 1)
-        # conv2 / norm2
         dw2 = db2 = dw1 = db1 = None
-        if ng[7] or ng[8]:       # (a2 / a1: the activated inputs the forward convolutions left behind -> prologue-free weight gradients)
-            dw2, db2 = conv_wgrad_raw(a2, None, dy, *geo, ACT_NONE, False, True) if a2 is not None else \
-                conv_wgrad_raw(hh, ss2, dy, *geo, ACT_AFFINE_SILU, False, True)
-        da2 = conv_fwd_raw(dy, None, ConvWeight(c2w, True), None, None, *geo, ACT_NONE, False, cd)
-        dh, dg2w, dg2b = gn_bwd(hh, da2, None, groups, ACT_AFFINE_SILU, n2w.detach().float(), mr2, ss2)
-        # conv1 / norm1 (+ the skip connection's gradient, fused into the GroupNorm-backward apply pass)
-        if ng[3] or ng[4]:
-            dw1, db1 = conv_wgrad_raw(a1, None, dh, *geo, ACT_NONE, False, True) if a1 is not None else \
-                conv_wgrad_raw(x, ss1, dh, *geo, ACT_AFFINE_SILU, False, True)
         dx = dg1w = dg1b = None
-        if ng[0] or ng[1] or ng[2]:
+
+        def wgrad2():
+            return conv_wgrad_raw(a2, None, dy, *geo, ACT_NONE, False, True) if a2 is not None else \
+                conv_wgrad_raw(hh, ss2, dy, *geo, ACT_AFFINE_SILU, False, True)
+
+        def wgrad1(dh_):
+            return conv_wgrad_raw(a1, None, dh_, *geo, ACT_NONE, False, True) if a1 is not None else \
+                conv_wgrad_raw(x, ss1, dh_, *geo, ACT_AFFINE_SILU, False, True)
+
+        need_x = ng[0] or ng[1] or ng[2]
+        if _OVERLAP and (ng[7] or ng[8]) and (ng[3] or ng[4]) and need_x:
+            # (see _OVERLAP above) main: dgrad2 | sg: GN2 backward  ||  sw: wgrad2 | main: dgrad1 | sg: GN1 backward  ||  sw: wgrad1 | join
+            main = torch.cuda.current_stream()
+            sg, sw, wcus = _overlap_streams(x.device)
+            da2 = conv_fwd_raw(dy, None, ConvWeight(c2w, True), None, None, *geo, ACT_NONE, False, cd)
+            e1 = torch.cuda.Event(); e1.record(main)
+            sg.wait_event(e1); sw.wait_event(e1)
+            with torch.cuda.stream(sg):
+                dh, dg2w, dg2b = gn_bwd(hh, da2, None, groups, ACT_AFFINE_SILU, n2w.detach().float(), mr2, ss2)
+                e2 = torch.cuda.Event(); e2.record(sg)
+            with torch.cuda.stream(sw), _cu_budget(wcus):
+                dw2, db2 = wgrad2()
+            main.wait_event(e2)
             da1 = conv_fwd_raw(dh, None, ConvWeight(c1w, True), None, None, *geo, ACT_NONE, False, cd)
-            dx, dg1w, dg1b = gn_bwd(x, da1, dy, groups, ACT_AFFINE_SILU, n1w.detach().float(), mr1, ss1)
+            e3 = torch.cuda.Event(); e3.record(main)
+            sg.wait_event(e3); sw.wait_event(e3)
+            with torch.cuda.stream(sg):
+                dx, dg1w, dg1b = gn_bwd(x, da1, dy, groups, ACT_AFFINE_SILU, n1w.detach().float(), mr1, ss1)
+                e4 = torch.cuda.Event(); e4.record(sg)
+            with torch.cuda.stream(sw), _cu_budget(wcus):
+                dw1, db1 = wgrad1(dh)
+                e5 = torch.cuda.Event(); e5.record(sw)
+            main.wait_event(e4); main.wait_event(e5)                # everything joined: the caller's stream owns all results again
+            for t in (dx, dg1w, dg1b, dg2w, dg2b, dw1, db1, dw2, db2):
+                t.record_stream(main)                                # (allocated on the side streams, consumed on the caller's)
+        else:
+            # conv2 / norm2
+            if ng[7] or ng[8]:       # (a2 / a1: the activated inputs the forward left behind -> prologue-free weight gradients)
+                dw2, db2 = wgrad2()
+            da2 = conv_fwd_raw(dy, None, ConvWeight(c2w, True), None, None, *geo, ACT_NONE, False, cd)
+            dh, dg2w, dg2b = gn_bwd(hh, da2, None, groups, ACT_AFFINE_SILU, n2w.detach().float(), mr2, ss2)
+            # conv1 / norm1 (+ the skip connection's gradient, fused into the GroupNorm-backward apply pass)
+            if ng[3] or ng[4]:
+                dw1, db1 = wgrad1(dh)
+            if need_x:
+                da1 = conv_fwd_raw(dh, None, ConvWeight(c1w, True), None, None, *geo, ACT_NONE, False, cd)
+                dx, dg1w, dg1b = gn_bwd(x, da1, dy, groups, ACT_AFFINE_SILU, n1w.detach().float(), mr1, ss1)
         cast = lambda g, ref: g.to(ref.dtype) if g is not None else None
         return (dx, cast(dg1w, n1w), cast(dg1b, n1w), cast(dw1, c1w), cast(db1, c1w), cast(dg2w, n2w), cast(dg2b, n2w),
                 cast(dw2, c2w), cast(db2, c2w), None, None, None, None, None, None)
