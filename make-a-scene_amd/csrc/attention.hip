@@ -15,6 +15,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -352,6 +353,205 @@ __global__ __launch_bounds__(NT, 2) void attn_causal_fwd_bf16_kernel(AttnParams 
             }
         if (p.lse && g == 0) p.lse[((size_t)b * p.H + h) * p.S + query] = m * 0.6931471805599453f + __logf(l);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// v2 of the head_dim-64 bf16 forward (round 3).  Same arithmetic, same products, same fragment layouts as the kernel above; what
+// changes is how many waves a SIMD holds.  v1: 132 VGPRs (16 of them the next tile's K / V rows in flight) and 43 KB of LDS per
+// work-group (row padding) = 3 waves per SIMD, and the SIMDs idle 40 % of the cycles (MFMA busy 24 %, other VALU ~36 %: nothing to
+// switch to while a wave waits for its score MFMAs, its LDS reads or the barrier).  v2:
+//   * K / V tiles go global -> LDS by DMA (`buffer_load_dwordx4 ... lds`, inline assembly as in conv_wgrad_dma.hip so that the
+//     compiler does not put a vmcnt(0) in front of the next LDS read): no staging registers, no ds_write;
+//   * unpadded 128-byte rows, XOR swizzles instead of padding (K: 16-byte slot ^ ((key >> 1) & 7), the ds_read_b128 pattern of the
+//     conv kernels; V: 64-byte block ^ ((key >> 1) & 1), the transpose-read pattern of conv_wgrad_dma.hip): 32 KB per work-group;
+//   * __launch_bounds__(256, 4): <= 128 VGPRs, 4 work-groups per CU.
+// The key loop is unrolled by two so that the stage offset is an immediate of every LDS read.
+typedef __attribute__((ext_vector_type(4))) int fa_i32x4;
+__device__ __forceinline__ void fa_dma16(fa_i32x4 rs, unsigned lds, int vo) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(vo), "s"(rs) : "memory", "m0");
+}
+__device__ __forceinline__ fa_i32x4 fa_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    fa_i32x4 r = {(int)(unsigned)a, (int)(unsigned)(a >> 32), (int)bytes, 0x00020000};
+    r[0] = __builtin_amdgcn_readfirstlane(r[0]); r[1] = __builtin_amdgcn_readfirstlane(r[1]);
+    r[2] = __builtin_amdgcn_readfirstlane(r[2]); r[3] = __builtin_amdgcn_readfirstlane(r[3]);
+    return r;
+}
+constexpr int F2_TILE = 64 * 128;                 // one 64-key x 64-dim bf16 tile
+constexpr int F2_STAGE = 2 * F2_TILE;             // K then V
+constexpr int F2_LDS = 2 * F2_STAGE;              // 32 KB
+constexpr int F2_OOB = (int)0x80000000;
+
+__global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnParams p) {
+    using T = bf16_t;
+    constexpr int HD = 64, KT2 = 64, NKK = 4, NMI = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)fa_smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31, G16 = (lane >> 4) & 1, sl = lane & 15;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * QT;     // heavy blocks first
+    const int qw = q0 + wave * 32, query = qw + l31;
+
+    const T* __restrict__ Q = reinterpret_cast<const T*>(p.q) + (size_t)b * p.q_bs + (size_t)h * HD;
+    const T* __restrict__ K = reinterpret_cast<const T*>(p.k) + (size_t)b * p.k_bs + (size_t)h * HD;
+    const T* __restrict__ V = reinterpret_cast<const T*>(p.v) + (size_t)b * p.v_bs + (size_t)h * HD;
+    // one descriptor per tensor over this (batch, head)'s rows: a key >= S lands past the end and reads as zeros
+    const fa_i32x4 rs_k = fa_rsrc(K, (unsigned)((size_t)(p.S - 1) * p.ld_k * 2 + HD * 2));
+    const fa_i32x4 rs_v = fa_rsrc(V, (unsigned)((size_t)(p.S - 1) * p.ld_v * 2 + HD * 2));
+
+    bf16x8 qf[NKK];                                  // Q^T fragments (B operand): lane = query, 8 consecutive head dims
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        u32x4 raw = u32x4{0u, 0u, 0u, 0u};
+        if (query < p.S) raw = *reinterpret_cast<const u32x4*>(Q + (size_t)query * p.ld_q + kk * 16 + g * 8);
+        qf[kk] = *reinterpret_cast<const bf16x8*>(&raw);
+    }
+    f32x16 oacc[NMI];
+#pragma unroll
+    for (int i = 0; i < NMI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.0f;
+    float m = -1e30f, l = 0.0f;                      // running max (log2 domain) and sum per query
+    const float c2 = p.scale * 1.4426950408889634f;
+
+    // ---- DMA plan: a tile is 8 pieces of 8 keys x 128 B per tensor; wave w moves pieces w and w + 4 of K and of V.  The LDS image
+    //      of a piece is lane-linear (key 8 piece + (lane >> 3), physical slot lane & 7): the swizzle goes on the SOURCE slot
+    int vk[2], vv[2];                                // lane parts of the source offsets (relative to the tile's first key)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int key_l = (wave + 4 * j) * 8 + (lane >> 3), ps = lane & 7;
+        vk[j] = key_l * p.ld_k * 2 + ((ps ^ ((key_l >> 1) & 7)) << 4);
+        vv[j] = key_l * p.ld_v * 2 + (((((ps >> 2) ^ ((key_l >> 1) & 1)) << 2) | (ps & 3)) << 4);
+    }
+    auto issue = [&](int k0, int stage) {
+        const int uk = k0 * p.ld_k * 2, uv = k0 * p.ld_v * 2;           // uniform
+        const bool full = k0 + KT2 <= p.S;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int key = k0 + (wave + 4 * j) * 8 + (lane >> 3);
+            const bool ok = full || key < p.S;
+            const unsigned dst = lds0 + stage * F2_STAGE + (wave + 4 * j) * 1024;
+            fa_dma16(rs_k, __builtin_amdgcn_readfirstlane(dst), ok ? vk[j] + uk : F2_OOB);
+            fa_dma16(rs_v, __builtin_amdgcn_readfirstlane(dst + F2_TILE), ok ? vv[j] + uv : F2_OOB);
+        }
+    };
+    // ---- fragment addresses (lane parts; the stage, sub-tile and k-step offsets are immediates)
+    const int key7 = (l31 >> 1) & 7;
+    int ka[NKK];                                     // K: row l31, logical slot 2 kk + g -> physical slot ^ key7
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) ka[kk] = l31 * 128 + (((2 * kk + g) ^ key7) << 4);
+    int va[NMI];                                     // V^T: key row 4 g + (sl >> 2), dims 32 i + 16 G16 + 4 (sl & 3): block i ^ ((sl >> 3) & 1)
+#pragma unroll
+    for (int i = 0; i < NMI; ++i) va[i] = (4 * g + (sl >> 2)) * 128 + ((i ^ ((sl >> 3) & 1)) << 6) + 32 * G16 + 8 * (sl & 3);
+
+    const int q_last = min(q0 + QT, p.S) - 1;        // keys beyond the work-group's last query are never needed
+    const int n_tiles = q_last / KT2 + 1;
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto tile = [&](int it, auto stage_c) {
+        constexpr int ST = decltype(stage_c)::value;
+        const int k0 = it * KT2;
+        const bool more = it + 1 < n_tiles;
+        if (more) issue(k0 + KT2, ST ^ 1);
+        if (k0 <= qw + 31) {                         // wave-uniform: otherwise the tile is entirely above this wave's diagonal
+            const unsigned char* kt = fa_smem + ST * F2_STAGE;
+            const unsigned char* vt = kt + F2_TILE;
+            f32x16 s[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[sub][r] = 0.0f;
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + ka[kk] + sub * 4096);
+                    mma16(s[sub], kf, qf[kk]);
+                }
+            }
+            if ((k0 + KT2 - 1 > qw) || (k0 + KT2 > p.S)) {          // tile touches the diagonal or the sequence end: mask
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = k0 + sub * 32 + acc_row(lane, r);
+                        if (!(key <= query && key < p.S)) s[sub][r] = -1e30f;
+                    }
+            }
+            float tmax = -1e30f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[sub][r]);
+            tmax = fmaxf(tmax, fa_other_half(tmax)) * c2;
+            const float m_new = fmaxf(m, tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            fa_f32x2 rs2 = fa_f32x2{0.0f, 0.0f};
+            const fa_f32x2 c22 = fa_f32x2{c2, c2}, nm2 = fa_f32x2{-m_new, -m_new};
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    fa_f32x2 t2 = fa_f32x2{s[sub][r], s[sub][r + 1]} * c22 + nm2;
+                    t2[0] = __builtin_amdgcn_exp2f(t2[0]);
+                    t2[1] = __builtin_amdgcn_exp2f(t2[1]);
+                    s[sub][r] = t2[0]; s[sub][r + 1] = t2[1];
+                    rs2 += t2;
+                }
+            float rsum = rs2[0] + rs2[1];
+            rsum += fa_other_half(rsum);
+            l = l * alpha + rsum;
+            m = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+                for (int i = 0; i < NMI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (T)s[sub][8 * t + j];
+#pragma unroll
+                    for (int i = 0; i < NMI; ++i) {
+                        const unsigned char* a0 = vt + va[i] + (sub * 32 + 16 * t) * 128;
+                        mma16(oacc[i], fa_tr_frag(a0, a0 + 8 * 128), pf);
+                    }
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of the next tile have landed
+        __syncthreads();
+    };
+    for (int it = 0; it < n_tiles; it += 2) {
+        tile(it, std::integral_constant<int, 0>{});
+        if (it + 1 < n_tiles) tile(it + 1, std::integral_constant<int, 1>{});
+    }
+
+    if (query < p.S) {                               // lane = query, accumulator rows = head dims (4 consecutive per register quad)
+        const float inv = 1.0f / l;
+        T* dst = reinterpret_cast<T*>(p.o) + ((size_t)b * p.S + query) * ((size_t)p.H * HD) + (size_t)h * HD;
+#pragma unroll
+        for (int i = 0; i < NMI; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                bf16x4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = (T)(oacc[i][4 * rq + e] * inv);
+                *reinterpret_cast<bf16x4*>(dst + i * 32 + 8 * rq + 4 * g) = o4;
+            }
+        if (p.lse && g == 0) p.lse[((size_t)b * p.H + h) * p.S + query] = m * 0.6931471805599453f + __logf(l);
+    }
+}
+
+int launch_fwd_fast_v2(const AttnParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(attn_causal_fwd_bf16_v2_kernel, dim3(mas_cdiv(p.S, QT), p.B * p.H), dim3(NT), F2_LDS, s, p);
+    MAS_CHECK_LAUNCH("attn_causal_fwd_v2");
+    return MAS_OK;
 }
 
 template <int HD>
@@ -979,7 +1179,13 @@ extern "C" int mas_attn_causal_fwd(const void* q, const void* k, const void* v, 
     if (dtype == MAS_BF16) {
         const bool fast = (hd == 64 || hd == 128) && fa_aligned(q, q_bs, ld_q) && fa_aligned(k, k_bs, ld_k) && fa_aligned(v, v_bs, ld_v) &&
                           (reinterpret_cast<uintptr_t>(o) & 7) == 0 && !attn_generic();
-        if (fast) return hd == 64 ? launch_fwd_fast<64>(p, s) : launch_fwd_fast<128>(p, s);
+        if (fast) {
+            // v2 (DMA staging, swizzled unpadded LDS, 4 work-groups per CU) needs 31-bit byte offsets inside one (batch, head) slab
+            static const int v2 = mas_env_int("MAS_ATTN_FWD_V2", 1);
+            const bool small = (long long)S * ld_k * 2 < 0x7fffffffLL && (long long)S * ld_v * 2 < 0x7fffffffLL;
+            if (hd == 64 && v2 && small) return launch_fwd_fast_v2(p, s);
+            return hd == 64 ? launch_fwd_fast<64>(p, s) : launch_fwd_fast<128>(p, s);
+        }
         return launch_hd<bf16_t>(p, hd, s);
     }
     if (dtype == MAS_F32) return launch_hd<float>(p, hd, s);
