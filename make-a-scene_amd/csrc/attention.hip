@@ -863,11 +863,34 @@ __device__ __forceinline__ bf16x8 fa_tr_tile_frag(const unsigned char* tile, int
     return fa_tr_frag(tile + fa_phys(r0, slot) + within, tile + fa_phys(r0 + 8, slot) + within);
 }
 
-__global__ __launch_bounds__(NT, 2) void attn_bwd_dkv_bf16_kernel(AttnBwdParams p) {
+// LDS-DMA staging of a swizzled 64 x 64 tile (round 3, as in the v2 forward): 8 pieces of 8 rows; wave w moves pieces w and w + 4.
+// The LDS image of a piece is lane-linear (row 8 piece + (lane >> 3), physical slot lane & 7), so the swizzle goes on the SOURCE slot.
+__device__ __forceinline__ void fa_dma_plan(int wave, int lane, int ld, int (&vo)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row_l = (wave + 4 * j) * 8 + (lane >> 3);
+        vo[j] = row_l * ld * 2 + (((lane & 7) ^ fa_swz(row_l)) << 4);
+    }
+}
+__device__ __forceinline__ void fa_dma_tile(fa_i32x4 rs, unsigned lds_tile, int row0, int S, int ld, int wave, int lane, const int (&vo)[2]) {
+    const int u0 = row0 * ld * 2;
+    const bool full = row0 + 64 <= S;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const bool ok = full || (row0 + (wave + 4 * j) * 8 + (lane >> 3) < S);
+        fa_dma16(rs, __builtin_amdgcn_readfirstlane(lds_tile + (wave + 4 * j) * 1024), ok ? vo[j] + u0 : F2_OOB);
+    }
+}
+
+#ifndef FA_DKV_WGS
+#define FA_DKV_WGS 2
+#endif
+__global__ __launch_bounds__(NT, FA_DKV_WGS) void attn_bwd_dkv_bf16_kernel(AttnBwdParams p) {
     using T = bf16_t;
     constexpr int HD = 64, NKK = 4, NMI = 2, QT2 = 64;
     constexpr int STAGE = 2 * FaTile::BYTES + 2 * QT2 * (int)sizeof(float);
     extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)fa_smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, l31 = lane & 31, G16 = (lane >> 4) & 1, sl = lane & 15;
@@ -901,11 +924,16 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkv_bf16_kernel(AttnBwdParams 
         for (int r = 0; r < 16; ++r) { dk[i][r] = 0.0f; dv[i][r] = 0.0f; }
     const float c2 = p.scale * 1.4426950408889634f;
 
-    u32x4 rq[2], rg[2];
+    // Q / dO tiles: global -> LDS by DMA (round 3; no staging registers); the lse / delta rows of the tile ride through two registers
+    const fa_i32x4 rs_q = fa_rsrc(Q, (unsigned)((size_t)(p.S - 1) * p.ld * 2 + HD * 2));
+    const fa_i32x4 rs_g = fa_rsrc(G, (unsigned)((size_t)(p.S - 1) * g_stride * 2 + HD * 2));
+    int voq[2], vog[2];
+    fa_dma_plan(wave, lane, p.ld, voq);
+    fa_dma_plan(wave, lane, (int)g_stride, vog);
     float rl = 0.0f, rd = 0.0f;
-    auto issue = [&](int q0) {
-        fa_issue_tile(Q, p.ld, q0, p.S, tid, rq);
-        fa_issue_tile(G, g_stride, q0, p.S, tid, rg);
+    auto issue = [&](int q0, int stage) {
+        fa_dma_tile(rs_q, lds0 + stage * STAGE, q0, p.S, p.ld, wave, lane, voq);
+        fa_dma_tile(rs_g, lds0 + stage * STAGE + FaTile::BYTES, q0, p.S, (int)g_stride, wave, lane, vog);
         if (tid < QT2) {
             const bool ok = q0 + tid < p.S;
             rl = ok ? LSE[q0 + tid] * 1.4426950408889634f : 0.0f;
@@ -913,8 +941,6 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkv_bf16_kernel(AttnBwdParams 
         }
     };
     auto commit = [&](unsigned char* st) {
-        fa_commit_tile(st, tid, rq);
-        fa_commit_tile(st + FaTile::BYTES, tid, rg);
         if (tid < QT2) {
             reinterpret_cast<float*>(st + 2 * FaTile::BYTES)[tid] = rl;
             reinterpret_cast<float*>(st + 2 * FaTile::BYTES)[QT2 + tid] = rd;
@@ -923,14 +949,15 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkv_bf16_kernel(AttnBwdParams 
 
     const int q_start = (k0 / QT2) * QT2;           // causal: queries before the work-group's first key never see it
     const int n_tiles = (p.S - q_start + QT2 - 1) / QT2;
-    issue(q_start);
+    issue(q_start, 0);
     commit(fa_smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
     for (int it = 0; it < n_tiles; ++it) {
         const int q0 = q_start + it * QT2;
         const bool more = it + 1 < n_tiles;
-        if (more) issue(q0 + QT2);
+        if (more) issue(q0 + QT2, cur ^ 1);         // the other stage was last read before the barrier that ended the previous tile
         const unsigned char* qt = fa_smem + cur * STAGE;
         const unsigned char* gt = qt + FaTile::BYTES;
         const float* lse_s = reinterpret_cast<const float*>(qt + 2 * FaTile::BYTES);
@@ -983,6 +1010,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkv_bf16_kernel(AttnBwdParams 
             }
         }
         if (more) commit(fa_smem + (cur ^ 1) * STAGE);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of the next tile have landed
         __syncthreads();
         cur ^= 1;
     }
@@ -1002,11 +1030,12 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkv_bf16_kernel(AttnBwdParams 
     }
 }
 
-__global__ __launch_bounds__(NT, 2) void attn_bwd_dq_bf16_kernel(AttnBwdParams p) {
+__global__ __launch_bounds__(NT, 3) void attn_bwd_dq_bf16_kernel(AttnBwdParams p) {       // (round 3: DMA staging -> <= 168 VGPRs, 3 waves per SIMD)
     using T = bf16_t;
     constexpr int HD = 64, NKK = 4, NMI = 2, KT2 = 64;
     constexpr int STAGE = 2 * FaTile::BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)fa_smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, l31 = lane & 31, G16 = (lane >> 4) & 1, sl = lane & 15;
@@ -1040,21 +1069,24 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_bf16_kernel(AttnBwdParams p
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.0f;
 
-    u32x4 rk[2], rv[2];
+    // K / V tiles: global -> LDS by DMA (no staging registers); a row >= S reads as zeros through the descriptor's bounds check
+    const fa_i32x4 rs_k = fa_rsrc(K, (unsigned)((size_t)(p.S - 1) * p.ld * 2 + HD * 2));
+    const fa_i32x4 rs_v = fa_rsrc(V, (unsigned)((size_t)(p.S - 1) * p.ld * 2 + HD * 2));
+    int vo[2];
+    fa_dma_plan(wave, lane, p.ld, vo);
     const int q_last = min(q0 + QT, p.S) - 1;
     const int n_tiles = q_last / KT2 + 1;
-    fa_issue_tile(K, p.ld, 0, p.S, tid, rk);
-    fa_issue_tile(V, p.ld, 0, p.S, tid, rv);
-    fa_commit_tile(fa_smem, tid, rk);
-    fa_commit_tile(fa_smem + FaTile::BYTES, tid, rv);
+    fa_dma_tile(rs_k, lds0, 0, p.S, p.ld, wave, lane, vo);
+    fa_dma_tile(rs_v, lds0 + FaTile::BYTES, 0, p.S, p.ld, wave, lane, vo);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
     for (int it = 0; it < n_tiles; ++it) {
         const int k0 = it * KT2;
         const bool more = it + 1 < n_tiles;
-        if (more) {
-            fa_issue_tile(K, p.ld, k0 + KT2, p.S, tid, rk);
-            fa_issue_tile(V, p.ld, k0 + KT2, p.S, tid, rv);
+        if (more) {                                 // the other stage was last read before the barrier that ended the previous tile
+            fa_dma_tile(rs_k, lds0 + (cur ^ 1) * STAGE, k0 + KT2, p.S, p.ld, wave, lane, vo);
+            fa_dma_tile(rs_v, lds0 + (cur ^ 1) * STAGE + FaTile::BYTES, k0 + KT2, p.S, p.ld, wave, lane, vo);
         }
         const unsigned char* kt = fa_smem + cur * STAGE;
         const unsigned char* vt = kt + FaTile::BYTES;
@@ -1095,10 +1127,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_bf16_kernel(AttnBwdParams p
                 for (int i = 0; i < NMI; ++i) mma16(dq[i], fa_tr_tile_frag(kt, sub * 32 + 16 * t, i, g, G16, sl), sf);   // dQ^T += K^T dS^T
             }
         }
-        if (more) {
-            fa_commit_tile(fa_smem + (cur ^ 1) * STAGE, tid, rk);
-            fa_commit_tile(fa_smem + (cur ^ 1) * STAGE + FaTile::BYTES, tid, rv);
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of the next tile have landed
         __syncthreads();
         cur ^= 1;
     }
