@@ -162,3 +162,33 @@ def test_bench_py_multi_rank_branch_end_to_end():
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 4 and j["scaling"] == "weak" and j["value"] > 0
     assert j["replica_weight_checksum_spread"] == 0.0                  # both replicas applied the same averaged gradients
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]   # only rank 0 prints
+
+
+def test_bench_py_multi_rank_gradient_accumulation_no_sync():
+    """the accumulation branch of the N > 1 path -- GradReducer.no_sync() on all but the last micro-batch, as the
+    reference accumulates (conf/img_config.yaml:13) -- end to end through `bench.py --workload e2e` (frozen VQ encode -> transformer,
+    micro-batches of 1 accumulated twice per step), two gloo ranks on the one GPU.  Both replicas must end with identical weights
+    (checksum spread 0): a reduction fired per micro-batch, or skipped on the last one, would break that or the averaging."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MAS_BENCH_SHARE_GPU="1", MAS_BENCH_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--workload", "e2e", "--gpus", "2", "--steps", "1",
+                                       "--warmup", "1", "--batch", "2", "--micro-batch", "1"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][1][-1500:] + outs[1][1][-1500:]
+    j = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 4 and j["value"] > 0
+    assert "accumulation" in j["config"]["workload"]
+    assert j["replica_weight_checksum_spread"] == 0.0
