@@ -311,6 +311,26 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
         // swizzled offset; a read is then `base register + compile-time offset` (row * 2304, +512 for the second half) -- round 2
         // formed every address with two VALU adds (120 per tile).  The bases move to the next buffer of the ring once per tile.
         auto load_b = [&](int pr) {                               // -> bf[PREFETCH ? pr & 1 : 0], from the buffer bxo points at
+#ifndef D_NO_KW_REUSE
+            if constexpr (SPLIT == 1) {
+                // The three kw fragments of a patch row are windows of the SAME 10 pixels (8 g + kw .. 8 g + kw + 7): three transpose reads
+                // (pixels +0..3, +4..7, +8..11 of the lane's channel; a dword = two pixels) instead of six -- kw = 2 is the window shifted
+                // by one dword (free), kw = 1 by half a dword (four v_alignbit).  (SPLIT 1: a step needs all three kw or none.)
+                if (!kw_needed(pr, 0)) return;
+                const unsigned char* b0 = smem + bxo[0][pr & 1] + pr * (D_PW * 128);
+                const d_s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) d_s16x4*)b0);
+                const d_s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) d_s16x4*)(b0 + 4 * 128));
+                const d_s16x4 r2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) d_s16x4*)(b0 + 8 * 128));
+                const u32x2 a = *reinterpret_cast<const u32x2*>(&r0), b = *reinterpret_cast<const u32x2*>(&r1), c = *reinterpret_cast<const u32x2*>(&r2);
+                const u32x4 f0 = {a[0], a[1], b[0], b[1]}, f2 = {a[1], b[0], b[1], c[0]};
+                const u32x4 f1 = {__builtin_amdgcn_alignbit(a[1], a[0], 16), __builtin_amdgcn_alignbit(b[0], a[1], 16),
+                                  __builtin_amdgcn_alignbit(b[1], b[0], 16), __builtin_amdgcn_alignbit(c[0], b[1], 16)};
+                bf[PREFETCH ? (pr & 1) : 0][0] = *reinterpret_cast<const bf16x8*>(&f0);
+                bf[PREFETCH ? (pr & 1) : 0][1] = *reinterpret_cast<const bf16x8*>(&f1);
+                bf[PREFETCH ? (pr & 1) : 0][2] = *reinterpret_cast<const bf16x8*>(&f2);
+                return;
+            }
+#endif
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 if (!kw_needed(pr, kw)) continue;
