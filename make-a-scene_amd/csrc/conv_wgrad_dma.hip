@@ -311,11 +311,13 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
         // swizzled offset; a read is then `base register + compile-time offset` (row * 2304, +512 for the second half) -- round 2
         // formed every address with two VALU adds (120 per tile).  The bases move to the next buffer of the ring once per tile.
         auto load_b = [&](int pr) {                               // -> bf[PREFETCH ? pr & 1 : 0], from the buffer bxo points at
-#ifndef D_NO_KW_REUSE
+#ifdef D_KW_REUSE      // experiment builds only -- measured SLOWER (0.594 vs 0.584 ms at 128->128 @256^2; step 63.52 vs 63.28 ms, one box):
             if constexpr (SPLIT == 1) {
                 // The three kw fragments of a patch row are windows of the SAME 10 pixels (8 g + kw .. 8 g + kw + 7): three transpose reads
                 // (pixels +0..3, +4..7, +8..11 of the lane's channel; a dword = two pixels) instead of six -- kw = 2 is the window shifted
-                // by one dword (free), kw = 1 by half a dword (four v_alignbit).  (SPLIT 1: a step needs all three kw or none.)
+                // by one dword, kw = 1 by half a dword (four v_alignbit).  80 -> 50 LDS reads per tile, but +70 VALU: the odd-register
+                // window of kw = 2 is not a legal MFMA operand (tuples are even-aligned), so it is copied, and an issued VALU instruction
+                // costs this kernel as much as an issued LDS read (R2.2's cost model).  (SPLIT 1: a step needs all three kw or none.)
                 if (!kw_needed(pr, 0)) return;
                 const unsigned char* b0 = smem + bxo[0][pr & 1] + pr * (D_PW * 128);
                 const d_s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) d_s16x4*)b0);
