@@ -18,8 +18,9 @@ fwd + bwd of the cross-entropy on the image tokens (train.py:150-152) + Adam, bf
 
 Rank 0 prints ONE JSON line; besides the driver's contract it carries
   "roofline":     the dominant kernel timed live with HIP events on the launch stream inside the timed steps, against the bf16
-                  MFMA peak (vq: the 3x3 128->128 conv at 256^2, fwd + dgrad launches, the two loader populations separately
-                  and launch-weighted; transformer / e2e: the causal-attention forward kernel);
+                  MFMA peak (vq: the 3x3 128->128 conv at 256^2, fwd + dgrad launches, per loader population and launch-weighted
+                  -- in training every launch is prologue-free since round 3; transformer / e2e: the causal-attention forward
+                  kernel); "mfma_only_floor_ms": the same kernel with everything but MFMAs and LDS reads compiled out (committed);
   "cpu_baseline": the CPU oracle (oracle/vq_oracle.py, a port of the reference's arithmetic -- /root/reference does not exist
                   on the GPU box) timed on this host's cores on a bounded sample (rank 0, N=1, vq workload only);
   "also":         (vq workload, N=1) compact results of short `--workload transformer` and `--workload e2e` runs (BASELINE configs
@@ -378,7 +379,9 @@ def run_vq(args):
             avg_ms = tot_ms / n_ev                           # launch-weighted over both populations
             ach = flops / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {"kernel": "3x3 stride-1 128->128 conv @256x256: conv3x3_wide_kernel (fwd + dgrad launches of the step; "
-                                         "'plain' = data gradients and prologue-free forwards, 'gn_silu' = forwards with the GroupNorm+SiLU loader)",
+                                         "'plain' = prologue-free launches -- since round 3 all of them in training: the GroupNorm+SiLU output is "
+                                         "written once by mas_gn_act, MAS_GN_MATERIALIZE=1 --, 'gn_silu' = forwards with the fused loader, "
+                                         "MAS_GN_MATERIALIZE=0; the forward launches also carry the next GroupNorm's statistics in their epilogue)",
                                "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": _pmc_traffic(),
                                "traffic_source": "committed rocprofv3 PMC pass on the same kernel and shape (profiles/pmc_dominant_kernel.json), not measured by this run",
@@ -410,7 +413,7 @@ def _also_workloads(budget_s=240):
     NOT part of `value`; the full lines come from running those workloads directly."""
     import subprocess
     res = {}
-    for wl, extra in (("transformer", ["--steps", "8", "--warmup", "4"]), ("e2e", ["--steps", "3", "--warmup", "2"])):
+    for wl, extra in (("transformer", ["--steps", "12", "--warmup", "6"]), ("e2e", ["--steps", "3", "--warmup", "2"])):
         t0 = time.perf_counter()
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--gpus", "1", "--no-cpu-baseline"] + extra,
