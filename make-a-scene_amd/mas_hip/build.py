@@ -10,6 +10,9 @@ CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libmas_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-file additions.  attention.hip: one fp32 VALU instruction per score in the softmax (no SLP packing into v_pk_*_f32: packed fp32
+# VALU beside MFMAs is slower on gfx950 -- measured -2 ... -5 % on the forward kernel, profiles/r03_attn_v2.txt)
+PER_FILE_FLAGS = {"attention.hip": ["-DFA_SCALAR_SOFTMAX", "-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -48,7 +51,7 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t):
             continue
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print("[mas_hip.build]", " ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
