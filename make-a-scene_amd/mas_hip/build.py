@@ -12,7 +12,9 @@ LIB = os.path.join(HERE, "libmas_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-file additions.  attention.hip: one fp32 VALU instruction per score in the softmax (no SLP packing into v_pk_*_f32: packed fp32
 # VALU beside MFMAs is slower on gfx950 -- measured -2 ... -5 % on the forward kernel, profiles/r03_attn_v2.txt)
-PER_FILE_FLAGS = {"attention.hip": ["-DFA_SCALAR_SOFTMAX", "-fno-slp-vectorize"]}
+# conv3x3_wide.hip: the same for the epilogue's bias / residual adds (-2 % on the launch, gpu_r3_17.sh; the stream kernel measured 5 % SLOWER
+# without packing and keeps it)
+PER_FILE_FLAGS = {"attention.hip": ["-DFA_SCALAR_SOFTMAX", "-fno-slp-vectorize"], "conv3x3_wide.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
