@@ -158,6 +158,15 @@ int mas_conv_wgrad(const MasConvDesc* d, const void* x, const float* scale_shift
  * dbias [Cout]; acc is zeroed again while it is read, so ONE scratch per stream serves every convolution of a step without fill
  * launches (the caller still owns it).                                                                                              */
 int mas_wgrad_commit(float* acc, float* dw_oihw, float* dbias, int Cout, int Cin, int ks, void* stream);
+/* Deterministic split-K (ABI v3): for the convolutions that carry the FLOPs (mas_conv_wgrad_splits(d) = nsplit > 0: bf16, 3x3, stride 1,
+ * Cin % 64 == 0, Cout % 128 == 0) mas_conv_wgrad_partial writes the nsplit partial sums -- part [nsplit][Cout][3][3][Cin] fp32,
+ * part_bias [nsplit][Cout] or NULL, every element exactly once, plain stores, no initialisation required -- and mas_wgrad_reduce adds
+ * the slabs in a fixed order into dw_oihw [Cout][Cin][ks][ks] / dbias [Cout]: no atomics, bitwise reproducible run to run.          */
+int mas_conv_wgrad_splits(const MasConvDesc* d);
+int mas_conv_wgrad_partial(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy,
+                           float* part, float* part_bias, void* stream);
+int mas_wgrad_reduce(const float* part, const float* part_bias, int nsplit, float* dw_oihw, float* dbias, int Cout, int Cin, int ks,
+                     void* stream);
 
 /* ---- CU partitioning (optional; overlap of HBM-bound passes with MFMA-bound kernels).  mas_stream_create_cu_range returns a HIP
  * stream whose kernels run only on CUs [first, first + count) (hipExtStreamCreateWithCUMask); mas_set_cu_budget(n) makes the

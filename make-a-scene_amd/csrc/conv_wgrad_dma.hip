@@ -26,6 +26,8 @@ namespace {
 
 struct DmaWgradParams {
     const unsigned char* x; const float* ss; const unsigned char* dy; float* dw; float* dbias;
+    float* part; float* part_bias;                 // split-K partials [nsplit][Cout][9][Cin] / [nsplit][Cout] (plain stores, fixed-order reduce
+                                                   // by mas_wgrad_reduce) instead of fp32 atomics into dw / dbias
     int N, H, W, Cin, Ho, Wo, Cout;
     int Hl, Wl, pad_top, pad_left, act, upsample;
     int tiles_h, tiles_w, n_pt, n_co_t, n_ci_t, nsplit;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
     float bsum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.0f;
-    const bool do_bias = (p.dbias != nullptr) && (ci_t == 0);
+    const bool do_bias = (p.dbias != nullptr || p.part_bias != nullptr) && (ci_t == 0);
 
     // ---- prologue: all of tile 0, the scale/shift rows of tiles 0 and 1 and the dY pieces of tile 1 that steady state issues in
     //      steps 8, 9 of the previous iteration; everything landed, tile 0 activated, barrier
@@ -453,27 +455,44 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
             return;
         }
 #endif
+        if (p.part) {
+            // this work-group's own slab of the partial table: plain coalesced stores (a half-wave writes 128 consecutive bytes).  The
+            // fp32 atomics they replace cost 45-60 us per launch on every shape but the largest (18.9 M read-modify-writes at the L2:
+            // profiles/r03_wgrad_commit.txt) and made the sums depend on arrival order
+            float* pw = p.part + (size_t)split * ((size_t)p.Cout * 9 * p.Cin);
 #pragma unroll
-        for (int t = LO; t < HI; ++t)
+            for (int t = LO; t < HI; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wco + acc_row(lane, r);
-                atomicAdd(p.dw + ((size_t)co * 9 + t) * p.Cin + ci, acc[t - LO][r]);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wco + acc_row(lane, r);
+                    pw[((size_t)co * 9 + t) * p.Cin + ci] = acc[t - LO][r];
+                }
+        } else {
+#pragma unroll
+            for (int t = LO; t < HI; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wco + acc_row(lane, r);
+                    atomicAdd(p.dw + ((size_t)co * 9 + t) * p.Cin + ci, acc[t - LO][r]);
+                }
+        }
     };
     if (SPLIT == 1 || half == 0) run(d_ic<0>{}); else run(d_ic<1>{});
 #ifdef D_ABL_NOATOM
     if (p.N != -12345) return;
 #endif
-    if (do_bias) {
+    if (do_bias) {                                 // thread (tid & 15) = channel unit, (tid >> 4) = pixel phase: fixed-order sum over the phases
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);
-        for (int k = tid; k < 128; k += NT) red[k] = 0.0f;
-        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);               // [NT / 16][128]
 #pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(&red[(tid & 15) * 8 + e], bsum[e]);
+        for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = bsum[e];
         __syncthreads();
-        for (int k = tid; k < 128; k += NT) atomicAdd(p.dbias + co0 + k, red[k]);
+        if (tid < 128) {
+            float t = 0.0f;
+            for (int k = 0; k < NT / 16; ++k) t += red[k * 128 + tid];
+            if (p.part_bias) p.part_bias[(size_t)split * p.Cout + co0 + tid] = t;
+            else atomicAdd(p.dbias + co0 + tid, t);
+        }
     }
 }
 
@@ -494,17 +513,13 @@ int launch_dma(DmaWgradParams p, hipStream_t s) {
 
 }  // namespace
 
-// Returns 1 if the shape qualifies and the launch was made, 0 if the caller should use the other kernels, < 0 on error.
-int mas_conv_wgrad_dma_try(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy, float* dw, float* dbias,
-                           hipStream_t s) {
+static bool dma_setup(const MasConvDesc* d, DmaWgradParams& p) {
     static const int mode = mas_env_int("MAS_WGRAD_DMA", 1);
-    if (!mode) return 0;
-    if (d->ks != 3 || d->stride != 1 || d->in_dtype != MAS_BF16) return 0;
-    if (d->Cin % 64 != 0 || d->Cout % 128 != 0 || d->act > MAS_ACT_AFFINE_SILU) return 0;
+    if (!mode) return false;
+    if (d->ks != 3 || d->stride != 1 || d->in_dtype != MAS_BF16) return false;
+    if (d->Cin % 64 != 0 || d->Cout % 128 != 0 || d->act > MAS_ACT_AFFINE_SILU) return false;
     const long long xb = (long long)d->N * d->H * d->W * d->Cin * 2, yb = (long long)d->N * d->Ho * d->Wo * d->Cout * 2;
-    if (xb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return 0;
-    DmaWgradParams p;
-    p.x = (const unsigned char*)x; p.ss = scale_shift; p.dy = (const unsigned char*)dy; p.dw = dw; p.dbias = dbias;
+    if (xb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return false;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
     p.Hl = d->upsample ? 2 * d->H : d->H; p.Wl = d->upsample ? 2 * d->W : d->W;
     p.pad_top = d->pad_top; p.pad_left = d->pad_left; p.act = d->act; p.upsample = d->upsample;
@@ -512,24 +527,60 @@ int mas_conv_wgrad_dma_try(const MasConvDesc* d, const void* x, const float* sca
     p.n_pt = p.N * p.tiles_h * p.tiles_w;
     p.n_co_t = d->Cout / 128; p.n_ci_t = d->Cin / 64;
     p.dbg = nullptr;
-#ifdef D_TIMELINE
-    if (const char* e = getenv("MAS_DBG_PTR")) p.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
-#endif
     const int out_tiles = p.n_co_t * p.n_ci_t;
     // One register-file-filling work-group per CU.  Under a co-running RCCL collective (data-parallel backward) some CUs are taken
     // and a grid of exactly one work-group per CU runs the displaced ones as a second FULL round; MAS_WGRAD_OVERSUB=2 (bench.py sets
-    // it for N > 1) halves the work-groups so the hardware rebalances at half-round granularity, for 2x the split-K atomics
-    // (+3 % of this kernel on an idle GPU).
+    // it for N > 1) halves the work-groups so the hardware rebalances at half-round granularity, for 2x the split-K partials.
     static const int oversub = mas_env_int("MAS_WGRAD_OVERSUB", 1);
     int nsplit = mas_cdiv(mas_cu_budget() * (oversub > 0 ? oversub : 1), out_tiles);     // (mas_set_cu_budget: a masked stream's share of the chip)
     if (nsplit > p.n_pt) nsplit = p.n_pt;
     if (nsplit < 1) nsplit = 1;
     p.nsplit = nsplit;
-    const bool act = d->act != MAS_ACT_NONE;
+    return true;
+}
+
+static int dma_launch(DmaWgradParams& p, hipStream_t s) {
+#ifdef D_TIMELINE
+    if (const char* e = getenv("MAS_DBG_PTR")) p.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
+#endif
+    const bool act = p.act != MAS_ACT_NONE;
 #ifdef D_SPLIT2         // experiment builds only: the 16-wave tap-split variant does not fit the 128-register cap (88 spilled registers)
     static const int wsplit = mas_env_int("MAS_WGRAD_SPLIT", 2);
-    if (wsplit == 2) { const int rc2 = act ? launch_dma<true, 2>(p, s) : launch_dma<false, 2>(p, s); return rc2 == MAS_OK ? 1 : rc2; }
+    if (wsplit == 2) return act ? launch_dma<true, 2>(p, s) : launch_dma<false, 2>(p, s);
 #endif
-    const int rc = act ? launch_dma<true, 1>(p, s) : launch_dma<false, 1>(p, s);
+    return act ? launch_dma<true, 1>(p, s) : launch_dma<false, 1>(p, s);
+}
+
+// Returns 1 if the shape qualifies and the launch was made, 0 if the caller should use the other kernels, < 0 on error.
+int mas_conv_wgrad_dma_try(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy, float* dw, float* dbias,
+                           hipStream_t s) {
+    DmaWgradParams p;
+    if (!dma_setup(d, p)) return 0;
+    p.x = (const unsigned char*)x; p.ss = scale_shift; p.dy = (const unsigned char*)dy; p.dw = dw; p.dbias = dbias;
+    p.part = nullptr; p.part_bias = nullptr;
+    const int rc = dma_launch(p, s);
     return rc == MAS_OK ? 1 : rc;
+}
+
+// Split-K factor of the LDS-DMA kernel for this convolution (= slabs of the partial table mas_conv_wgrad_partial writes), or 0 when the
+// shape does not take that kernel (mas_conv_wgrad with its atomic commit is the path then).
+extern "C" int mas_conv_wgrad_splits(const MasConvDesc* d) {
+    DmaWgradParams p;
+    if (!d || !dma_setup(d, p)) return 0;
+    return p.nsplit;
+}
+
+// The weight gradient as split-K PARTIALS: part [nsplit][Cout][3][3][Cin] fp32 and (when non-NULL) part_bias [nsplit][Cout], every
+// element written exactly once by plain stores (no zero-initialisation needed, no atomics); mas_wgrad_reduce sums the slabs in a
+// fixed order: bitwise run-to-run deterministic.  nsplit = mas_conv_wgrad_splits(d) (> 0 required).
+extern "C" int mas_conv_wgrad_partial(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy, float* part,
+                                      float* part_bias, void* stream) {
+    MAS_ENTER();
+    if (!d || !x || !dy || !part) MAS_FAIL(MAS_EINVAL, "conv_wgrad_partial: null argument");
+    if (d->act != MAS_ACT_NONE && !scale_shift) MAS_FAIL(MAS_EINVAL, "conv_wgrad_partial: act prologue needs scale_shift");
+    DmaWgradParams p;
+    if (!dma_setup(d, p)) MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad_partial: this convolution does not take the split-K partial path (mas_conv_wgrad_splits == 0)");
+    p.x = (const unsigned char*)x; p.ss = scale_shift; p.dy = (const unsigned char*)dy; p.dw = nullptr; p.dbias = nullptr;
+    p.part = part; p.part_bias = part_bias;
+    return dma_launch(p, reinterpret_cast<hipStream_t>(stream));
 }

@@ -345,6 +345,92 @@ extern "C" int mas_wgrad_commit(float* acc, float* dw_oihw, float* dbias, int Co
     return MAS_OK;
 }
 
+// ---- fixed-order reduction of split-K weight-gradient partials (mas_conv_wgrad_partial): part [nsplit][Cout][kk][Cin] -> dw OIHW,
+// part_bias [nsplit][Cout] -> db.  A block owns (one output channel) x (64 input channels) x (all taps): thread (el, g) sums slabs
+// g, g + 4, g + 8, ... of its input channel for each tap (coalesced 256-byte rows, every load independent), the four group sums are
+// added in order -- the same association every run, whatever the arrival order of the work-groups that wrote the slabs -- and the
+// 64 x kk results leave as ONE contiguous run of the OIHW tensor.  The last cdiv(Cout, 64) blocks do the bias the same way.
+// G = 16 (many slabs, few output channels: 128 -> 128 channels has 128 slabs and only 256 (o, 64 ci) blocks): 16 slab groups per block,
+// blockIdx.y picks the tap set {y, y + 4, y + 8, y + 12}.
+template <int G>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_bias, int nsplit,
+                                                           float* __restrict__ dw, float* __restrict__ db, int Cout, int Cin, int kk,
+                                                           int ci_chunks) {
+    __shared__ float red[G][64 / G][64];                            // [slab group][tap slot][ci]
+    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int nwb = Cout * ci_chunks;
+    if ((int)blockIdx.x >= nwb) {                                   // bias (blockIdx.y == 0 only)
+        if (blockIdx.y) return;
+        const int o = ((int)blockIdx.x - nwb) * 64 + el;
+        float acc = 0.0f;
+        if (o < Cout)
+            for (int sp = grp; sp < nsplit; sp += 4) acc += part_bias[(long long)sp * Cout + o];
+        red[grp][0][el] = acc;
+        __syncthreads();
+        if (grp == 0 && o < Cout) db[o] = ((red[0][0][el] + red[1][0][el]) + red[2][0][el]) + red[3][0][el];
+        return;
+    }
+    const int o = (int)blockIdx.x / ci_chunks, i0 = ((int)blockIdx.x % ci_chunks) * 64;
+    const long long slab = (long long)Cout * kk * Cin;
+    // 16 float4 lanes span the 64 input channels; the other 16 ways = G slab groups x 16 / G tap sets {ts, ts + 4, ts + 8, ts + 12}: up
+    // to 8 independent 16-byte loads in flight per thread (a scalar version left the latency exposed: 3.5 TB/s)
+    const int q = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int g = G == 4 ? (r & 3) : r, ts = G == 4 ? (r >> 2) : (int)blockIdx.y;
+    const int i = i0 + q * 4;
+    if (i < Cin) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const float* src = part + ((long long)o * kk + ts) * Cin + i;
+#pragma unroll 2
+        for (int sp = g; sp < nsplit; sp += G) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ts + 4 * k < kk) acc[k] += *reinterpret_cast<const f32x4*>(src + (long long)sp * slab + (long long)(4 * k) * Cin);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (ts + 4 * k < kk) *reinterpret_cast<f32x4*>(&red[g][G == 4 ? ts + 4 * k : k][q * 4]) = acc[k];
+    }
+    __syncthreads();
+    const int ni = Cin - i0 < 64 ? Cin - i0 : 64;
+    float* dst = dw + ((long long)o * Cin + i0) * kk;               // [i][t]
+    if (G == 4) {                                                   // all taps here: one contiguous run
+        for (int j = threadIdx.x; j < ni * kk; j += 256) {
+            const int il = j / kk, t = j - il * kk;
+            dst[j] = ((red[0][t][il] + red[1][t][il]) + red[2][t][il]) + red[3][t][il];
+        }
+    } else {
+        const int nk = (kk - ts + 3) / 4;                           // taps of this block's set
+        for (int j = threadIdx.x; j < ni * nk; j += 256) {
+            const int il = j / nk, k = j - il * nk;
+            float v = 0.0f;
+#pragma unroll
+            for (int gg = 0; gg < G; ++gg) v += red[gg][k][il];
+            dst[il * kk + ts + 4 * k] = v;
+        }
+    }
+}
+
+extern "C" int mas_wgrad_reduce(const float* part, const float* part_bias, int nsplit, float* dw_oihw, float* dbias, int Cout, int Cin,
+                                int ks, void* stream) {
+    MAS_ENTER();
+    if (!part || !dw_oihw || nsplit <= 0 || Cout <= 0 || Cin <= 0 || ks < 1 || ks > 4) MAS_FAIL(MAS_EINVAL, "wgrad_reduce: bad argument");
+    if (dbias && !part_bias) MAS_FAIL(MAS_EINVAL, "wgrad_reduce: dbias without part_bias");
+    if (Cin % 4 != 0 || (reinterpret_cast<uintptr_t>(part) & 15)) MAS_FAIL(MAS_EINVAL, "wgrad_reduce: Cin % 4 == 0 and a 16-byte aligned table required");
+    const int ci_chunks = (Cin + 63) / 64;
+    const long long blocks = (long long)Cout * ci_chunks + (dbias ? (Cout + 63) / 64 : 0);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (nsplit >= 32 && ks > 1)                                     // a function of the shape and the CU budget only: the association is fixed
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)blocks, ks * ks < 4 ? ks * ks : 4), dim3(256), 0, s, part, part_bias,
+                           nsplit, dw_oihw, dbias, Cout, Cin, ks * ks, ci_chunks);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, part, part_bias, nsplit, dw_oihw, dbias, Cout,
+                           Cin, ks * ks, ci_chunks);
+    MAS_CHECK_LAUNCH("wgrad_reduce");
+    return MAS_OK;
+}
+
 #define MAS_DISPATCH_NHWC(NAME, KERN, TOTAL, ...)                                                                   \
     do {                                                                                                            \
         const int epu_ = dtype == MAS_BF16 ? 8 : 4;                                                                 \

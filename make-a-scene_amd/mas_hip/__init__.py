@@ -57,6 +57,9 @@ _SIGNATURES = {
     "mas_gn_stats_from_partials": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
     "mas_conv_wgrad": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
     "mas_wgrad_commit": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "mas_conv_wgrad_splits": (_i, [C.POINTER(ConvDesc)]),
+    "mas_conv_wgrad_partial": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
+    "mas_wgrad_reduce": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _p]),
     "mas_set_cu_budget": (_i, [_i]),
     "mas_stream_create_cu_range": (_i, [_i, _i, C.POINTER(C.c_void_p)]),
     "mas_stream_destroy": (_i, [_p]),

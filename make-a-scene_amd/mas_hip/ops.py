@@ -454,10 +454,33 @@ def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ac
         if ks == 1:                                 # [cout,1,1,cin] == OIHW memory; a permute would keep odd size-1 strides (DDP warns)
             return dw.view(cout, cin, 1, 1), db
         return dw.permute(0, 3, 1, 2).contiguous(), db
-    # The split-K kernels ADD into a zero accumulator.  One persistent scratch per (device, stream), zeroed once, is handed to every
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    ns = lib().mas_conv_wgrad_splits(C.byref(d)) if _WGRAD_PARTIALS else 0
+    if ns > 0:
+        # The convolutions that carry the FLOPs: every split-K work-group stores its partial sums into its own slab of a persistent
+        # workspace (written in full by each launch: never zeroed) and ``mas_wgrad_reduce`` adds the slabs in a fixed order straight
+        # into the OIHW gradient.  No fp32 atomics (they cost 45-60 us per launch and made the sums order-dependent): the weight
+        # gradient of these layers is bitwise reproducible run to run.
+        need = ns * (nw + cout)
+        ws = _wgrad_partials.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _wgrad_partials[key] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=x.device)
+        dwo = torch.empty((cout, cin, ks, ks), dtype=torch.float32, device=x.device)
+        db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
+        pb = C.c_void_p(ws.data_ptr() + 4 * ns * nw) if want_bias else None
+
+        def launch():
+            check(lib().mas_conv_wgrad_partial(C.byref(d), _ptr(x), _ptr(ss), _ptr(dy), _ptr(ws), pb, _stream()), "conv_wgrad_partial")
+
+        if _launch_hook is not None:
+            _launch_hook("conv_wgrad", (n, h, w, cin, ho, wo, cout, ks, stride, act, 0), launch)
+        else:
+            launch()
+        check(lib().mas_wgrad_reduce(_ptr(ws), pb, ns, _ptr(dwo), _ptr(db), cout, cin, ks, _stream()), "wgrad_reduce")
+        return dwo, db
+    # The other split-K kernels ADD into a zero accumulator.  One persistent scratch per (device, stream), zeroed once, is handed to every
     # weight-gradient launch; ``mas_wgrad_commit`` moves the sums into a fresh OIHW gradient tensor (+ bias gradient) and zeroes the
     # scratch again while it reads it: no fill launch and no permute copy per convolution (round 2: 356 fills per VQ-IMG step).
-    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
     acc = _wgrad_scratch.get(key)
     if acc is None or acc.numel() < nw + cout:
         acc = _wgrad_scratch[key] = torch.zeros(max(nw + cout, 1 << 22), dtype=torch.float32, device=x.device)
@@ -482,6 +505,8 @@ def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ac
 
 _WGRAD_SCRATCH = os.environ.get("MAS_WGRAD_SCRATCH", "1") == "1"
 _wgrad_scratch = {}
+_WGRAD_PARTIALS = os.environ.get("MAS_WGRAD_PARTIALS", "1") == "1"   # 0: the fp32-atomic commit everywhere (A/B switch)
+_wgrad_partials = {}
 
 # --------------------------------------------------------------------------- #
 # overlap of the HBM-bound GroupNorm backward with the MFMA-bound weight gradient (ResnetBlock backward)

@@ -303,6 +303,56 @@ def test_wgrad_scratch_is_rezeroed_between_convolutions():
     assert len(ops._wgrad_scratch) >= 1
 
 
+def test_split_k_partials_are_deterministic_and_need_no_zeroing():
+    """The 3x3 stride-1 weight gradients that carry the FLOPs store split-K PARTIALS (mas_conv_wgrad_partial) that mas_wgrad_reduce adds
+    in a fixed order -- no fp32 atomics.  (1) against autograd of F.conv2d on the CPU, ragged tile edges / upsample fold / activation
+    prologue included; (2) the workspace is poisoned with NaN before each call: every element a reduce reads was written by the launch
+    before it; (3) two runs are BITWISE equal (the atomic commit was not); (4) the atomic path (MAS_WGRAD_PARTIALS=0 route, reached
+    here through mas_conv_wgrad) agrees to fp32 summation-order noise."""
+    import ctypes as C
+    import mas_hip
+    from mas_hip import ops, ACT_NONE, ACT_AFFINE_SILU
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    for (n, cin, h, w, cout, act, up) in ((4, 128, 32, 32, 128, ACT_NONE, False), (3, 64, 24, 40, 256, ACT_AFFINE_SILU, False),
+                                          (2, 128, 12, 20, 128, ACT_NONE, True), (16, 512, 16, 16, 512, ACT_NONE, False)):
+        x = torch.randn(n, cin, h, w, generator=g).bfloat16()
+        ho, wo = (2 * h, 2 * w) if up else (h, w)
+        dy = (0.25 * torch.randn(n, cout, ho, wo, generator=g)).bfloat16()
+        ss = None
+        if act != ACT_NONE:
+            ss = torch.stack([1.0 + 0.2 * torch.randn(n, cin, generator=g), 0.3 * torch.randn(n, cin, generator=g)], dim=-1).contiguous()
+        d = ops._desc(n, h, w, cin, ho, wo, cout, 3, 1, 1, 1, torch.bfloat16, torch.bfloat16, act, up)
+        ns = mas_hip.lib().mas_conv_wgrad_splits(C.byref(d))
+        assert ns > 0, "this shape must take the split-K partial path"
+        xd, dyd, ssd = cl(x), cl(dy), (ss.to(dev) if ss is not None else None)
+        outs = []
+        for _ in range(2):
+            for ws in ops._wgrad_partials.values():
+                ws.fill_(float("nan"))
+            dw, db = ops.conv_wgrad_raw(xd, ssd, dyd, n, h, w, cin, ho, wo, cout, 3, 1, 1, 1, act, up, True)
+            torch.cuda.synchronize()
+            outs.append((dw.clone(), db.clone()))
+        assert len(ops._wgrad_partials) >= 1
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "split-K reduce is not run-to-run bitwise"
+        a = x.float()
+        if ss is not None:
+            a = _silu(a * ss[..., 0][:, :, None, None] + ss[..., 1][:, :, None, None]).bfloat16().float()
+        if up:
+            a = F.interpolate(a, scale_factor=2.0, mode="nearest")
+        wr = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+        F.conv2d(a, wr, None, padding=1).backward(dy.float())
+        assert outs[0][0].shape == wr.shape and outs[0][0].is_contiguous()
+        assert relerr(outs[0][0], wr.grad) < 2e-3 and relerr(outs[0][1], dy.float().sum((0, 2, 3))) < 2e-3, (n, cin, h, w, cout, act, up)
+        acc = torch.zeros(cout * 9 * cin + cout, dtype=torch.float32, device=dev)
+        mas_hip.check(mas_hip.lib().mas_conv_wgrad(C.byref(d), ops._ptr(xd), ops._ptr(ssd), ops._ptr(dyd), ops._ptr(acc),
+                                                   C.c_void_p(acc.data_ptr() + 4 * cout * 9 * cin), ops._stream()), "conv_wgrad")
+        torch.cuda.synchronize()
+        dwa = acc[:cout * 9 * cin].view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+        assert relerr(outs[0][0], dwa) < 1e-5 and relerr(outs[0][1], acc[cout * 9 * cin:]) < 1e-5
+
+
 # --------------------------------------------------------------------------------------------------------------
 # 6. materialised GroupNorm(+SiLU) output (mas_gn_act) == what the fused loaders form
 # --------------------------------------------------------------------------------------------------------------
