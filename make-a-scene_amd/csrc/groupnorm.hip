@@ -12,6 +12,22 @@
 namespace {
 
 constexpr int NT = 256;
+// Streaming access of the element-wise passes.  Stores of dx / the materialised activation are NON-TEMPORAL: the 0.5 GB tensors do not
+// fit the 256 MiB Infinity Cache, and written through the default policy they evict what the next pass could still have hit (x and
+// da, left there by gn_bwd_partial in the reverse block order).  Measured (profiles/r03_gn_streaming.txt): gn_bwd 128 ch @256^2
+// 0.543 -> 0.528 ms, with 4096 apply blocks 0.479; @128^2 0.125 -> 0.111.  Non-temporal LOADS are a wash: gn_bwd_partial alone gains
+// 19 % (207 -> 169 us = 6.35 TB/s) and gn_bwd_apply loses the same microseconds again (its operands were not left in the cache) --
+// -DGN_NT_LD keeps the experiment; -DGN_NO_NT_ST restores default-policy stores.
+#ifdef GN_NT_LD
+#define GN_LD(p) __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p))
+#else
+#define GN_LD(p) (*reinterpret_cast<const u32x4*>(p))
+#endif
+#ifndef GN_NO_NT_ST
+#define GN_ST(p, v) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p))
+#else
+#define GN_ST(p, v) (*reinterpret_cast<u32x4*>(p) = (v))
+#endif
 constexpr int MAX_SPLIT = 64;
 
 // ---------------------------------------------------------------------------------------
@@ -252,6 +268,76 @@ __global__ __launch_bounds__(NT) void gn_bwd_partial(const T* __restrict__ x, co
     for (int i = tid; i < 2 * C; i += NT) out[i] = red[i];
 }
 
+// backward stage 1, bf16, channel unit of a thread loop invariant (NT % (C / 8) == 0): the same sums on PACKED fp32 math.  The generic
+// kernel above issues 26 instructions per element (scalar fp32 ops, a run-time `act` branch per element, s_nop hazards around each
+// transcendental) and is instruction-issue-bound at 4.3-5.3 TB/s: 537 M elements x 26 / (1024 SIMDs x 2.4 GHz / 4) = 0.36 ms for the
+// 128-channel 256^2 map, HBM floor 0.17 ms.  Here two elements share each VALU instruction (v_pk_fma / v_pk_mul / v_pk_add; there are
+// no MFMAs in this kernel for them to disturb) and `act` is a template parameter: ~10 issue slots per element.
+template <bool SILU>
+__global__ __launch_bounds__(NT) void gn_bwd_partial_pk(const bf16_t* __restrict__ x, const bf16_t* __restrict__ da, int HW, int C, int G,
+                                                        int nsplit, const float* __restrict__ mean_rstd, const float* __restrict__ ss,
+                                                        float* __restrict__ partial, int rev) {
+    const int bid = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;   // (see gn_stats_partial)
+    const int n = bid / nsplit, sp = bid % nsplit;
+    const int upp = C / 8, cpg = C / G;
+    const int tid = threadIdx.x;
+    extern __shared__ float red[];
+    const int rows_per = (HW + nsplit - 1) / nsplit;
+    const int r0 = sp * rows_per, r1 = min(HW, r0 + rows_per);
+    const long long total = (long long)(r1 - r0) * upp;
+    const int cu = tid % upp;
+    f32x2 sc[4], sh[4], xr[4], xb[4], s1[4], s2[4];  // xhat = x * rstd - mean * rstd (one v_pk_fma)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = cu * 8 + 2 * p + h;
+            sc[p][h] = ss[((size_t)n * C + c) * 2 + 0]; sh[p][h] = ss[((size_t)n * C + c) * 2 + 1];
+            const float mu = mean_rstd[((size_t)n * G + c / cpg) * 2 + 0], rs = mean_rstd[((size_t)n * G + c / cpg) * 2 + 1];
+            xr[p][h] = rs; xb[p][h] = -mu * rs;
+            s1[p][h] = 0.0f; s2[p][h] = 0.0f;
+        }
+    }
+    auto acc2 = [&](const u32x4& rx, const u32x4& rd) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const f32x2 xe = bf16pair_f32(rx[p]);
+            f32x2 du = bf16pair_f32(rd[p]);
+            if constexpr (SILU) du = du * dsilu2_f(xe * sc[p] + sh[p]);
+            s1[p] += du; s2[p] += du * (xe * xr[p] + xb[p]);
+        }
+    };
+    const bf16_t* xb_ = x + ((size_t)n * HW + r0) * C;
+    const bf16_t* db_ = da + ((size_t)n * HW + r0) * C;
+    long long u = tid;
+    for (; u + NT < total; u += 2 * NT) {
+        const size_t o0 = (size_t)u * 8, o1 = (size_t)(u + NT) * 8;
+        const u32x4 x0 = GN_LD(xb_ + o0), x1 = GN_LD(xb_ + o1);
+        const u32x4 d0 = GN_LD(db_ + o0), d1 = GN_LD(db_ + o1);
+        acc2(x0, d0); acc2(x1, d1);
+    }
+    for (; u < total; u += NT) {
+        const u32x4 x0 = GN_LD(xb_ + (size_t)u * 8), d0 = GN_LD(db_ + (size_t)u * 8);
+        acc2(x0, d0);
+    }
+    float* slots = red + 2 * C;                     // [NT/upp][C][2]: fixed-order combine of the row groups, as in the generic kernel
+    const int rg = tid / upp, rstep = NT / upp;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            slots[((size_t)rg * C + cu * 8 + 2 * p + h) * 2 + 0] = s1[p][h];
+            slots[((size_t)rg * C + cu * 8 + 2 * p + h) * 2 + 1] = s2[p][h];
+        }
+    __syncthreads();
+    float* out = partial + ((size_t)(n * nsplit + sp) * C) * 2;
+    for (int i = tid; i < 2 * C; i += NT) {
+        float a = 0.0f;
+        for (int k = 0; k < rstep; ++k) a += slots[(size_t)k * 2 * C + i];
+        out[i] = a;
+    }
+}
+
 // backward stage 2: one block per n: coefficient table coef[n][c][4] = {c1, k2, k3, 0} with
 //   dx = c1*du + k2*x + k3 ; c1 = rstd*gamma_c ; k2 = -rstd^2*B/m ; k3 = rstd*(mean*rstd*B - A)/m
 //   A = sum_{c in g} gamma_c S1_c ; B = sum_{c in g} gamma_c S2_c ; m = cpg*HW
@@ -368,6 +454,69 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply(const T* __restrict__ x, cons
     }
 }
 
+// backward stage 3, bf16, on packed fp32 math with `act` / `dres` as template parameters (see gn_bwd_partial_pk: the generic kernel is
+// instruction-issue-bound, 0.345 ms where three 537 MB streams take 0.26 ms)
+template <bool SILU, bool RES>
+__global__ __launch_bounds__(NT) void gn_bwd_apply_pk(const bf16_t* __restrict__ x, const bf16_t* __restrict__ da, const bf16_t* __restrict__ dres,
+                                                      bf16_t* __restrict__ dx, int HW, int C, const float* __restrict__ ss,
+                                                      const float* __restrict__ coef, long long units_per_n,
+                                                      const float* __restrict__ nsum, int N, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int upp = C / 8;
+    const int n = blockIdx.y;
+    if (blockIdx.y == 0 && (dgamma || dbeta)) {     // dgamma / dbeta = sum over n of nsum
+        for (int c = blockIdx.x * NT + threadIdx.x; c < C; c += gridDim.x * NT) {
+            double a = 0.0, b = 0.0;
+            for (int m = 0; m < N; ++m) { a += (double)nsum[((size_t)m * C + c) * 2 + 0]; b += (double)nsum[((size_t)m * C + c) * 2 + 1]; }
+            if (dgamma) dgamma[c] = (float)a;
+            if (dbeta) dbeta[c] = (float)b;
+        }
+    }
+    const size_t base = (size_t)n * HW * C;
+    const long long u0 = (long long)blockIdx.x * NT + threadIdx.x;
+    const int cu = (int)(u0 % upp);
+    f32x2 sc[4], sh[4], k0[4], k1[4], k2[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = cu * 8 + 2 * p + h;
+            sc[p][h] = ss[((size_t)n * C + c) * 2]; sh[p][h] = ss[((size_t)n * C + c) * 2 + 1];
+            const float* k = coef + ((size_t)n * C + c) * 4;
+            k0[p][h] = k[0]; k1[p][h] = k[1]; k2[p][h] = k[2];
+        }
+    auto body = [&](const u32x4& rx, const u32x4& rd, const u32x4& rr, size_t off) {
+        u32x4 ov;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const f32x2 xe = bf16pair_f32(rx[p]);
+            f32x2 du = bf16pair_f32(rd[p]);
+            if constexpr (SILU) du = du * dsilu2_f(xe * sc[p] + sh[p]);
+            f32x2 v = k0[p] * du + (k1[p] * xe + k2[p]);
+            if constexpr (RES) v = v + bf16pair_f32(rr[p]);
+            ov[p] = f32pair_bf16(v);
+        }
+        GN_ST(dx + off, ov);
+    };
+    const long long stride = (long long)gridDim.x * NT;
+    long long u = u0;
+    for (; u + stride < units_per_n; u += 2 * stride) {
+        const size_t o0 = base + (size_t)u * 8, o1 = base + (size_t)(u + stride) * 8;
+        const u32x4 rx0 = GN_LD(x + o0), rx1 = GN_LD(x + o1);
+        const u32x4 rd0 = GN_LD(da + o0), rd1 = GN_LD(da + o1);
+        u32x4 rr0 = {0u, 0u, 0u, 0u}, rr1 = rr0;
+        if constexpr (RES) { rr0 = GN_LD(dres + o0); rr1 = GN_LD(dres + o1); }
+        body(rx0, rd0, rr0, o0);
+        body(rx1, rd1, rr1, o1);
+    }
+    for (; u < units_per_n; u += stride) {
+        const size_t off = base + (size_t)u * 8;
+        const u32x4 rx = GN_LD(x + off), rd = GN_LD(da + off);
+        u32x4 rr = {0u, 0u, 0u, 0u};
+        if constexpr (RES) rr = GN_LD(dres + off);
+        body(rx, rd, rr, off);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // materialised activation: a = act(x * scale + shift) in the activation dtype (one read, one write).  The optional alternative to
 // the fused loader prologue (ops.py MAS_GN_MATERIALIZE): the forward convolution AND the weight gradient of a GroupNorm(+SiLU)-fed
@@ -405,7 +554,7 @@ __global__ __launch_bounds__(NT) void gn_act_kernel(const T* __restrict__ x, T* 
                 f[e] = act == MAS_ACT_AFFINE_SILU ? silu_f(u) : u;
             }
         }
-        *reinterpret_cast<u32x4*>(a + off) = v;
+        GN_ST(a + off, v);
     };
     const long long stride = (long long)gridDim.x * NT;
     long long u = u0;
@@ -433,7 +582,8 @@ int gn_reverse() {
 
 int pick_split(int N, int HW) {
     // enough blocks to fill 256 CUs a few times over, but >= 64 pixels per block
-    int s = mas_cdiv(1024, N);
+    static const int target = mas_env_int("MAS_GN_SPLIT_BLOCKS", 1024);
+    int s = mas_cdiv(target, N);
     if (s > MAX_SPLIT) s = MAX_SPLIT;
     const int cap = HW / 64 > 0 ? HW / 64 : 1;
     if (s > cap) s = cap;
@@ -526,7 +676,13 @@ extern "C" int mas_gn_bwd(const void* x, const void* da, const void* dres, int d
     float* coef = partial + (size_t)N * MAX_SPLIT * C * 2;
     float* nsum = coef + (size_t)N * C * 4;
     const size_t lds1 = ((size_t)2 * C + (size_t)NT * epu * 2) * sizeof(float);
-    if (dtype == MAS_BF16)
+    static const int packed = mas_env_int("MAS_GN_BWD_PACKED", 1);
+    const bool pk = packed && dtype == MAS_BF16 && NT % (C / epu) == 0 && (act == MAS_ACT_AFFINE || act == MAS_ACT_AFFINE_SILU);
+    if (pk && act == MAS_ACT_AFFINE_SILU)
+        hipLaunchKernelGGL(gn_bwd_partial_pk<true>, dim3(N * nsplit), dim3(NT), lds1, s, (const bf16_t*)x, (const bf16_t*)da, HW, C, G, nsplit, mean_rstd, scale_shift, partial, gn_reverse());
+    else if (pk)
+        hipLaunchKernelGGL(gn_bwd_partial_pk<false>, dim3(N * nsplit), dim3(NT), lds1, s, (const bf16_t*)x, (const bf16_t*)da, HW, C, G, nsplit, mean_rstd, scale_shift, partial, gn_reverse());
+    else if (dtype == MAS_BF16)
         hipLaunchKernelGGL(gn_bwd_partial<bf16_t>, dim3(N * nsplit), dim3(NT), lds1, s, (const bf16_t*)x, (const bf16_t*)da, HW, C, G, nsplit, act, mean_rstd, scale_shift, partial, gn_reverse());
     else
         hipLaunchKernelGGL(gn_bwd_partial<float>, dim3(N * nsplit), dim3(NT), lds1, s, (const float*)x, (const float*)da, HW, C, G, nsplit, act, mean_rstd, scale_shift, partial, gn_reverse());
@@ -535,10 +691,23 @@ extern "C" int mas_gn_bwd(const void* x, const void* da, const void* dres, int d
     MAS_CHECK_LAUNCH("gn_bwd_finalize");
     const long long units_per_n = (long long)HW * C / epu;
     int gx = (int)((units_per_n + NT - 1) / NT);
-    const int cap = mas_cdiv(2048, N) > 0 ? mas_cdiv(2048, N) : 1;
+    // 4096 blocks over the batch (16 per CU: the write stream wants more requests in flight than 8 gave it, 0.528 -> 0.479 ms at 128 ch
+    // @256^2), but at least four 16-byte units per thread (512 ch @32^2 loses 8 % on thinner blocks)
+    static const int apply_blocks = mas_env_int("MAS_GN_APPLY_BLOCKS", 4096);
+    int cap = mas_cdiv(apply_blocks, N) > 0 ? mas_cdiv(apply_blocks, N) : 1;
+    const long long thick = units_per_n / (4LL * NT);
+    if (cap > thick) cap = thick > 0 ? (int)thick : 1;
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
-    if (dtype == MAS_BF16)
+#define MAS_GN_APPLY_PK(SILU, RES) hipLaunchKernelGGL((gn_bwd_apply_pk<SILU, RES>), dim3(gx, N), dim3(NT), 0, s, (const bf16_t*)x, (const bf16_t*)da, \
+        (const bf16_t*)dres, (bf16_t*)dx, HW, C, scale_shift, coef, units_per_n, nsum, N, dgamma, dbeta)
+    if (pk) {
+        const bool silu = act == MAS_ACT_AFFINE_SILU;
+        if (silu && dres) MAS_GN_APPLY_PK(true, true);
+        else if (silu) MAS_GN_APPLY_PK(true, false);
+        else if (dres) MAS_GN_APPLY_PK(false, true);
+        else MAS_GN_APPLY_PK(false, false);
+    } else if (dtype == MAS_BF16)
         hipLaunchKernelGGL(gn_bwd_apply<bf16_t>, dim3(gx, N), dim3(NT), 0, s, (const bf16_t*)x, (const bf16_t*)da, (const bf16_t*)dres, (bf16_t*)dx, HW, C, act, scale_shift, coef, units_per_n, nsum, N, dgamma, dbeta);
     else
         hipLaunchKernelGGL(gn_bwd_apply<float>, dim3(gx, N), dim3(NT), 0, s, (const float*)x, (const float*)da, (const float*)dres, (float*)dx, HW, C, act, scale_shift, coef, units_per_n, nsum, N, dgamma, dbeta);

@@ -105,6 +105,24 @@ __device__ __forceinline__ unsigned act_pair_bf16(unsigned w, f32x2 sc, f32x2 sh
     const bf16x2 o = __builtin_convertvector(u, bf16x2);
     return *reinterpret_cast<const unsigned*>(&o);
 }
+// two bf16 of one dword -> two fp32 (v_lshlrev / v_and), and the packed silu'(u): 5 v_pk_* + 2 v_exp + 2 v_rcp for two elements
+__device__ __forceinline__ f32x2 bf16pair_f32(unsigned w) {
+    f32x2 x;
+    x[0] = __uint_as_float(w << 16); x[1] = __uint_as_float(w & 0xffff0000u);
+    return x;
+}
+__device__ __forceinline__ unsigned f32pair_bf16(f32x2 v) {
+    const bf16x2 o = __builtin_convertvector(v, bf16x2);
+    return *reinterpret_cast<const unsigned*>(&o);
+}
+__device__ __forceinline__ f32x2 dsilu2_f(f32x2 u) {
+    f32x2 t = u * -1.4426950408889634f;
+    t[0] = __builtin_amdgcn_exp2f(t[0]); t[1] = __builtin_amdgcn_exp2f(t[1]);
+    t = t + 1.0f;
+    f32x2 s;
+    s[0] = __builtin_amdgcn_rcpf(t[0]); s[1] = __builtin_amdgcn_rcpf(t[1]);
+    return s * (u * (1.0f - s) + 1.0f);
+}
 // d silu(u)/du = s*(1+u*(1-s)),  s = sigmoid(u)
 __device__ __forceinline__ float dsilu_f(float u) { float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u)); return s * (1.0f + u * (1.0f - s)); }
 

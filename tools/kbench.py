@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of single libmas_hip kernels on synthetic shapes (HIP-event timed).
-    python tools/kbench.py conv_fwd|dgrad|wgrad|gn_stats|gn_bwd|vq [--n 32 --c 128 --hw 256 --act 2 --iters 20]
+    python tools/kbench.py conv_fwd|dgrad|wgrad|gn_stats|gn_bwd|gn_act|vq [--n 32 --c 128 --hw 256 --act 2 --iters 20]
 Prints achieved TFLOP/s / GB/s per launch; run under rocprofv3 for counters."""
 import argparse
 import os
@@ -77,6 +77,11 @@ def main():
         da = torch.randn_like(x)
         ms = timeit(lambda: ops.gn_bwd(x, da, None, 32, a.act or 2, g, mr, ss), a.iters)
         print(f"gn_bwd n={n} c={c} hw={h}: {ms:.4f} ms  {5*x.numel()*esz/ms/1e6:.1f} GB/s (2 reads x2 + 1 write)")
+    elif a.kind == "gn_act":
+        g, bta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+        mr, ss = ops.gn_stats(x, g, bta, 32, 1e-6)
+        ms = timeit(lambda: ops.gn_act(x, ss, a.act or 2), a.iters)
+        print(f"gn_act n={n} c={c} hw={h}: {ms:.4f} ms  {2*x.numel()*esz/ms/1e6:.1f} GB/s (1 read + 1 write)")
     elif a.kind == "attn":
         b, h, sq, hd = a.n, 16, a.hw if a.hw != 256 else 1536, 64
         qkv = torch.randn(b, sq, 3 * h * hd, device=dev).to(dt).requires_grad_(True)
