@@ -27,7 +27,18 @@ struct AttnParams {
     int ld_q, ld_k, ld_v;           // token strides (elements)
     int B, H, S;
     float scale;
+    int lpt;                        // grid = (B * H, tiles) instead of (tiles, B * H): see fa_lpt()
 };
+
+// Causal attention work per work-group grows linearly with its tile index, and the grid (12 tiles x 128 heads at S = 1536, B = 8) is
+// 1.5 rounds of the 1024 resident work-groups.  With the tile index in blockIdx.x the dispatcher hands out heavy and light work-groups
+// interleaved, head by head, and the last heads' heaviest tiles START late: makespan ~ 7 + 24 tile-times where the balanced load is
+// 19.5.  With (B * H) in blockIdx.x and the heaviest tile in blockIdx.y = 0 the dispatch order is longest-processing-time-first, and
+// a head's work-groups all land on XCD (head % 8): its K / V stay in one L2.  MAS_ATTN_LPT=0 restores the old order.
+static int fa_lpt() {
+    static const int v = mas_env_int("MAS_ATTN_LPT", 1);
+    return v;
+}
 
 template <typename T, int HD>
 __global__ __launch_bounds__(NT) void attn_causal_fwd_kernel(AttnParams p) {
@@ -390,8 +401,8 @@ __global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnPara
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, l31 = lane & 31, G16 = (lane >> 4) & 1, sl = lane & 15;
-    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
-    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * QT;     // heavy blocks first
+    const int bh = p.lpt ? blockIdx.x : blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = p.lpt ? ((int)gridDim.y - 1 - (int)blockIdx.y) * QT : ((int)gridDim.x - 1 - (int)blockIdx.x) * QT;     // heavy blocks first
     const int qw = q0 + wave * 32, query = qw + l31;
 
     const T* __restrict__ Q = reinterpret_cast<const T*>(p.q) + (size_t)b * p.q_bs + (size_t)h * HD;
@@ -564,7 +575,10 @@ __global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnPara
 }
 
 int launch_fwd_fast_v2(const AttnParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(attn_causal_fwd_bf16_v2_kernel, dim3(mas_cdiv(p.S, QT), p.B * p.H), dim3(NT), F2_LDS, s, p);
+    AttnParams q = p;
+    q.lpt = fa_lpt();
+    const dim3 grid = q.lpt ? dim3(p.B * p.H, mas_cdiv(p.S, QT)) : dim3(mas_cdiv(p.S, QT), p.B * p.H);
+    hipLaunchKernelGGL(attn_causal_fwd_bf16_v2_kernel, grid, dim3(NT), F2_LDS, s, q);
     MAS_CHECK_LAUNCH("attn_causal_fwd_v2");
     return MAS_OK;
 }
@@ -606,6 +620,7 @@ struct AttnBwdParams {
     long long bs; int ld;           // q/k/v and dq/dk/dv share the fused-qkv addressing: ptr[b*bs + s*ld + h*hd + d]
     int B, H, S;
     float scale;
+    int lpt;                        // (see AttnParams)
 };
 
 template <typename T, int HD>
@@ -909,8 +924,8 @@ __global__ __launch_bounds__(NT, FA_DKV_WGS) void attn_bwd_dkv_bf16_kernel(AttnB
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, l31 = lane & 31, G16 = (lane >> 4) & 1, sl = lane & 15;
-    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
-    const int k0 = blockIdx.x * QT;                 // 128 keys per work-group; block 0 is the heaviest (all queries)
+    const int bh = p.lpt ? blockIdx.x : blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int k0 = (p.lpt ? blockIdx.y : blockIdx.x) * QT;          // 128 keys per work-group; block 0 is the heaviest (all queries)
     const int kw = k0 + wave * 32, key = kw + l31;
     const size_t head = (size_t)b * p.bs + (size_t)h * HD;
     const T* __restrict__ Q = reinterpret_cast<const T*>(p.q) + head;
@@ -1054,8 +1069,8 @@ __global__ __launch_bounds__(NT, 3) void attn_bwd_dq_bf16_kernel(AttnBwdParams p
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, l31 = lane & 31, G16 = (lane >> 4) & 1, sl = lane & 15;
-    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
-    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * QT;     // heavy (late) query blocks first
+    const int bh = p.lpt ? blockIdx.x : blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = p.lpt ? ((int)gridDim.y - 1 - (int)blockIdx.y) * QT : ((int)gridDim.x - 1 - (int)blockIdx.x) * QT;     // heavy (late) query blocks first
     const int qw = q0 + wave * 32, query = qw + l31;
     const size_t head = (size_t)b * p.bs + (size_t)h * HD;
     const T* __restrict__ Q = reinterpret_cast<const T*>(p.q) + head;
@@ -1163,10 +1178,12 @@ __global__ __launch_bounds__(NT, 3) void attn_bwd_dq_bf16_kernel(AttnBwdParams p
 int launch_bwd_fast64(const AttnBwdParams& p, hipStream_t s) {
     const long long rows = (long long)p.B * p.H * p.S;
     hipLaunchKernelGGL((attn_bwd_delta_kernel<bf16_t, 64>), dim3((unsigned)((rows + NT - 1) / NT)), dim3(NT), 0, s, p);
-    const dim3 grid(mas_cdiv(p.S, QT), p.B * p.H);
+    AttnBwdParams q = p;
+    q.lpt = fa_lpt();
+    const dim3 grid = q.lpt ? dim3(p.B * p.H, mas_cdiv(p.S, QT)) : dim3(mas_cdiv(p.S, QT), p.B * p.H);
     constexpr size_t lds_dkv = 2 * (2 * FaTile::BYTES + 2 * 64 * sizeof(float)), lds_dq = 2 * (2 * FaTile::BYTES);
-    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, dim3(NT), lds_dkv, s, p);
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, dim3(NT), lds_dq, s, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, dim3(NT), lds_dkv, s, q);
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, dim3(NT), lds_dq, s, q);
     MAS_CHECK_LAUNCH("attn_causal_bwd");
     return MAS_OK;
 }
@@ -1218,7 +1235,7 @@ extern "C" int mas_attn_causal_fwd(const void* q, const void* k, const void* v, 
     AttnParams p;
     p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse;
     p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.ld_q = ld_q; p.ld_k = ld_k; p.ld_v = ld_v;
-    p.B = B; p.H = H; p.S = S; p.scale = scale;
+    p.B = B; p.H = H; p.S = S; p.scale = scale; p.lpt = 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MAS_BF16) {
         const bool fast = (hd == 64 || hd == 128) && fa_aligned(q, q_bs, ld_q) && fa_aligned(k, k_bs, ld_k) && fa_aligned(v, v_bs, ld_v) &&
@@ -1249,7 +1266,7 @@ extern "C" int mas_attn_causal_bwd(const void* qkv, const void* o, const void* d
     p.q = x; p.k = x + (size_t)d * esz; p.v = x + (size_t)2 * d * esz;
     p.dq = gx; p.dk = gx + (size_t)d * esz; p.dv = gx + (size_t)2 * d * esz;
     p.o = o; p.dout = dout; p.lse = lse; p.delta = delta;
-    p.ld = 3 * d; p.bs = (long long)S * 3 * d; p.B = B; p.H = H; p.S = S; p.scale = scale;
+    p.ld = 3 * d; p.bs = (long long)S * 3 * d; p.B = B; p.H = H; p.S = S; p.scale = scale; p.lpt = 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MAS_BF16) {
         const bool al = ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dqkv) | reinterpret_cast<uintptr_t>(dout)) & 15) == 0 && (d % 8) == 0;
