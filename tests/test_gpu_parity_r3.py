@@ -381,3 +381,18 @@ def test_gn_act_equals_the_fused_prologue(shape, dtype):
             y_fused = ops.conv_fwd_raw(xd, ss.to(dev), ops.ConvWeight(wt, False), None, None, n, h, w, c, h, w, 64, 3, 1, 1, 1, act, False, dtype)
             y_mat = ops.conv_fwd_raw(a, None, ops.ConvWeight(wt, False), None, None, n, h, w, c, h, w, 64, 3, 1, 1, 1, ACT_NONE, False, dtype)
             assert torch.equal(y_fused, y_mat), (shape, dtype, act)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# 7. MAS_WEIGHT_CACHE_CHECK=1: the debugging aid for writes the packed-weight stamp cannot see
+# --------------------------------------------------------------------------------------------------------------
+def test_weight_cache_check_flags_a_write_through_data():
+    """``w.data.mul_(2)`` changes neither ``_version`` nor the storage: the packed image stays stale until invalidate_weight_cache().
+    With MAS_WEIGHT_CACHE_CHECK=1 the next cache hit must raise instead of convolving with the old weights (ops.py:_PackCache)."""
+    import subprocess
+    _dev()
+    env = dict(os.environ, MAS_WEIGHT_CACHE_CHECK="1")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "helpers", "cache_check.py")], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "flagged:" in r.stdout and "after invalidate ok True" in r.stdout, r.stdout
