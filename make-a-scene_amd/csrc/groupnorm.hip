@@ -580,11 +580,11 @@ int gn_reverse() {
     return r;
 }
 
-int pick_split(int N, int HW) {
+int pick_split(int N, int HW, int max_split = MAX_SPLIT) {
     // enough blocks to fill 256 CUs a few times over, but >= 64 pixels per block
     static const int target = mas_env_int("MAS_GN_SPLIT_BLOCKS", 1024);
     int s = mas_cdiv(target, N);
-    if (s > MAX_SPLIT) s = MAX_SPLIT;
+    if (s > max_split) s = max_split;
     const int cap = HW / 64 > 0 ? HW / 64 : 1;
     if (s > cap) s = cap;
     return s < 1 ? 1 : s;
@@ -671,46 +671,71 @@ extern "C" int mas_gn_bwd(const void* x, const void* da, const void* dres, int d
     if (C % epu || NT % (C / epu)) MAS_FAIL(MAS_EUNSUPPORTED, "gn_bwd: C=%d: C/%d must divide %d", C, epu, NT);
     if (ws_bytes < mas_gn_bwd_workspace(N, C)) MAS_FAIL(MAS_EWORKSPACE, "gn_bwd: workspace too small");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int nsplit = pick_split(N, HW);
     float* partial = reinterpret_cast<float*>(workspace);
     float* coef = partial + (size_t)N * MAX_SPLIT * C * 2;
     float* nsum = coef + (size_t)N * C * 4;
     const size_t lds1 = ((size_t)2 * C + (size_t)NT * epu * 2) * sizeof(float);
     static const int packed = mas_env_int("MAS_GN_BWD_PACKED", 1);
     const bool pk = packed && dtype == MAS_BF16 && NT % (C / epu) == 0 && (act == MAS_ACT_AFFINE || act == MAS_ACT_AFFINE_SILU);
-    if (pk && act == MAS_ACT_AFFINE_SILU)
-        hipLaunchKernelGGL(gn_bwd_partial_pk<true>, dim3(N * nsplit), dim3(NT), lds1, s, (const bf16_t*)x, (const bf16_t*)da, HW, C, G, nsplit, mean_rstd, scale_shift, partial, gn_reverse());
-    else if (pk)
-        hipLaunchKernelGGL(gn_bwd_partial_pk<false>, dim3(N * nsplit), dim3(NT), lds1, s, (const bf16_t*)x, (const bf16_t*)da, HW, C, G, nsplit, mean_rstd, scale_shift, partial, gn_reverse());
-    else if (dtype == MAS_BF16)
-        hipLaunchKernelGGL(gn_bwd_partial<bf16_t>, dim3(N * nsplit), dim3(NT), lds1, s, (const bf16_t*)x, (const bf16_t*)da, HW, C, G, nsplit, act, mean_rstd, scale_shift, partial, gn_reverse());
-    else
-        hipLaunchKernelGGL(gn_bwd_partial<float>, dim3(N * nsplit), dim3(NT), lds1, s, (const float*)x, (const float*)da, HW, C, G, nsplit, act, mean_rstd, scale_shift, partial, gn_reverse());
-    MAS_CHECK_LAUNCH("gn_bwd_partial");
-    hipLaunchKernelGGL(gn_bwd_finalize, dim3(N), dim3(NT), (size_t)2 * C * sizeof(double), s, partial, HW, C, G, nsplit, gamma, mean_rstd, coef, nsum);
-    MAS_CHECK_LAUNCH("gn_bwd_finalize");
+    const size_t esz = dtype == MAS_BF16 ? 2 : 4;
+    const size_t img = (size_t)HW * C * esz;                         // bytes of one image of x (= of da, dres, dx)
+    // The statistics are per image, so the three stages can walk the batch in IMAGE GROUPS: reduce -> finalize -> apply per group, the
+    // apply pass re-reading x / da while the group is still in the 256 MiB Infinity Cache (MAS_GN_BWD_CHUNK_MB = budget for the group's
+    // x + da, 0 = one group; profiles/r03_gn_streaming.txt section 4).  The partial table is reused by every group (stream order).
+    static const int chunk_mb = mas_env_int("MAS_GN_BWD_CHUNK_MB", 0);
+    int nc = N;
+    if (chunk_mb > 0 && 2 * img * (size_t)N > ((size_t)chunk_mb << 20)) {
+        nc = (int)(((size_t)chunk_mb << 20) / (2 * img));
+        if (nc < 1) nc = 1;
+    }
     const long long units_per_n = (long long)HW * C / epu;
-    int gx = (int)((units_per_n + NT - 1) / NT);
-    // 4096 blocks over the batch (16 per CU: the write stream wants more requests in flight than 8 gave it, 0.528 -> 0.479 ms at 128 ch
-    // @256^2), but at least four 16-byte units per thread (512 ch @32^2 loses 8 % on thinner blocks)
     static const int apply_blocks = mas_env_int("MAS_GN_APPLY_BLOCKS", 4096);
-    int cap = mas_cdiv(apply_blocks, N) > 0 ? mas_cdiv(apply_blocks, N) : 1;
-    const long long thick = units_per_n / (4LL * NT);
-    if (cap > thick) cap = thick > 0 ? (int)thick : 1;
-    if (gx > cap) gx = cap;
-    if (gx < 1) gx = 1;
-#define MAS_GN_APPLY_PK(SILU, RES) hipLaunchKernelGGL((gn_bwd_apply_pk<SILU, RES>), dim3(gx, N), dim3(NT), 0, s, (const bf16_t*)x, (const bf16_t*)da, \
-        (const bf16_t*)dres, (bf16_t*)dx, HW, C, scale_shift, coef, units_per_n, nsum, N, dgamma, dbeta)
-    if (pk) {
-        const bool silu = act == MAS_ACT_AFFINE_SILU;
-        if (silu && dres) MAS_GN_APPLY_PK(true, true);
-        else if (silu) MAS_GN_APPLY_PK(true, false);
-        else if (dres) MAS_GN_APPLY_PK(false, true);
-        else MAS_GN_APPLY_PK(false, false);
-    } else if (dtype == MAS_BF16)
-        hipLaunchKernelGGL(gn_bwd_apply<bf16_t>, dim3(gx, N), dim3(NT), 0, s, (const bf16_t*)x, (const bf16_t*)da, (const bf16_t*)dres, (bf16_t*)dx, HW, C, act, scale_shift, coef, units_per_n, nsum, N, dgamma, dbeta);
-    else
-        hipLaunchKernelGGL(gn_bwd_apply<float>, dim3(gx, N), dim3(NT), 0, s, (const float*)x, (const float*)da, (const float*)dres, (float*)dx, HW, C, act, scale_shift, coef, units_per_n, nsum, N, dgamma, dbeta);
-    MAS_CHECK_LAUNCH("gn_bwd_apply");
+    for (int n0 = 0; n0 < N; n0 += nc) {
+        const int cn = N - n0 < nc ? N - n0 : nc;
+        const bool last = n0 + cn >= N;
+        int nsplit = pick_split(cn, HW, (int)std::min<long long>(256, (long long)MAX_SPLIT * N / cn));
+        const unsigned char* xc = (const unsigned char*)x + (size_t)n0 * img;
+        const unsigned char* dac = (const unsigned char*)da + (size_t)n0 * img;
+        const unsigned char* drc = dres ? (const unsigned char*)dres + (size_t)n0 * img : nullptr;
+        unsigned char* dxc = (unsigned char*)dx + (size_t)n0 * img;
+        const float* mrc = mean_rstd + (size_t)n0 * G * 2;
+        const float* ssc = scale_shift + (size_t)n0 * C * 2;
+        float* coefc = coef + (size_t)n0 * C * 4;
+        float* nsumc = nsum + (size_t)n0 * C * 2;
+        if (pk && act == MAS_ACT_AFFINE_SILU)
+            hipLaunchKernelGGL(gn_bwd_partial_pk<true>, dim3(cn * nsplit), dim3(NT), lds1, s, (const bf16_t*)xc, (const bf16_t*)dac, HW, C, G, nsplit, mrc, ssc, partial, gn_reverse());
+        else if (pk)
+            hipLaunchKernelGGL(gn_bwd_partial_pk<false>, dim3(cn * nsplit), dim3(NT), lds1, s, (const bf16_t*)xc, (const bf16_t*)dac, HW, C, G, nsplit, mrc, ssc, partial, gn_reverse());
+        else if (dtype == MAS_BF16)
+            hipLaunchKernelGGL(gn_bwd_partial<bf16_t>, dim3(cn * nsplit), dim3(NT), lds1, s, (const bf16_t*)xc, (const bf16_t*)dac, HW, C, G, nsplit, act, mrc, ssc, partial, gn_reverse());
+        else
+            hipLaunchKernelGGL(gn_bwd_partial<float>, dim3(cn * nsplit), dim3(NT), lds1, s, (const float*)xc, (const float*)dac, HW, C, G, nsplit, act, mrc, ssc, partial, gn_reverse());
+        MAS_CHECK_LAUNCH("gn_bwd_partial");
+        hipLaunchKernelGGL(gn_bwd_finalize, dim3(cn), dim3(NT), (size_t)2 * C * sizeof(double), s, partial, HW, C, G, nsplit, gamma, mrc, coefc, nsumc);
+        MAS_CHECK_LAUNCH("gn_bwd_finalize");
+        int gx = (int)((units_per_n + NT - 1) / NT);
+        // 4096 blocks over the batch (16 per CU: the write stream wants more requests in flight than 8 gave it, 0.528 -> 0.479 ms at 128 ch
+        // @256^2), but at least four 16-byte units per thread (512 ch @32^2 loses 8 % on thinner blocks)
+        int cap = mas_cdiv(apply_blocks, cn) > 0 ? mas_cdiv(apply_blocks, cn) : 1;
+        const long long thick = units_per_n / (4LL * NT);
+        if (cap > thick) cap = thick > 0 ? (int)thick : 1;
+        if (gx > cap) gx = cap;
+        if (gx < 1) gx = 1;
+        float* dg = last ? dgamma : nullptr;                         // dgamma / dbeta = sums over ALL images of nsum: by the last group's launch
+        float* db = last ? dbeta : nullptr;
+#define MAS_GN_APPLY_PK(SILU, RES) hipLaunchKernelGGL((gn_bwd_apply_pk<SILU, RES>), dim3(gx, cn), dim3(NT), 0, s, (const bf16_t*)xc, (const bf16_t*)dac, \
+            (const bf16_t*)drc, (bf16_t*)dxc, HW, C, ssc, coefc, units_per_n, nsum, N, dg, db)
+        if (pk) {
+            const bool silu = act == MAS_ACT_AFFINE_SILU;
+            if (silu && drc) MAS_GN_APPLY_PK(true, true);
+            else if (silu) MAS_GN_APPLY_PK(true, false);
+            else if (drc) MAS_GN_APPLY_PK(false, true);
+            else MAS_GN_APPLY_PK(false, false);
+        } else if (dtype == MAS_BF16)
+            hipLaunchKernelGGL(gn_bwd_apply<bf16_t>, dim3(gx, cn), dim3(NT), 0, s, (const bf16_t*)xc, (const bf16_t*)dac, (const bf16_t*)drc, (bf16_t*)dxc, HW, C, act, ssc, coefc, units_per_n, nsum, N, dg, db);
+        else
+            hipLaunchKernelGGL(gn_bwd_apply<float>, dim3(gx, cn), dim3(NT), 0, s, (const float*)xc, (const float*)dac, (const float*)drc, (float*)dxc, HW, C, act, ssc, coefc, units_per_n, nsum, N, dg, db);
+        MAS_CHECK_LAUNCH("gn_bwd_apply");
+    }
     return MAS_OK;
 }
