@@ -1,0 +1,194 @@
+// 1x1 / stride-1 / bf16 convolution = the plain GEMM  y[pixel][cout] = sum_ci a[pixel][ci] * w[cout][ci] + bias (+ residual)  on NHWC rows
+// (reference models/modules.py:106-108 `nin_shortcut`, :145-160 AttnBlock q / k / v / proj_out, and the data gradients of the same sites).
+//
+// Why its own kernel.  conv_fwd.hip stages a halo patch per 64-channel chunk and then runs the filter taps over it: nine taps of MFMA
+// work per staging for a 3x3 filter, ONE for a 1x1 -- the same barriers, waits and register-staged copies for a ninth of the arithmetic
+// (profiles/r03_conv_shapes.txt: 512 -> 1536 @16^2 52 us = 247 TFLOP/s, the data gradient 37 us, all 1x1 launches 1.7 ms of a 60 ms step).
+// Without a halo there is nothing to stage but two plain tiles, so this is a textbook LDS-tiled GEMM in the idiom of the other kernels:
+//   * tile = 128 pixels x 128 couts, K chunks of 64 channels (128-byte rows); both operands go global -> LDS by DMA
+//     (`buffer_load_dwordx4 ... lds`, inline assembly: no staging registers, and no compiler-inserted vmcnt(0) in front of the LDS reads),
+//     double-buffered, ONE work-group barrier per chunk: chunk c + 1 is requested right after the barrier that publishes chunk c;
+//   * the weights come straight from the K64 image conv_fwd.hip uses (mas_pack_conv_weight_layout: [chunk][tap][cout][128 B], 16-byte slot
+//     ^ ((row >> 1) & 7)); the pixel rows get the same XOR on the SOURCE address of the DMA, so every ds_read_b128 is conflict-free;
+//   * 4 waves, wave tile 64 couts x 64 pixels (4 accumulator tiles of v_mfma_f32_32x32x16_bf16: 1 fragment read per MFMA);
+//   * epilogue as in conv3x3_stream.hip: lanes l / l + 32 swap accumulator quads so that a lane owns 8 consecutive couts of its pixel:
+//     16-byte bias / residual loads and stores.
+// LDS 64 KiB, <= 128 VGPRs: two work-groups per CU.
+#include "mas_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) int pw_i32x4;
+__device__ __forceinline__ void pw_dma16(pw_i32x4 rs, unsigned lds, int vo) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(vo), "s"(rs) : "memory", "m0");
+}
+__device__ __forceinline__ pw_i32x4 pw_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    pw_i32x4 r = {(int)(unsigned)a, (int)(unsigned)(a >> 32), (int)bytes, 0x00020000};
+    r[0] = __builtin_amdgcn_readfirstlane(r[0]); r[1] = __builtin_amdgcn_readfirstlane(r[1]);
+    r[2] = __builtin_amdgcn_readfirstlane(r[2]); r[3] = __builtin_amdgcn_readfirstlane(r[3]);
+    return r;
+}
+
+struct PwParams {
+    const unsigned char* a; const unsigned char* w; const float* bias; const unsigned char* res; unsigned char* y;
+    int M, K, N;                               // pixels, input channels, output channels
+    int rows_pad, n_chunks, n_nt;              // weight image: rows per chunk (Cout rounded up to 128), 64-channel chunks; cout tiles
+};
+
+constexpr int PW_NT = 256;
+constexpr int PW_TILE = 128 * 128;             // 128 rows x 128 B
+constexpr int PW_STAGE = 2 * PW_TILE;          // pixel rows, then weight rows
+constexpr int PW_LDS = 2 * PW_STAGE;
+constexpr int PW_OOB = (int)0x80000000;
+
+__global__ __launch_bounds__(PW_NT, 2) void conv1x1_kernel(PwParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)pw_smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31;
+    const int wave_n = wave & 1, wave_m = wave >> 1;               // 2 x 64 couts, 2 x 64 pixels
+    // cout tile fastest: the work-groups that share a pixel tile are dispatched together (its rows come from HBM once, then L2)
+    const int nt = (int)blockIdx.x % p.n_nt, mt = (int)blockIdx.x / p.n_nt;
+    const int m0 = mt * 128, n0 = nt * 128;
+
+    const pw_i32x4 rs_a = pw_rsrc(p.a, (unsigned)((size_t)p.M * p.K * 2));
+    const pw_i32x4 rs_w = pw_rsrc(p.w, (unsigned)((size_t)p.n_chunks * p.rows_pad * 128));
+
+    // ---- DMA plan: a tile is 16 pieces of 8 rows x 128 B; wave w moves pieces 4 w .. 4 w + 3 of both tiles.  LDS image lane-linear
+    //      (row 8 piece + (lane >> 3), physical slot lane & 7); the pixel rows carry the swizzle on the SOURCE slot, the weight image
+    //      is stored swizzled already.
+    int va[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3), ps = lane & 7;
+        va[j] = (m0 + row < p.M) ? (m0 + row) * p.K * 2 + ((ps ^ ((row >> 1) & 7)) << 4) : PW_OOB;
+    }
+    const int vw = n0 * 128 + wave * 4096 + lane * 16;
+    auto issue = [&](int c, int stage) {
+        const int wc = c * p.rows_pad * 128;                        // uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned dst = lds0 + stage * PW_STAGE + (wave * 4 + j) * 1024;
+            pw_dma16(rs_a, __builtin_amdgcn_readfirstlane(dst), va[j] + c * 128);          // (PW_OOB + c * 128 stays out of range)
+            pw_dma16(rs_w, __builtin_amdgcn_readfirstlane(dst + PW_TILE), vw + wc + j * 1024);
+        }
+    };
+
+    // ---- fragment addresses (lane parts; stage and k-step are immediates / XOR constants)
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave_n * 64 + i * 32 + l31;                 // cout row of the weight tile
+        aoff[i] = PW_TILE + row * 128 + ((g ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = wave_m * 64 + j * 32 + l31;                 // pixel row
+        boff[j] = row * 128 + ((g ^ ((row >> 1) & 7)) << 4);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    issue(0, 0);
+    auto chunk = [&](int c, auto stage_c) {
+        constexpr int ST = decltype(stage_c)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of chunk c have landed ...
+        __builtin_amdgcn_s_barrier();                                // ... everybody's have, and everybody is done reading chunk c - 1
+        asm volatile("" ::: "memory");
+        if (c + 1 < p.n_chunks) issue(c + 1, ST ^ 1);
+        const unsigned char* sb = pw_smem + ST * PW_STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 afr[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) afr[i] = *reinterpret_cast<const bf16x8*>(sb + (aoff[i] ^ (kk << 5)));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + (boff[j] ^ (kk << 5)));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma16(acc[i][j], afr[i], bfr[j]);               // D[cout][pixel]: registers = couts, lane = pixel
+        }
+    };
+    for (int c = 0; c < p.n_chunks; c += 2) {
+        chunk(c, std::integral_constant<int, 0>{});
+        if (c + 1 < p.n_chunks) chunk(c + 1, std::integral_constant<int, 1>{});
+    }
+
+    // ---- epilogue (bias and residual by UNCONDITIONAL buffer loads: a null pointer is a zero-length descriptor that returns zeros)
+    const unsigned out_bytes = (unsigned)((size_t)p.M * p.N * 2);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.res ? p.res : p.y), 0, p.res ? out_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(p.bias ? (void*)p.bias : (void*)p.y, 0, p.bias ? (unsigned)(p.N * 4) : 0u, 0x00020000);
+    f32x4 bv[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+            const int cb = (n0 + wave_n * 64 + i * 32 + 16 * qp + 8 * g) * 4;
+            bv[i][qp][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, cb, 0, 0));
+            bv[i][qp][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, cb + 16, 0, 0));
+        }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pix = m0 + wave_m * 64 + j * 32 + l31;
+        const int obase = pix < p.M ? (pix * p.N + n0 + wave_n * 64 + 8 * g) * 2 : PW_OOB;   // the stores add (i * 32 + qp * 16) * 2
+        u32x4 rv[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) rv[i][qp] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, obase + (i * 32 + qp * 16) * 2, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float qa = acc[i][j][(2 * qp) * 4 + e], qb = acc[i][j][(2 * qp + 1) * 4 + e];
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(qa), __float_as_uint(qb), false, false);
+                    v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
+                }
+                const bf16_t* rb = reinterpret_cast<const bf16_t*>(&rv[i][qp]);
+                u32x4 o;
+                bf16_t* ob = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ob[e] = (bf16_t)(v[e] + bv[i][qp][e >> 2][e & 3] + (float)rb[e]);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, obase + (i * 32 + qp * 16) * 2, 0, 0);
+            }
+    }
+}
+
+}  // namespace
+
+// Returns 1 if the convolution is a plain 1x1 GEMM this kernel takes (and the launch was made), 0 if the caller should use conv_fwd.hip.
+int mas_conv1x1_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s) {
+    static const int on = mas_env_int("MAS_CONV1X1", 1);
+    if (!on) return 0;
+    if (d->ks != 1 || d->stride != 1 || d->upsample || d->act != MAS_ACT_NONE || d->pad_top || d->pad_left) return 0;
+    if (d->in_dtype != MAS_BF16 || d->out_dtype != MAS_BF16 || d->w_layout != MAS_WLAYOUT_K64) return 0;
+    if (d->Cin % 64 || d->Cout % 128 || d->Ho != d->H || d->Wo != d->W) return 0;
+    const long long M = (long long)d->N * d->H * d->W;
+    if (M * d->Cin * 2 >= 0x7fffffffLL || M * d->Cout * 2 >= 0x7fffffffLL) return 0;
+    PwParams p;
+    p.a = (const unsigned char*)x; p.w = (const unsigned char*)w_packed; p.bias = bias; p.res = (const unsigned char*)residual; p.y = (unsigned char*)y;
+    p.M = (int)M; p.K = d->Cin; p.N = d->Cout;
+    p.rows_pad = mas_roundup(d->Cout, 128); p.n_chunks = d->Cin / 64; p.n_nt = d->Cout / 128;
+    static bool attr = false;                   // (64 KiB of dynamic LDS needs no opt-in on gfx950; kept for symmetry with the other launchers)
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
+        attr = true;
+    }
+    const long long grid = (M + 127) / 128 * p.n_nt;
+    hipLaunchKernelGGL(conv1x1_kernel, dim3((unsigned)grid), dim3(PW_NT), PW_LDS, s, p);
+    MAS_CHECK_LAUNCH("conv1x1");
+    return 1;
+}

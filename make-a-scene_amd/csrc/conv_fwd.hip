@@ -612,6 +612,7 @@ int mas_conv3x3_wide_launch(const MasConvDesc* d, const void* x, const float* sc
                             const void* residual, void* y, float* stats, void* act_out, hipStream_t s);
 bool mas_conv3x3_wide_act_out_ok(const MasConvDesc* d);
 int mas_conv3x3_wide_stat_rows(const MasConvDesc* d);
+int mas_conv1x1_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s);
 
 // Can mas_conv_fwd_stats fill the consumer's GroupNorm statistics for this convolution, and with how many table rows per image?
 extern "C" int mas_conv_stat_rows(const MasConvDesc* d) {
@@ -672,6 +673,10 @@ static int conv_fwd_impl(const MasConvDesc* d, const void* x, const float* scale
     if (d->w_layout != MAS_WLAYOUT_K64) MAS_FAIL(MAS_EINVAL, "conv_fwd: bad w_layout %d", d->w_layout);
     {   // the FLOP-carrying shapes (3x3, stride 1, bf16, Cin/Cout multiples of 128) take the stream-scheduled kernel
         const int rc = mas_conv3x3_stream_try(d, x, scale_shift, w_packed, bias, residual, y, reinterpret_cast<hipStream_t>(stream));
+        if (rc != 0) return rc < 0 ? rc : MAS_OK;
+    }
+    {   // plain 1x1 GEMMs (nin_shortcut, AttnBlock q / k / v / proj_out and their data gradients): conv1x1.hip
+        const int rc = mas_conv1x1_try(d, x, w_packed, bias, residual, y, reinterpret_cast<hipStream_t>(stream));
         if (rc != 0) return rc < 0 ? rc : MAS_OK;
     }
     ConvParams p;

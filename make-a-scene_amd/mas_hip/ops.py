@@ -505,6 +505,7 @@ def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ac
 
 _WGRAD_SCRATCH = os.environ.get("MAS_WGRAD_SCRATCH", "1") == "1"
 _wgrad_scratch = {}
+_CONV1X1 = os.environ.get("MAS_CONV1X1", "1") == "1"                 # (read by the library too: conv1x1.hip)
 _WGRAD_PARTIALS = os.environ.get("MAS_WGRAD_PARTIALS", "1") == "1"   # 0: the fp32-atomic commit everywhere (A/B switch)
 _wgrad_partials = {}
 
@@ -616,7 +617,11 @@ class _NormActConv(torch.autograd.Function):
         res = nhwc(residual, cd) if residual is not None else None
         # (needs_input_grad reflects requires_grad of the inputs even under torch.no_grad(); cfg["grad"] is the caller's grad mode)
         need_wgrad = cfg["grad"] and (ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]))
-        if act != ACT_NONE and need_wgrad and _MATERIALIZE and ks == 3 and not ups and _gn_act_ok(cin, x.dtype):
+        # 1x1: the GEMM kernel (conv1x1.hip) has no prologue; one small pass + GEMM beats conv_fwd.hip's fused KS = 1 instance with or
+        # without a weight gradient to share the tensor with (512 -> 1536 @16^2: 6 + 22 us against 52)
+        pointwise = (ks == 1 and stride == 1 and not ups and pt == 0 and pl == 0 and _CONV1X1 and cin % 64 == 0 and cout % 128 == 0
+                     and x.dtype == torch.bfloat16 and cfg["out_dtype"] == torch.bfloat16)
+        if act != ACT_NONE and _MATERIALIZE and ((need_wgrad and ks == 3 and not ups) or pointwise) and _gn_act_ok(cin, x.dtype):
             a = gn_act(x, ss, act)                  # both consumers (this convolution, its weight gradient) run prologue-free on it
             y, ypart, yrows = conv_fwd_raw(a, None, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ACT_NONE, ups,
                                            cfg["out_dtype"], want_stats=True)

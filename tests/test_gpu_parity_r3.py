@@ -384,6 +384,40 @@ def test_gn_act_equals_the_fused_prologue(shape, dtype):
 
 
 # --------------------------------------------------------------------------------------------------------------
+# 6b. 1x1 convolutions on the GEMM kernel (conv1x1.hip)
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 64, 128, 16, 16), (3, 192, 384, 9, 7), (32, 512, 1536, 16, 16), (1, 128, 256, 40, 24), (4, 256, 128, 5, 5)])
+def test_conv1x1_gemm_kernel_vs_cpu_fp32(shape):
+    """nin_shortcut / AttnBlock q,k,v,proj_out (reference models/modules.py:106-108,145-160) as plain GEMMs: forward with bias and
+    residual, the data gradient (transposed weight image) and the weight gradient, against F.conv2d / autograd in fp32 on the CPU.
+    Ragged pixel counts (not a multiple of the 128-pixel tile), 1 / 3 / 8 / 24 channel chunks (odd and even: both LDS stages end the
+    loop), several cout tiles."""
+    from mas_hip import ops
+    dev = _dev()
+    n, cin, cout, h, w = shape
+    g = torch.Generator(device="cpu").manual_seed(cin * 7 + cout)
+    x = torch.randn(n, cin, h, w, generator=g).bfloat16()
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5)
+    b = 0.1 * torch.randn(cout, generator=g)
+    res = torch.randn(n, cout, h, w, generator=g).bfloat16()
+    dy = torch.randn(n, cout, h, w, generator=g).bfloat16()
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = torch.nn.Parameter(wt.to(dev))
+    bd = torch.nn.Parameter(b.to(dev))
+    rd = res.to(dev).contiguous(memory_format=torch.channels_last)
+    y = ops.norm_act_conv(xd, wd, bd, residual=rd, padding=(0, 0, 0, 0))
+    y.backward(dy.to(dev).contiguous(memory_format=torch.channels_last))
+    torch.cuda.synchronize()
+    xr = x.float().requires_grad_(True)
+    wr = wt.bfloat16().float().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br) + res.float()
+    yr.backward(dy.float())
+    assert y.shape == yr.shape and relerr(y.float(), yr) < 1e-2, shape
+    assert relerr(xd.grad.float(), xr.grad) < 1e-2 and relerr(wd.grad, wr.grad) < 2e-3 and relerr(bd.grad, br.grad) < 2e-3, shape
+
+
+# --------------------------------------------------------------------------------------------------------------
 # 7. MAS_WEIGHT_CACHE_CHECK=1: the debugging aid for writes the packed-weight stamp cannot see
 # --------------------------------------------------------------------------------------------------------------
 def test_weight_cache_check_flags_a_write_through_data():
