@@ -158,8 +158,8 @@ int mas_conv_wgrad(const MasConvDesc* d, const void* x, const float* scale_shift
  * dbias [Cout]; acc is zeroed again while it is read, so ONE scratch per stream serves every convolution of a step without fill
  * launches (the caller still owns it).                                                                                              */
 int mas_wgrad_commit(float* acc, float* dw_oihw, float* dbias, int Cout, int Cin, int ks, void* stream);
-/* Deterministic split-K (ABI v3): for the convolutions that carry the FLOPs (mas_conv_wgrad_splits(d) = nsplit > 0: bf16, 3x3, stride 1,
- * Cin % 64 == 0, Cout % 128 == 0) mas_conv_wgrad_partial writes the nsplit partial sums -- part [nsplit][Cout][3][3][Cin] fp32,
+/* Deterministic split-K (ABI v3): for the convolutions that carry the FLOPs (mas_conv_wgrad_splits(d) = nsplit > 0: bf16, stride 1, no
+ * prologue; 3x3 with Cin % 64 == 0, Cout % 128 == 0, or 1x1 with Cin % 128 == 0, Cout % 128 == 0: part is then [nsplit][Cout][ks][ks][Cin]) mas_conv_wgrad_partial writes the nsplit partial sums -- part [nsplit][Cout][3][3][Cin] fp32,
  * part_bias [nsplit][Cout] or NULL, every element exactly once, plain stores, no initialisation required -- and mas_wgrad_reduce adds
  * the slabs in a fixed order into dw_oihw [Cout][Cin][ks][ks] / dbias [Cout]: no atomics, bitwise reproducible run to run.          */
 int mas_conv_wgrad_splits(const MasConvDesc* d);

@@ -167,6 +167,126 @@ __global__ __launch_bounds__(PW_NT, 2) void conv1x1_kernel(PwParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// weight gradient of the same layers:  dW[cout][cin] = sum over pixels of dy[pixel][cout] * a[pixel][cin]  -- a GEMM whose reduction
+// dimension is the OUTER dimension of both NHWC operands.  Both are staged in their natural [pixel][channel] layout (64 pixels x 128
+// channels = 64 rows of 256 B per chunk, by LDS-DMA) and the MFMA fragments come from the LDS transpose read (ds_read_b64_tr_b16;
+// semantics in conv_wgrad.hip), 64-byte blocks XOR-swizzled with (pixel & 3) as in conv_wgrad_dma.hip.  Split-K over the pixel chunks
+// into partial slabs [nsplit][Cout][Cin] that mas_wgrad_reduce adds in a fixed order (no atomics: bitwise reproducible).  Tile 128 couts x
+// 128 cins, 4 waves of 64 x 64; the conv_wgrad_tr_kernel<1, 64> instance it replaces spent 66 us on 512 -> 1536 @16^2 (194 TFLOP/s).
+struct PwWgradParams {
+    const unsigned char* dy; const unsigned char* x; float* part; float* part_bias;   // part_bias [nsplit][Cout] or NULL
+    int M, Cout, Cin, n_co_t, n_ci_t, nsplit, n_chunks;
+};
+
+__global__ __launch_bounds__(PW_NT, 2) void wgrad1x1_kernel(PwWgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)pw_smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31, G16 = (lane >> 4) & 1, sl = lane & 15;
+    const int wave_co = wave & 1, wave_ci = wave >> 1;
+    int bid = blockIdx.x;
+    const int split = bid % p.nsplit; bid /= p.nsplit;
+    const int ci_t = bid % p.n_ci_t, co_t = bid / p.n_ci_t;
+    const int co0 = co_t * 128, ci0 = ci_t * 128;
+
+    const pw_i32x4 rs_dy = pw_rsrc(p.dy, (unsigned)((size_t)p.M * p.Cout * 2));
+    const pw_i32x4 rs_x = pw_rsrc(p.x, (unsigned)((size_t)p.M * p.Cin * 2));
+
+    // ---- DMA plan: a chunk tile = 16 pieces of 4 pixel rows x 256 B; wave w moves pieces 4 w .. 4 w + 3 of both tensors.  Lane: pixel
+    //      lane >> 4 of the piece, physical 64-byte block (lane >> 2) & 3 holding LOGICAL block ^ (pixel & 3), 16-byte slot lane & 3
+    const int lp = lane >> 4;
+    const int lsrc = ((((lane >> 2) & 3) ^ lp) << 6) + ((lane & 3) << 4);
+    auto issue = [&](int c, int stage) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pix = c * 64 + (wave * 4 + j) * 4 + lp;
+            const bool ok = pix < p.M;
+            const unsigned dst = lds0 + stage * PW_STAGE + (wave * 4 + j) * 1024;
+            pw_dma16(rs_dy, __builtin_amdgcn_readfirstlane(dst), ok ? (pix * p.Cout + co0) * 2 + lsrc : PW_OOB);
+            pw_dma16(rs_x, __builtin_amdgcn_readfirstlane(dst + PW_TILE), ok ? (pix * p.Cin + ci0) * 2 + lsrc : PW_OOB);
+        }
+    };
+    // ---- transpose-read lane addressing: pixel 8 g + (sl >> 2) (+ 4 for the second read) of a 16-pixel k-step, channels
+    //      16 G16 + 4 (sl & 3) ..+3 of a 32-channel group; the group's 64-byte block ^ (pixel & 3)
+    const int t4 = sl >> 2;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a_off[i] = (8 * g + t4) * 256 + (((wave_co * 2 + i) ^ t4) << 6) + 32 * G16 + 8 * (sl & 3);
+        b_off[i] = PW_TILE + (8 * g + t4) * 256 + (((wave_ci * 2 + i) ^ t4) << 6) + 32 * G16 + 8 * (sl & 3);
+    }
+    auto tr = [](const unsigned char* a0) {
+        typedef __attribute__((ext_vector_type(4))) short s16x4_;
+        const s16x4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_*)a0);
+        const s16x4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_*)(a0 + 4 * 256));
+        const __attribute__((ext_vector_type(8))) short v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return *reinterpret_cast<const bf16x8*>(&v);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // bias gradient = dy^T x 1: one more MFMA per k-step and cout tile against an all-ones operand, by the waves of the first cin tile
+    const bool do_bias = p.part_bias != nullptr && ci_t == 0 && wave_ci == 0;     // (wave-uniform)
+    f32x16 accb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.0f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+
+    const int n_mine = (p.n_chunks - split + p.nsplit - 1) / p.nsplit;          // chunks split, split + nsplit, ...
+    if (n_mine > 0) issue(split, 0);
+    auto chunk = [&](int it, auto stage_c) {
+        constexpr int ST = decltype(stage_c)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + 1 < n_mine) issue(split + (it + 1) * p.nsplit, ST ^ 1);
+        const unsigned char* sb = pw_smem + ST * PW_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 afr[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { afr[i] = tr(sb + a_off[i] + ks * 16 * 256); bfr[i] = tr(sb + b_off[i] + ks * 16 * 256); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma16(acc[i][j], afr[i], bfr[j]);               // D[cout][cin]
+            if (do_bias) { mma16(accb[0], afr[0], ones); mma16(accb[1], afr[1], ones); }   // every column = sum over the 16 pixels of dy[.][cout]
+        }
+    };
+    for (int it = 0; it < n_mine; it += 2) {
+        chunk(it, std::integral_constant<int, 0>{});
+        if (it + 1 < n_mine) chunk(it + 1, std::integral_constant<int, 1>{});
+    }
+    float* pw = p.part + (size_t)split * ((size_t)p.Cout * p.Cin);               // this work-group's slab: plain coalesced stores
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wave_co * 64 + i * 32 + acc_row(lane, r);
+                const int ci = ci0 + wave_ci * 64 + j * 32 + l31;
+                pw[(size_t)co * p.Cin + ci] = acc[i][j][r];
+            }
+    if (do_bias && l31 == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p.part_bias[(size_t)split * p.Cout + co0 + wave_co * 64 + i * 32 + acc_row(lane, r)] = accb[i][r];
+    }
+}
+
 }  // namespace
 
 // Returns 1 if the convolution is a plain 1x1 GEMM this kernel takes (and the launch was made), 0 if the caller should use conv_fwd.hip.
@@ -190,5 +310,39 @@ int mas_conv1x1_try(const MasConvDesc* d, const void* x, const void* w_packed, c
     const long long grid = (M + 127) / 128 * p.n_nt;
     hipLaunchKernelGGL(conv1x1_kernel, dim3((unsigned)grid), dim3(PW_NT), PW_LDS, s, p);
     MAS_CHECK_LAUNCH("conv1x1");
+    return 1;
+}
+
+static bool pw_wgrad_setup(const MasConvDesc* d, PwWgradParams& p) {
+    static const int on = mas_env_int("MAS_CONV1X1", 1);
+    if (!on) return false;
+    if (d->ks != 1 || d->stride != 1 || d->upsample || d->act != MAS_ACT_NONE || d->pad_top || d->pad_left) return false;
+    if (d->in_dtype != MAS_BF16 || d->Cin % 128 || d->Cout % 128 || d->Ho != d->H || d->Wo != d->W) return false;
+    const long long M = (long long)d->N * d->H * d->W;
+    if (M * d->Cin * 2 >= 0x7fffffffLL || M * d->Cout * 2 >= 0x7fffffffLL) return false;
+    p.M = (int)M; p.Cout = d->Cout; p.Cin = d->Cin; p.n_co_t = d->Cout / 128; p.n_ci_t = d->Cin / 128;
+    p.n_chunks = (int)((M + 63) / 64);
+    const int tiles = p.n_co_t * p.n_ci_t;
+    int ns = mas_cdiv(2 * mas_cu_budget(), tiles);                               // two work-groups per CU
+    if (ns > p.n_chunks / 2) ns = p.n_chunks / 2;                                 // at least two chunks per work-group
+    if (ns > 256) ns = 256;
+    if (ns < 1) ns = 1;
+    p.nsplit = ns;
+    return true;
+}
+
+// split-K factor of the 1x1 weight-gradient kernel for this convolution, 0 when it does not take it (mas_conv_wgrad_splits forwards here)
+int mas_wgrad1x1_splits(const MasConvDesc* d) {
+    PwWgradParams p;
+    return pw_wgrad_setup(d, p) ? p.nsplit : 0;
+}
+
+// part [nsplit][Cout][Cin] fp32 and (non-NULL) part_bias [nsplit][Cout], every element written once (see mas_conv_wgrad_partial)
+int mas_wgrad1x1_partial(const MasConvDesc* d, const void* x, const void* dy, float* part, float* part_bias, hipStream_t s) {
+    PwWgradParams p;
+    if (!pw_wgrad_setup(d, p)) return 0;
+    p.dy = (const unsigned char*)dy; p.x = (const unsigned char*)x; p.part = part; p.part_bias = part_bias;
+    hipLaunchKernelGGL(wgrad1x1_kernel, dim3((unsigned)(p.n_co_t * p.n_ci_t * p.nsplit)), dim3(PW_NT), PW_LDS, s, p);
+    MAS_CHECK_LAUNCH("wgrad1x1");
     return 1;
 }

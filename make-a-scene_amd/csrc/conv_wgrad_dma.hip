@@ -564,9 +564,14 @@ int mas_conv_wgrad_dma_try(const MasConvDesc* d, const void* x, const float* sca
 
 // Split-K factor of the LDS-DMA kernel for this convolution (= slabs of the partial table mas_conv_wgrad_partial writes), or 0 when the
 // shape does not take that kernel (mas_conv_wgrad with its atomic commit is the path then).
+int mas_wgrad1x1_splits(const MasConvDesc* d);                                   // conv1x1.hip
+int mas_wgrad1x1_partial(const MasConvDesc* d, const void* x, const void* dy, float* part, float* part_bias, hipStream_t s);
+
 extern "C" int mas_conv_wgrad_splits(const MasConvDesc* d) {
     DmaWgradParams p;
-    if (!d || !dma_setup(d, p)) return 0;
+    if (!d) return 0;
+    if (d->ks == 1) return mas_wgrad1x1_splits(d);
+    if (!dma_setup(d, p)) return 0;
     return p.nsplit;
 }
 
@@ -578,6 +583,11 @@ extern "C" int mas_conv_wgrad_partial(const MasConvDesc* d, const void* x, const
     MAS_ENTER();
     if (!d || !x || !dy || !part) MAS_FAIL(MAS_EINVAL, "conv_wgrad_partial: null argument");
     if (d->act != MAS_ACT_NONE && !scale_shift) MAS_FAIL(MAS_EINVAL, "conv_wgrad_partial: act prologue needs scale_shift");
+    if (d->ks == 1) {                            // plain GEMM (conv1x1.hip)
+        const int rc = mas_wgrad1x1_partial(d, x, dy, part, part_bias, reinterpret_cast<hipStream_t>(stream));
+        if (rc == 0) MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad_partial: this 1x1 convolution does not take the split-K partial path (mas_conv_wgrad_splits == 0)");
+        return rc < 0 ? rc : MAS_OK;
+    }
     DmaWgradParams p;
     if (!dma_setup(d, p)) MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad_partial: this convolution does not take the split-K partial path (mas_conv_wgrad_splits == 0)");
     p.x = (const unsigned char*)x; p.ss = scale_shift; p.dy = (const unsigned char*)dy; p.dw = nullptr; p.dbias = nullptr;

@@ -462,12 +462,13 @@ def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ac
         # into the OIHW gradient.  No fp32 atomics (they cost 45-60 us per launch and made the sums order-dependent): the weight
         # gradient of these layers is bitwise reproducible run to run.
         need = ns * (nw + cout)
+        own_bias = want_bias
         ws = _wgrad_partials.get(key)
         if ws is None or ws.numel() < need:
             ws = _wgrad_partials[key] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=x.device)
         dwo = torch.empty((cout, cin, ks, ks), dtype=torch.float32, device=x.device)
-        db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
-        pb = C.c_void_p(ws.data_ptr() + 4 * ns * nw) if want_bias else None
+        db = torch.empty(cout, dtype=torch.float32, device=x.device) if own_bias else None
+        pb = C.c_void_p(ws.data_ptr() + 4 * ns * nw) if own_bias else None
 
         def launch():
             check(lib().mas_conv_wgrad_partial(C.byref(d), _ptr(x), _ptr(ss), _ptr(dy), _ptr(ws), pb, _stream()), "conv_wgrad_partial")
