@@ -1,0 +1,194 @@
+// The RGB-edge layers of the VQ models: conv_in (3 -> 128, reference models/modules.py:219) and conv_out (128 -> 3, :345), whose 3-channel
+// side is zero-padded to one 16-byte slot (8 channels) by ops.norm_act_conv.  Their arithmetic is negligible (2 x 9 x 8 x 128 FLOP per
+// pixel) but each streams a 128-channel 256^2 tensor, and the general kernels treat the 8-channel side as a full 64-channel chunk /
+// 128-cout tile: 8-16x the MFMA work, 0.32-0.59 ms per launch where the tensor's HBM time is 0.1 ms (profiles/r03_conv_shapes.txt).
+//
+// wgrad_thin_kernel -- both weight gradients as ONE GEMM shape:  D[(tap, cs)][cb] = sum over pixels of S[pixel + sgn (tap - 1)][cs] * B[pixel][cb]
+//   B = the 128-channel tensor (conv_out: the activated input, conv_in: dy), S = the 8-channel one (conv_out: dy, conv_in: x), sgn = -1 / +1.
+//   K = pixels (outer dimension of both operands): fragments by the LDS transpose read (ds_read_b64_tr_b16, semantics in conv_wgrad.hip).
+//   The trick for the thin side: a transpose-read source lane supplies 4 consecutive channels of ONE pixel at an ARBITRARY address, so the
+//   72 rows (tap, cs) of the A operand are read straight out of an (4+2) x (16+2)-pixel halo tile of S -- row quad q of a 16-lane group
+//   points at tap 4 i + 2 G16 + (q >> 1), channels 4 (q & 1) ..+3, shifted by the tap: no im2col, no padding of S to 128 channels.
+//   Tile = 4 x 16 pixels of B (16 KiB, LDS-DMA, 64-byte blocks ^ (pixel & 3)), 4 waves = the 4 32-channel groups of B, 3 accumulator
+//   tiles (96 rows, 72 used) per wave; split-K over tiles into slabs that mas_wgrad_reduce adds in a fixed order; the bias gradient is
+//   one more MFMA per k-step against an all-ones operand.  HBM-bound by construction (12 MFMAs per 16 KiB of B).
+#include "mas_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) int th_i32x4;
+typedef __attribute__((ext_vector_type(4))) short th_s16x4;
+__device__ __forceinline__ void th_dma16(th_i32x4 rs, unsigned lds, int vo) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(vo), "s"(rs) : "memory", "m0");
+}
+__device__ __forceinline__ th_i32x4 th_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    th_i32x4 r = {(int)(unsigned)a, (int)(unsigned)(a >> 32), (int)bytes, 0x00020000};
+    r[0] = __builtin_amdgcn_readfirstlane(r[0]); r[1] = __builtin_amdgcn_readfirstlane(r[1]);
+    r[2] = __builtin_amdgcn_readfirstlane(r[2]); r[3] = __builtin_amdgcn_readfirstlane(r[3]);
+    return r;
+}
+__device__ __forceinline__ bf16x8 th_tr(const unsigned char* a0, const unsigned char* a1) {
+    const th_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) th_s16x4*)a0);
+    const th_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) th_s16x4*)a1);
+    const __attribute__((ext_vector_type(8))) short v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return *reinterpret_cast<const bf16x8*>(&v);
+}
+
+struct ThinWgradParams {
+    const unsigned char* big; const unsigned char* small; float* part; float* part_bias;
+    int N, H, W, sgn;                          // S pixel = B pixel + sgn * (tap - 1)
+    int col_stride, tap_stride, cs_stride;     // slab index of D[(tap, cs)][cb] = cb * col_stride + tap * tap_stride + cs * cs_stride
+    int bias_small;                            // the bias gradient sums S (conv_out: dy is the thin tensor) / B (conv_in)
+    int tiles_h, tiles_w, n_tiles, nsplit;
+};
+
+constexpr int TH_NT = 256, TH_TH = 4, TH_TW = 16;
+constexpr int TH_BIG = 64 * 256;               // 64 pixels x 128 channels
+constexpr int TH_SMALL = 2048;                 // (4 + 2) x (16 + 2) = 108 pixels x 16 B in two 1-KiB DMA pieces
+constexpr int TH_STAGE = TH_BIG + TH_SMALL;
+constexpr int TH_LDS = 2 * TH_STAGE;
+constexpr int TH_OOB = (int)0x80000000;
+constexpr int TH_SLAB = 9 * 8 * 128;
+
+__global__ __launch_bounds__(TH_NT, 2) void wgrad_thin_kernel(ThinWgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char th_smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)th_smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31, G16 = (lane >> 4) & 1, sl = lane & 15;
+    const int split = blockIdx.x;
+    const th_i32x4 rs_b = th_rsrc(p.big, (unsigned)((size_t)p.N * p.H * p.W * 256));
+    const th_i32x4 rs_s = th_rsrc(p.small, (unsigned)((size_t)p.N * p.H * p.W * 16));
+
+    // ---- DMA plan.  B: 16 pieces of 4 pixels x 256 B, wave w moves pieces 4 w .. 4 w + 3 = tile row w; piece 4 w + j holds columns
+    //      4 j .. 4 j + 3; lane: column 4 j + (lane >> 4), physical 64-byte block (lane >> 2) & 3 = logical block ^ (column & 3).
+    //      S: waves 0 / 1 move halo pixels 64 wave + lane (108 of 128 slots live), 16 B each, unswizzled.
+    const int lp = lane >> 4;
+    const int lsrc = ((((lane >> 2) & 3) ^ lp) << 6) + ((lane & 3) << 4);
+    const int hp = wave * 64 + lane, hr = hp / 18, hc = hp - hr * 18;            // (waves 0, 1 only)
+    auto issue = [&](int t, int stage) {
+        const int tw_i = t % p.tiles_w; const int q = t / p.tiles_w;
+        const int th_i = q % p.tiles_h, n = q / p.tiles_h;
+        const int h0 = th_i * TH_TH, w0 = tw_i * TH_TW;
+        const int ih = h0 + wave;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iw = w0 + 4 * j + lp;
+            const bool ok = ih < p.H && iw < p.W;
+            th_dma16(rs_b, __builtin_amdgcn_readfirstlane(lds0 + stage * TH_STAGE + (wave * 4 + j) * 1024), ok ? ((n * p.H + ih) * p.W + iw) * 256 + lsrc : TH_OOB);
+        }
+        if (wave < 2) {
+            const int sh = h0 + hr - 1, sw = w0 + hc - 1;
+            const bool ok = hp < 108 && sh >= 0 && sh < p.H && sw >= 0 && sw < p.W;
+            th_dma16(rs_s, __builtin_amdgcn_readfirstlane(lds0 + stage * TH_STAGE + TH_BIG + wave * 1024), ok ? ((n * p.H + sh) * p.W + sw) * 16 : TH_OOB);
+        }
+    };
+
+    // ---- fragment addressing.  A (rows (tap, cs) of row tile i): source lane -> pixel column 8 g + (sl >> 2) (+ 4 for the second read) of
+    //      tile row r, row quad q = sl & 3 -> tap 4 i + 2 G16 + (q >> 1), channels 4 (q & 1) ..+3; halo pixel (r + 1 + sgn (kh - 1),
+    //      column + 1 + sgn (kw - 1)).  Taps >= 9 (rows 72..95) read tap 8's data; their rows are never stored.
+    const int t4 = sl >> 2, qd = sl & 3;
+    int a_off[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int tap = 4 * i + 2 * G16 + (qd >> 1);
+        if (tap > 8) tap = 8;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        a_off[i] = TH_BIG + ((1 + p.sgn * (kh - 1)) * 18 + (8 * g + t4 + 1 + p.sgn * (kw - 1))) * 16 + (qd & 1) * 8;
+    }
+    // B (columns = this wave's 32-channel group): pixel 16 r + 8 g + t4 (+ 4), channels 16 G16 + 4 (sl & 3) ..+3, block wave ^ t4
+    const int b_off = (8 * g + t4) * 256 + ((wave ^ t4) << 6) + 32 * G16 + 8 * (sl & 3);
+
+    f32x16 acc[3], accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; acc[2][r] = 0.0f; accb[r] = 0.0f; }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+    const bool bias_s = p.part_bias != nullptr && p.bias_small && wave == 0;     // (wave-uniform)
+    const bool bias_b = p.part_bias != nullptr && !p.bias_small;
+
+    const int n_mine = (p.n_tiles - split + p.nsplit - 1) / p.nsplit;           // tiles split, split + nsplit, ...
+    if (n_mine > 0) issue(split, 0);
+    auto tile = [&](int it, auto stage_c) {
+        constexpr int ST = decltype(stage_c)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + 1 < n_mine) issue(split + (it + 1) * p.nsplit, ST ^ 1);
+        const unsigned char* sb = th_smem + ST * TH_STAGE;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                            // k-step = tile row r (16 pixels)
+            const unsigned char* b0 = sb + b_off + r * 16 * 256;
+            const bf16x8 bfr = th_tr(b0, b0 + 4 * 256);
+            bf16x8 afr[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { const unsigned char* a0 = sb + a_off[i] + r * 18 * 16; afr[i] = th_tr(a0, a0 + 4 * 16); }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) mma16(acc[i], afr[i], bfr);
+            if (bias_s) mma16(accb, afr[1], ones);                               // rows 32..39 = centre tap: sum over the tile of S[pixel][cs]
+            if (bias_b) mma16(accb, ones, bfr);                                  // every row = sum over the tile of B[pixel][cb]
+        }
+    };
+    for (int it = 0; it < n_mine; it += 2) {
+        tile(it, std::integral_constant<int, 0>{});
+        if (it + 1 < n_mine) tile(it + 1, std::integral_constant<int, 1>{});
+    }
+
+    float* pw = p.part + (size_t)split * TH_SLAB;
+    const int cb = wave * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * i + acc_row(lane, r);
+            const int tap = row >> 3, cs = row & 7;
+            if (tap < 9) pw[cb * p.col_stride + tap * p.tap_stride + cs * p.cs_stride] = acc[i][r];
+        }
+    if (bias_s && l31 == 0) {                                                    // rows 0..7 of row tile 1: lanes 0 (rows 0-3) and 32 (rows 4-7)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p.part_bias[(size_t)split * 8 + 4 * g + r] = accb[r];
+    }
+    if (bias_b && g == 0) p.part_bias[(size_t)split * 128 + cb] = accb[0];     // row 0
+}
+
+}  // namespace
+
+static bool thin_wgrad_setup(const MasConvDesc* d, ThinWgradParams& p, bool& big_is_x) {
+    static const int on = mas_env_int("MAS_CONV_THIN", 1);
+    if (!on) return false;
+    if (d->ks != 3 || d->stride != 1 || d->upsample || d->act != MAS_ACT_NONE || d->pad_top != 1 || d->pad_left != 1) return false;
+    if (d->in_dtype != MAS_BF16 || d->Ho != d->H || d->Wo != d->W) return false;
+    if (!((d->Cin == 128 && d->Cout == 8) || (d->Cin == 8 && d->Cout == 128))) return false;
+    if ((long long)d->N * d->H * d->W * 256 >= 0x7fffffffLL) return false;
+    big_is_x = d->Cin == 128;
+    p.N = d->N; p.H = d->H; p.W = d->W;
+    p.tiles_h = mas_cdiv(d->H, TH_TH); p.tiles_w = mas_cdiv(d->W, TH_TW);
+    p.n_tiles = d->N * p.tiles_h * p.tiles_w;
+    if (big_is_x) {      // dW[co = cs][tap][ci = cb]; dy pixel = x pixel - (tap - 1); the bias gradient sums dy = S
+        p.sgn = -1; p.cs_stride = 9 * 128; p.tap_stride = 128; p.col_stride = 1; p.bias_small = 1;
+    } else {             // dW[co = cb][tap][ci = cs]; x pixel = dy pixel + (tap - 1); the bias gradient sums dy = B
+        p.sgn = 1; p.col_stride = 72; p.tap_stride = 8; p.cs_stride = 1; p.bias_small = 0;
+    }
+    int ns = 2 * mas_cu_budget();
+    if (ns > p.n_tiles / 4) ns = p.n_tiles / 4;
+    if (ns < 1) ns = 1;
+    p.nsplit = ns;
+    return true;
+}
+
+int mas_wgrad_thin_splits(const MasConvDesc* d) {
+    ThinWgradParams p; bool bx;
+    return thin_wgrad_setup(d, p, bx) ? p.nsplit : 0;
+}
+
+// part [nsplit][Cout][3][3][Cin], part_bias [nsplit][Cout] or NULL (see mas_conv_wgrad_partial)
+int mas_wgrad_thin_partial(const MasConvDesc* d, const void* x, const void* dy, float* part, float* part_bias, hipStream_t s) {
+    ThinWgradParams p; bool bx;
+    if (!thin_wgrad_setup(d, p, bx)) return 0;
+    p.big = (const unsigned char*)(bx ? x : dy); p.small = (const unsigned char*)(bx ? dy : x); p.part = part; p.part_bias = part_bias;
+    hipLaunchKernelGGL(wgrad_thin_kernel, dim3((unsigned)p.nsplit), dim3(TH_NT), TH_LDS, s, p);
+    MAS_CHECK_LAUNCH("wgrad_thin");
+    return 1;
+}

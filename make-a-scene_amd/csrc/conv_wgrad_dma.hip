@@ -567,11 +567,14 @@ int mas_conv_wgrad_dma_try(const MasConvDesc* d, const void* x, const float* sca
 int mas_wgrad1x1_splits(const MasConvDesc* d);                                   // conv1x1.hip
 int mas_wgrad1x1_partial(const MasConvDesc* d, const void* x, const void* dy, float* part, float* part_bias, hipStream_t s);
 
+int mas_wgrad_thin_splits(const MasConvDesc* d);                                  // conv_thin.hip
+int mas_wgrad_thin_partial(const MasConvDesc* d, const void* x, const void* dy, float* part, float* part_bias, hipStream_t s);
+
 extern "C" int mas_conv_wgrad_splits(const MasConvDesc* d) {
     DmaWgradParams p;
     if (!d) return 0;
     if (d->ks == 1) return mas_wgrad1x1_splits(d);
-    if (!dma_setup(d, p)) return 0;
+    if (!dma_setup(d, p)) return mas_wgrad_thin_splits(d);
     return p.nsplit;
 }
 
@@ -589,6 +592,10 @@ extern "C" int mas_conv_wgrad_partial(const MasConvDesc* d, const void* x, const
         return rc < 0 ? rc : MAS_OK;
     }
     DmaWgradParams p;
+    if (!dma_setup(d, p)) {                      // the RGB-edge layers (8 <-> 128 channels): conv_thin.hip
+        const int rc = mas_wgrad_thin_partial(d, x, dy, part, part_bias, reinterpret_cast<hipStream_t>(stream));
+        if (rc != 0) return rc < 0 ? rc : MAS_OK;
+    }
     if (!dma_setup(d, p)) MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad_partial: this convolution does not take the split-K partial path (mas_conv_wgrad_splits == 0)");
     p.x = (const unsigned char*)x; p.ss = scale_shift; p.dy = (const unsigned char*)dy; p.dw = nullptr; p.dbias = nullptr;
     p.part = part; p.part_bias = part_bias;

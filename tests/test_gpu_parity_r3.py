@@ -418,6 +418,40 @@ def test_conv1x1_gemm_kernel_vs_cpu_fp32(shape):
 
 
 # --------------------------------------------------------------------------------------------------------------
+# 6c. the RGB-edge layers' weight gradients on the thin transpose-read kernel (conv_thin.hip)
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 128, 8, 10, 24), (2, 8, 128, 10, 24), (3, 128, 8, 32, 32), (3, 8, 128, 33, 17), (32, 8, 128, 64, 64)])
+def test_thin_wgrad_kernel_vs_cpu_fp32(shape):
+    """conv_out (128 -> 3, zero-padded to 8) and conv_in (3 -> 8 -> 128) weight / bias gradients (autograd of reference
+    models/modules.py:219,345): ragged tiles in both directions (the 4 x 16-pixel tile against 10 x 24 / 33 x 17 maps), image borders
+    (the zero padding of the convolution = out-of-range halo pixels), several tiles per work-group; against autograd of F.conv2d in
+    fp32 on the CPU, and bitwise run to run."""
+    import ctypes as C
+    import mas_hip
+    from mas_hip import ops, ACT_NONE
+    dev = _dev()
+    n, cin, cout, h, w = shape
+    g = torch.Generator(device="cpu").manual_seed(cin + 3 * h)
+    x = torch.randn(n, cin, h, w, generator=g).bfloat16()
+    dy = (0.5 * torch.randn(n, cout, h, w, generator=g)).bfloat16()
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    d = ops._desc(n, h, w, cin, h, w, cout, 3, 1, 1, 1, torch.bfloat16, torch.bfloat16, ACT_NONE, False)
+    assert mas_hip.lib().mas_conv_wgrad_splits(C.byref(d)) > 0, "this shape must take the thin split-K path"
+    outs = []
+    for _ in range(2):
+        for ws in ops._wgrad_partials.values():
+            ws.fill_(float("nan"))
+        dw, db = ops.conv_wgrad_raw(cl(x), None, cl(dy), n, h, w, cin, h, w, cout, 3, 1, 1, 1, ACT_NONE, False, True)
+        torch.cuda.synchronize()
+        outs.append((dw.clone(), db.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    wr = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    F.conv2d(x.float(), wr, None, padding=1).backward(dy.float())
+    assert outs[0][0].shape == wr.shape
+    assert relerr(outs[0][0], wr.grad) < 2e-3 and relerr(outs[0][1], dy.float().sum((0, 2, 3))) < 2e-3, shape
+
+
+# --------------------------------------------------------------------------------------------------------------
 # 7. MAS_WEIGHT_CACHE_CHECK=1: the debugging aid for writes the packed-weight stamp cannot see
 # --------------------------------------------------------------------------------------------------------------
 def test_weight_cache_check_flags_a_write_through_data():
