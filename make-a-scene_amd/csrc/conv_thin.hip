@@ -153,6 +153,123 @@ __global__ __launch_bounds__(TH_NT, 2) void wgrad_thin_kernel(ThinWgradParams p)
     if (bias_b && g == 0) p.part_bias[(size_t)split * 128 + cb] = accb[0];     // row 0
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_thin_fwd_kernel -- 3x3 / stride 1 / pad 1, 8 -> 128 channels (conv_in's forward, conv_out's data gradient):
+//   y[pixel][co] = sum over (tap, ci) of W[co][tap][ci] * x[pixel + tap - 1][ci] + bias[co]
+// One GEMM with K = 9 taps x 8 channels = 72 (5 k-steps of 16, the tenth tap zero): the A operand (all 128 couts x 80 k = 20 fragments,
+// 80 VGPRs) is read ONCE per wave from the K64 weight image conv_fwd.hip uses (its 64-channel rows hold 8 live channels in logical slot
+// 0) and stays in registers; a B fragment is one 16-byte LDS read of the (8 + 2) x (32 + 2)-pixel halo tile of x (half-wave g takes tap
+// 2 kk + g).  20 MFMAs per 32 pixels against 9 x 64-channel chunks x 4 cout tiles = 144 in conv_fwd.hip.  Store-bound: the kernel's
+// job is to write 256 B per pixel.  Persistent work-groups, halo tiles double-buffered by LDS-DMA.
+struct ThinFwdParams {
+    const unsigned char* x; const unsigned char* w; const float* bias; unsigned char* y;
+    int N, H, W, rows_pad, tiles_h, tiles_w, n_tiles;
+};
+constexpr int TF_TH = 8, TF_TW = 32, TF_HW = TF_TW + 2, TF_HALO = (TF_TH + 2) * TF_HW;   // 340 pixels x 16 B
+constexpr int TF_STAGE = 6 * 1024;             // 6 DMA pieces of 64 pixels
+constexpr int TF_LDS = 2 * TF_STAGE;
+
+__global__ __launch_bounds__(TH_NT, 2) void conv_thin_fwd_kernel(ThinFwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char th_smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)th_smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31;
+    const th_i32x4 rs_x = th_rsrc(p.x, (unsigned)((size_t)p.N * p.H * p.W * 16));
+    const unsigned out_bytes = (unsigned)((size_t)p.N * p.H * p.W * 256);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(p.bias ? (void*)p.bias : (void*)p.y, 0, p.bias ? 512u : 0u, 0x00020000);
+
+    // ---- weights: fragment (cout tile i, k-step kk): row 32 i + l31, tap 2 kk + g, channels 0..7 = logical slot 0 of the image row
+    bf16x8 afr[4][5];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) {
+            const int row = 32 * i + l31, tap = 2 * kk + g;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (tap < 9) v = *reinterpret_cast<const u32x4*>(p.w + ((size_t)tap * p.rows_pad + row) * 128 + (((row >> 1) & 7) << 4));
+            afr[i][kk] = *reinterpret_cast<const bf16x8*>(&v);
+        }
+    // ---- B fragment addresses: pixel (tile row 2 wave + j, column l31), tap 2 kk + g -> halo pixel (row + kh, column + kw)
+    int b_off[5];
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) {
+        int tap = 2 * kk + g;
+        if (tap > 8) tap = 8;                                                    // (multiplied by zero weights)
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        b_off[kk] = ((2 * wave + kh) * TF_HW + l31 + kw) * 16;
+    }
+    auto issue = [&](int t, int stage) {
+        const int tw_i = t % p.tiles_w; const int q = t / p.tiles_w;
+        const int th_i = q % p.tiles_h, n = q / p.tiles_h;
+        const int h0 = th_i * TF_TH - 1, w0 = tw_i * TF_TW - 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int piece = wave + 4 * j;
+            if (piece < 6) {
+                const int hp = piece * 64 + lane, hr = hp / TF_HW, hc = hp - hr * TF_HW;
+                const int ih = h0 + hr, iw = w0 + hc;
+                const bool ok = hp < TF_HALO && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                th_dma16(rs_x, __builtin_amdgcn_readfirstlane(lds0 + stage * TF_STAGE + piece * 1024), ok ? ((n * p.H + ih) * p.W + iw) * 16 : TH_OOB);
+            }
+        }
+    };
+    const int first = blockIdx.x, stride = gridDim.x;
+    if (first < p.n_tiles) issue(first, 0);
+    auto tile = [&](int t, auto stage_c) {
+        constexpr int ST = decltype(stage_c)::value;
+        // this tile's halo pieces have landed; the 16 stores of the previous tile are YOUNGER than them and stay in flight (in-order retirement)
+        if (t == first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + stride < p.n_tiles) issue(t + stride, ST ^ 1);
+        const unsigned char* sb = th_smem + ST * TF_STAGE;
+        const int tw_i = t % p.tiles_w; const int q = t / p.tiles_w;
+        const int th_i = q % p.tiles_h, n = q / p.tiles_h;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x16 acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < 5; ++kk) {
+                const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(sb + b_off[kk] + j * TF_HW * 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mma16(acc[i], afr[i][kk], bfr);      // D[cout][pixel]
+            }
+            const int oh = th_i * TF_TH + 2 * wave + j, ow = tw_i * TF_TW + l31;
+            const int obase = (oh < p.H && ow < p.W) ? (((n * p.H + oh) * p.W + ow) * 128 + 8 * g) * 2 : TH_OOB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int qp = 0; qp < 2; ++qp) {
+                    const int cb = (32 * i + 16 * qp + 8 * g) * 4;
+                    const f32x4 b0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, cb, 0, 0));
+                    const f32x4 b1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, cb + 16, 0, 0));
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float qa = acc[i][(2 * qp) * 4 + e], qb = acc[i][(2 * qp + 1) * 4 + e];
+                        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(qa), __float_as_uint(qb), false, false);
+                        v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
+                    }
+                    u32x4 o;
+                    bf16_t* ob = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ob[e] = (bf16_t)(v[e] + b0[e]); ob[4 + e] = (bf16_t)(v[4 + e] + b1[e]); }
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, obase + (32 * i + 16 * qp) * 2, 0, 0);
+                }
+        }
+    };
+    for (int t = first; t < p.n_tiles; t += 2 * stride) {
+        tile(t, std::integral_constant<int, 0>{});
+        if (t + stride < p.n_tiles) tile(t + stride, std::integral_constant<int, 1>{});
+    }
+}
+
 }  // namespace
 
 static bool thin_wgrad_setup(const MasConvDesc* d, ThinWgradParams& p, bool& big_is_x) {
@@ -190,5 +307,24 @@ int mas_wgrad_thin_partial(const MasConvDesc* d, const void* x, const void* dy, 
     p.big = (const unsigned char*)(bx ? x : dy); p.small = (const unsigned char*)(bx ? dy : x); p.part = part; p.part_bias = part_bias;
     hipLaunchKernelGGL(wgrad_thin_kernel, dim3((unsigned)p.nsplit), dim3(TH_NT), TH_LDS, s, p);
     MAS_CHECK_LAUNCH("wgrad_thin");
+    return 1;
+}
+
+// 3x3 / stride 1 / pad 1 / bf16, 8 -> 128 channels, no prologue, no residual: returns 1 if launched, 0 if conv_fwd.hip should take it
+int mas_conv_thin_fwd_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s) {
+    static const int on = mas_env_int("MAS_CONV_THIN", 1);
+    if (!on || residual) return 0;
+    if (d->ks != 3 || d->stride != 1 || d->upsample || d->act != MAS_ACT_NONE || d->pad_top != 1 || d->pad_left != 1) return 0;
+    if (d->in_dtype != MAS_BF16 || d->out_dtype != MAS_BF16 || d->w_layout != MAS_WLAYOUT_K64) return 0;
+    if (d->Cin != 8 || d->Cout != 128 || d->Ho != d->H || d->Wo != d->W) return 0;
+    if ((long long)d->N * d->H * d->W * 256 >= 0x7fffffffLL) return 0;
+    ThinFwdParams p;
+    p.x = (const unsigned char*)x; p.w = (const unsigned char*)w_packed; p.bias = bias; p.y = (unsigned char*)y;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.rows_pad = 128;
+    p.tiles_h = mas_cdiv(d->H, TF_TH); p.tiles_w = mas_cdiv(d->W, TF_TW); p.n_tiles = d->N * p.tiles_h * p.tiles_w;
+    int grid = 8 * mas_num_cus();                                                // two resident work-groups per CU, four rounds
+    if (grid > p.n_tiles) grid = p.n_tiles;
+    hipLaunchKernelGGL(conv_thin_fwd_kernel, dim3((unsigned)grid), dim3(TH_NT), TF_LDS, s, p);
+    MAS_CHECK_LAUNCH("conv_thin_fwd");
     return 1;
 }

@@ -451,6 +451,47 @@ def test_thin_wgrad_kernel_vs_cpu_fp32(shape):
     assert relerr(outs[0][0], wr.grad) < 2e-3 and relerr(outs[0][1], dy.float().sum((0, 2, 3))) < 2e-3, shape
 
 
+@pytest.mark.parametrize("shape", [(2, 10, 24), (3, 33, 17), (1, 64, 96), (32, 64, 64)])
+def test_thin_forward_kernel_vs_cpu_fp32(shape):
+    """conv_in's forward (RGB zero-padded to 8 channels -> 128) and conv_out's data gradient (the same geometry with the transposed,
+    flipped weight image) on conv_thin_fwd_kernel: ragged 8 x 32 tiles, image borders, more tiles than work-groups is not needed for a
+    non-pipelined epilogue but (32, 64, 64) walks 4 tiles per work-group-slot pair; through the public op (ops.norm_act_conv pads 3 -> 8),
+    forward and backward, against F.conv2d / autograd in fp32 on the CPU."""
+    from mas_hip import ops
+    dev = _dev()
+    n, h, w = shape
+    g = torch.Generator(device="cpu").manual_seed(h * 31 + w)
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    # conv_in: 3 -> 128 with bias
+    x = torch.randn(n, 3, h, w, generator=g).bfloat16()
+    w1 = 0.2 * torch.randn(128, 3, 3, 3, generator=g)
+    b1 = 0.1 * torch.randn(128, generator=g)
+    dy = torch.randn(n, 128, h, w, generator=g).bfloat16()
+    w1d, b1d = torch.nn.Parameter(w1.to(dev)), torch.nn.Parameter(b1.to(dev))
+    y = ops.norm_act_conv(cl(x), w1d, b1d)
+    y.backward(cl(dy))
+    w1r, b1r = w1.bfloat16().float().requires_grad_(True), b1.clone().requires_grad_(True)
+    yr = F.conv2d(x.float(), w1r, b1r, padding=1)
+    yr.backward(dy.float())
+    assert relerr(y.float(), yr) < 1e-2 and relerr(w1d.grad, w1r.grad) < 2e-3 and relerr(b1d.grad, b1r.grad) < 2e-3, shape
+    # conv_out: 128 -> 3; its data gradient is the 8 -> 128 geometry
+    a = torch.randn(n, 128, h, w, generator=g).bfloat16()
+    w2 = 0.05 * torch.randn(3, 128, 3, 3, generator=g)
+    b2 = 0.1 * torch.randn(3, generator=g)
+    d3 = torch.randn(n, 3, h, w, generator=g).bfloat16()
+    ad = cl(a).requires_grad_(True)
+    w2d, b2d = torch.nn.Parameter(w2.to(dev)), torch.nn.Parameter(b2.to(dev))
+    o = ops.norm_act_conv(ad, w2d, b2d)
+    o.backward(cl(d3))
+    ar = a.float().requires_grad_(True)
+    w2r, b2r = w2.bfloat16().float().requires_grad_(True), b2.clone().requires_grad_(True)
+    orr = F.conv2d(ar, w2r, b2r, padding=1)
+    orr.backward(d3.float())
+    torch.cuda.synchronize()
+    assert o.shape == orr.shape and relerr(o.float(), orr) < 1e-2, shape
+    assert relerr(ad.grad.float(), ar.grad) < 1e-2 and relerr(w2d.grad, w2r.grad) < 2e-3 and relerr(b2d.grad, b2r.grad) < 2e-3, shape
+
+
 # --------------------------------------------------------------------------------------------------------------
 # 7. MAS_WEIGHT_CACHE_CHECK=1: the debugging aid for writes the packed-weight stamp cannot see
 # --------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,17 @@
+#!/bin/bash
+# round-3 GPU call 40: conv_thin_fwd_kernel (8 -> 128 channels) vs conv_fwd.hip; whole-step A/B of the thin kernels
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+cd $R
+timeout 900 python -m pytest tests/test_gpu_parity_r3.py tests/test_gpu_model.py -m gpu -x -q 2>&1 | tail -3
+KB="timeout 120 python tools/kbench.py"
+for v in 1 0; do
+  echo "== [MAS_CONV_THIN=$v]"
+  MAS_CONV_THIN=$v $KB conv_fwd --n 32 --c 8 --co 128 --hw 256 --iters 30 2>&1 | tail -1
+  MAS_CONV_THIN=$v $KB dgrad --n 32 --c 8 --co 128 --hw 256 --iters 30 2>&1 | tail -1
+done
+B="timeout 300 python bench.py --no-cpu-baseline --no-also --steps 15 --warmup 10"
+for v in 1 0 1 0; do
+  echo -n "bench [thin=$v]: "; MAS_CONV_THIN=$v $B 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.2f img/s  %.3f ms/step  dominant %.4f ms' % (d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms']))"
+done
