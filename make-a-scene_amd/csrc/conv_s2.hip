@@ -1,0 +1,199 @@
+// Stride-2 3x3 convolutions (reference models/modules.py:62-81 Downsample: F.pad(x, (0, 1, 0, 1)) + Conv2d(stride 2, padding 0)).
+//
+// wgrad_s2_kernel -- their weight gradient  dW[co][kh][kw][ci] = sum over (n, i, j) of dy[n, i, j, co] * x[n, 2 i + kh, 2 j + kw, ci]
+// on the transpose-read GEMM of conv_wgrad_dma.hip / conv1x1.hip: K = output pixels, both operands staged [pixel][channel] by LDS-DMA,
+// fragments by ds_read_b64_tr_b16 -- whose per-lane addresses make the stride free: the B fragment of tap (kh, kw) reads patch pixel
+// (2 r + kh, 2 c + kw).  conv_wgrad.hip's stride-2 instance (round 1: transposed register staging, 4x4-channel micro-tiles) ran at
+// ~300 TFLOP/s: 0.40 ms for 128 -> 128 @256^2 where streaming x once takes 0.1 ms (profiles/r03_conv_shapes.txt).
+//   * work-group = 8 waves = one 128 (co) x 64 (ci) x 9-tap accumulator block (wave: 32 x 32 x 9 = 144 VGPRs), as conv_wgrad_dma.hip;
+//   * tile = 4 x 16 output pixels: dy tile 64 pixels x 256 B (16 KiB, 64-byte blocks ^ (pixel & 3)), x patch 9 x 33 pixels x 128 B
+//     (38 KiB, 64-byte blocks ^ ((column >> 1) & 1): the four pixels of a transpose read sit 256 B apart, so this read is 2-way
+//     bank-conflicted -- the kernel is bound by the 54 KiB of DMA per 36 MFMAs of a wave, not by LDS);
+//   * double-buffered, one barrier per tile; split-K over tiles into slabs for mas_wgrad_reduce (fixed order: bitwise reproducible);
+//     bias gradient = one more MFMA per k-step against an all-ones operand.
+#include "mas_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) int s2_i32x4;
+typedef __attribute__((ext_vector_type(4))) short s2_s16x4;
+__device__ __forceinline__ void s2_dma16(s2_i32x4 rs, unsigned lds, int vo) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(vo), "s"(rs) : "memory", "m0");
+}
+__device__ __forceinline__ s2_i32x4 s2_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    s2_i32x4 r = {(int)(unsigned)a, (int)(unsigned)(a >> 32), (int)bytes, 0x00020000};
+    r[0] = __builtin_amdgcn_readfirstlane(r[0]); r[1] = __builtin_amdgcn_readfirstlane(r[1]);
+    r[2] = __builtin_amdgcn_readfirstlane(r[2]); r[3] = __builtin_amdgcn_readfirstlane(r[3]);
+    return r;
+}
+__device__ __forceinline__ bf16x8 s2_tr(const unsigned char* a0, const unsigned char* a1) {
+    const s2_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s2_s16x4*)a0);
+    const s2_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s2_s16x4*)a1);
+    const __attribute__((ext_vector_type(8))) short v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return *reinterpret_cast<const bf16x8*>(&v);
+}
+
+struct S2WgradParams {
+    const unsigned char* x; const unsigned char* dy; float* part; float* part_bias;
+    int N, H, W, Cin, Ho, Wo, Cout;
+    int tiles_h, tiles_w, n_tiles, n_co_t, n_ci_t, nsplit;
+};
+
+constexpr int S2_NT = 512, S2_TH = 4, S2_TW = 16, S2_PH = 9, S2_PW = 33, S2_NPP = S2_PH * S2_PW;   // 297 patch pixels
+constexpr int S2_DY = 64 * 256;                // 16 KiB
+constexpr int S2_XP = 38 * 1024;               // 297 pixels x 128 B -> 38 DMA pieces of 8 pixels
+constexpr int S2_STAGE = S2_DY + S2_XP;
+constexpr int S2_LDS = 2 * S2_STAGE;           // 108 KiB
+constexpr int S2_OOB = (int)0x80000000;
+
+__global__ __launch_bounds__(S2_NT, 1) void wgrad_s2_kernel(S2WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s2_smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)s2_smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31, G16 = (lane >> 4) & 1, sl = lane & 15;
+    const int wco = (wave & 3) * 32, wci = (wave >> 2) * 32;
+    int bid = blockIdx.x;
+    const int split = bid % p.nsplit; bid /= p.nsplit;
+    const int ci_t = bid % p.n_ci_t, co_t = bid / p.n_ci_t;
+    const int co0 = co_t * 128, ci0 = ci_t * 64;
+
+    const s2_i32x4 rs_dy = s2_rsrc(p.dy, (unsigned)((size_t)p.N * p.Ho * p.Wo * p.Cout * 2));
+    const s2_i32x4 rs_x = s2_rsrc(p.x, (unsigned)((size_t)p.N * p.H * p.W * p.Cin * 2));
+
+    // ---- DMA plan.  dY: 16 pieces of 4 pixels x 256 B; wave w moves pieces 2 w, 2 w + 1 (tile row w >> 1, columns 8 (w & 1) + 4 j + (lane >> 4));
+    //      physical 64-byte block (lane >> 2) & 3 = logical block ^ (column & 3).  Patch: pieces wave + 8 k (k < 5, piece < 38) of 8 pixels x 128 B;
+    //      lane: pixel 8 piece + (lane >> 3), physical block (lane >> 2) & 1 = logical block ^ ((patch column >> 1) & 1), 16-byte slot lane & 3.
+    const int lp = lane >> 4;
+    const int dsrc = ((((lane >> 2) & 3) ^ lp) << 6) + ((lane & 3) << 4);
+    auto issue = [&](int t, int stage) {
+        const int tw_i = t % p.tiles_w; const int q = t / p.tiles_w;
+        const int th_i = q % p.tiles_h, n = q / p.tiles_h;
+        const int oh0 = th_i * S2_TH, ow0 = tw_i * S2_TW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int piece = 2 * wave + j;
+            const int oh = oh0 + (piece >> 2), ow = ow0 + 4 * (piece & 3) + lp;
+            const bool ok = oh < p.Ho && ow < p.Wo;
+            s2_dma16(rs_dy, __builtin_amdgcn_readfirstlane(lds0 + stage * S2_STAGE + piece * 1024),
+                     ok ? (((n * p.Ho + oh) * p.Wo + ow) * p.Cout + co0) * 2 + dsrc : S2_OOB);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int piece = wave + 8 * k;
+            if (piece < 38) {
+                const int px = piece * 8 + (lane >> 3);
+                const int pr = px / S2_PW, pc = px - pr * S2_PW;
+                const int ih = 2 * oh0 + pr, iw = 2 * ow0 + pc;
+                const bool ok = px < S2_NPP && ih < p.H && iw < p.W;                 // (rows / columns past the map = the one-sided zero padding)
+                const int blk = ((lane >> 2) & 1) ^ ((pc >> 1) & 1);
+                s2_dma16(rs_x, __builtin_amdgcn_readfirstlane(lds0 + stage * S2_STAGE + S2_DY + piece * 1024),
+                         ok ? (((n * p.H + ih) * p.W + iw) * p.Cin + ci0) * 2 + (blk << 6) + ((lane & 3) << 4) : S2_OOB);
+            }
+        }
+    };
+
+    // ---- transpose-read lane addressing: pixel column 8 g + t4 (+ 4) of tile row r; A: channels wco + 16 G16 + 4 (sl & 3) ..+3 of the dY row,
+    //      B: channels wci + ... of patch pixel (2 r + kh, 2 column + kw)
+    const int t4 = sl >> 2;
+    const int a_off = (8 * g + t4) * 256 + (((wco >> 5) ^ t4) << 6) + 32 * G16 + 8 * (sl & 3);
+    int b_off[3];                                  // per kw (tile row 0, kh = 0); + (2 r + kh) * 33 * 128 per row; second read + 8 * 128
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int col = 2 * (8 * g + t4) + kw;
+        b_off[kw] = S2_DY + col * 128 + ((((wci >> 5) ^ (col >> 1)) & 1) << 6) + 32 * G16 + 8 * (sl & 3);
+    }
+
+    f32x16 acc[9], accb;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.0f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+    const bool do_bias = p.part_bias != nullptr && ci_t == 0 && wci == 0;       // (wave-uniform)
+
+    const int n_mine = (p.n_tiles - split + p.nsplit - 1) / p.nsplit;
+    if (n_mine > 0) issue(split, 0);
+    auto tile = [&](int it, auto stage_c) {
+        constexpr int ST = decltype(stage_c)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + 1 < n_mine) issue(split + (it + 1) * p.nsplit, ST ^ 1);
+        const unsigned char* sb = s2_smem + ST * S2_STAGE;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned char* a0 = sb + a_off + r * 16 * 256;
+            const bf16x8 afr = s2_tr(a0, a0 + 4 * 256);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const unsigned char* b0 = sb + b_off[kw] + (2 * r + kh) * S2_PW * 128;
+                    mma16(acc[kh * 3 + kw], afr, s2_tr(b0, b0 + 8 * 128));          // D[co][ci]
+                }
+            if (do_bias) mma16(accb, afr, ones);
+        }
+    };
+    for (int it = 0; it < n_mine; it += 2) {
+        tile(it, std::integral_constant<int, 0>{});
+        if (it + 1 < n_mine) tile(it + 1, std::integral_constant<int, 1>{});
+    }
+
+    float* pw = p.part + (size_t)split * ((size_t)p.Cout * 9 * p.Cin);
+    const int ci = ci0 + wci + l31;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco + acc_row(lane, r);
+            pw[((size_t)co * 9 + t) * p.Cin + ci] = acc[t][r];
+        }
+    if (do_bias && l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p.part_bias[(size_t)split * p.Cout + co0 + wco + acc_row(lane, r)] = accb[r];
+    }
+}
+
+}  // namespace
+
+static bool s2_wgrad_setup(const MasConvDesc* d, S2WgradParams& p) {
+    static const int on = mas_env_int("MAS_CONV_S2", 1);
+    if (!on) return false;
+    if (d->ks != 3 || d->stride != 2 || d->upsample || d->act != MAS_ACT_NONE || d->pad_top != 0 || d->pad_left != 0) return false;
+    if (d->in_dtype != MAS_BF16 || d->Cin % 64 || d->Cout % 128) return false;
+    if ((long long)d->N * d->H * d->W * d->Cin * 2 >= 0x7fffffffLL || (long long)d->N * d->Ho * d->Wo * d->Cout * 2 >= 0x7fffffffLL) return false;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+    p.tiles_h = mas_cdiv(d->Ho, S2_TH); p.tiles_w = mas_cdiv(d->Wo, S2_TW); p.n_tiles = d->N * p.tiles_h * p.tiles_w;
+    p.n_co_t = d->Cout / 128; p.n_ci_t = d->Cin / 64;
+    int ns = mas_cdiv(mas_cu_budget(), p.n_co_t * p.n_ci_t);                      // one 108-KiB work-group per CU
+    if (ns > p.n_tiles) ns = p.n_tiles;
+    if (ns < 1) ns = 1;
+    p.nsplit = ns;
+    return true;
+}
+
+int mas_wgrad_s2_splits(const MasConvDesc* d) {
+    S2WgradParams p;
+    return s2_wgrad_setup(d, p) ? p.nsplit : 0;
+}
+
+// part [nsplit][Cout][3][3][Cin], part_bias [nsplit][Cout] or NULL (see mas_conv_wgrad_partial)
+int mas_wgrad_s2_partial(const MasConvDesc* d, const void* x, const void* dy, float* part, float* part_bias, hipStream_t s) {
+    S2WgradParams p;
+    if (!s2_wgrad_setup(d, p)) return 0;
+    p.x = (const unsigned char*)x; p.dy = (const unsigned char*)dy; p.part = part; p.part_bias = part_bias;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_s2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS) != hipSuccess) return 0;
+        attr = true;
+    }
+    hipLaunchKernelGGL(wgrad_s2_kernel, dim3((unsigned)(p.n_co_t * p.n_ci_t * p.nsplit)), dim3(S2_NT), S2_LDS, s, p);
+    MAS_CHECK_LAUNCH("wgrad_s2");
+    return 1;
+}

@@ -567,6 +567,8 @@ int mas_conv_wgrad_dma_try(const MasConvDesc* d, const void* x, const float* sca
 int mas_wgrad1x1_splits(const MasConvDesc* d);                                   // conv1x1.hip
 int mas_wgrad1x1_partial(const MasConvDesc* d, const void* x, const void* dy, float* part, float* part_bias, hipStream_t s);
 
+int mas_wgrad_s2_splits(const MasConvDesc* d);                                    // conv_s2.hip
+int mas_wgrad_s2_partial(const MasConvDesc* d, const void* x, const void* dy, float* part, float* part_bias, hipStream_t s);
 int mas_wgrad_thin_splits(const MasConvDesc* d);                                  // conv_thin.hip
 int mas_wgrad_thin_partial(const MasConvDesc* d, const void* x, const void* dy, float* part, float* part_bias, hipStream_t s);
 
@@ -574,6 +576,7 @@ extern "C" int mas_conv_wgrad_splits(const MasConvDesc* d) {
     DmaWgradParams p;
     if (!d) return 0;
     if (d->ks == 1) return mas_wgrad1x1_splits(d);
+    if (d->stride == 2) return mas_wgrad_s2_splits(d);
     if (!dma_setup(d, p)) return mas_wgrad_thin_splits(d);
     return p.nsplit;
 }
@@ -589,6 +592,11 @@ extern "C" int mas_conv_wgrad_partial(const MasConvDesc* d, const void* x, const
     if (d->ks == 1) {                            // plain GEMM (conv1x1.hip)
         const int rc = mas_wgrad1x1_partial(d, x, dy, part, part_bias, reinterpret_cast<hipStream_t>(stream));
         if (rc == 0) MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad_partial: this 1x1 convolution does not take the split-K partial path (mas_conv_wgrad_splits == 0)");
+        return rc < 0 ? rc : MAS_OK;
+    }
+    if (d->stride == 2) {                        // Downsample: conv_s2.hip
+        const int rc = mas_wgrad_s2_partial(d, x, dy, part, part_bias, reinterpret_cast<hipStream_t>(stream));
+        if (rc == 0) MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad_partial: this stride-2 convolution does not take the split-K partial path (mas_conv_wgrad_splits == 0)");
         return rc < 0 ? rc : MAS_OK;
     }
     DmaWgradParams p;

@@ -493,6 +493,40 @@ def test_thin_forward_kernel_vs_cpu_fp32(shape):
 
 
 # --------------------------------------------------------------------------------------------------------------
+# 6d. Downsample's weight gradient on the stride-2 transpose-read kernel (conv_s2.hip)
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 128, 128, 20, 36), (3, 64, 128, 17, 33), (4, 256, 256, 32, 32), (32, 128, 128, 64, 64), (1, 192, 384, 8, 8)])
+def test_stride2_wgrad_kernel_vs_cpu_fp32(shape):
+    """reference models/modules.py:62-81 (pad right / bottom by one, 3x3 stride 2, no other padding): weight and bias gradient against
+    autograd of F.conv2d on the CPU.  Even and odd map sizes (odd: the padded row / column is never read; even: it is the last tap),
+    ragged 4 x 16 output tiles, several cout / cin blocks, many tiles per work-group; bitwise run to run."""
+    import ctypes as C
+    import mas_hip
+    from mas_hip import ops, ACT_NONE
+    dev = _dev()
+    n, cin, cout, h, w = shape
+    ho, wo = (h + 1 - 3) // 2 + 1, (w + 1 - 3) // 2 + 1
+    g = torch.Generator(device="cpu").manual_seed(cin + 5 * h + w)
+    x = torch.randn(n, cin, h, w, generator=g).bfloat16()
+    dy = (0.5 * torch.randn(n, cout, ho, wo, generator=g)).bfloat16()
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    d = ops._desc(n, h, w, cin, ho, wo, cout, 3, 2, 0, 0, torch.bfloat16, torch.bfloat16, ACT_NONE, False)
+    assert mas_hip.lib().mas_conv_wgrad_splits(C.byref(d)) > 0, "this shape must take the stride-2 split-K path"
+    outs = []
+    for _ in range(2):
+        for ws in ops._wgrad_partials.values():
+            ws.fill_(float("nan"))
+        dw, db = ops.conv_wgrad_raw(cl(x), None, cl(dy), n, h, w, cin, ho, wo, cout, 3, 2, 0, 0, ACT_NONE, False, True)
+        torch.cuda.synchronize()
+        outs.append((dw.clone(), db.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    wr = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), wr, None, stride=2).backward(dy.float())
+    assert outs[0][0].shape == wr.shape
+    assert relerr(outs[0][0], wr.grad) < 2e-3 and relerr(outs[0][1], dy.float().sum((0, 2, 3))) < 2e-3, shape
+
+
+# --------------------------------------------------------------------------------------------------------------
 # 7. MAS_WEIGHT_CACHE_CHECK=1: the debugging aid for writes the packed-weight stamp cannot see
 # --------------------------------------------------------------------------------------------------------------
 def test_weight_cache_check_flags_a_write_through_data():
