@@ -528,8 +528,11 @@ int mas_conv3x3_stream_try(const MasConvDesc* d, const void* x, const float* sca
     p.n_chunks = d->Cin / 64; p.Cout_pad = mas_roundup(d->Cout, 128);
     p.tiles_h = mas_cdiv(d->Ho, 16); p.tiles_w = mas_cdiv(d->Wo, 16); p.n_ct = d->Cout / 128;
     const long long tiles = (long long)p.N * p.tiles_h * p.tiles_w * p.n_ct;
-    static const int min_per_cu = mas_env_int("MAS_CONV_STREAM_MIN_TILES_PER_CU", 2);
-    if (tiles < (long long)min_per_cu * mas_num_cus() || tiles > 0x7fffffffLL) return 0;   // small maps: the 8x16-tile general kernel fills the chip better
+    // Small maps (fewer tiles than CUs): round 2 sent them to the 8x16-tile general kernel, which fills the chip; since the 16x16 level's
+    // layers are (Cin, Cout) = (512, 512) -- 72 tap-steps per tile -- one stream tile on half the CUs is as fast per launch (52 vs 51 us)
+    // and the step is 0.3 ms faster with it (profiles/r03_ab_stream_small.txt).  MAS_CONV_STREAM_MIN_TILES_PER_CU=2 restores the old rule.
+    static const int min_per_cu = mas_env_int("MAS_CONV_STREAM_MIN_TILES_PER_CU", 0);
+    if (tiles < (long long)min_per_cu * mas_num_cus() || tiles > 0x7fffffffLL) return 0;
     const bool defer = (mode & 2) != 0;
     int rc;
     if (d->act != MAS_ACT_NONE) rc = defer ? launch_stream<true, true>(p, s) : launch_stream<true, false>(p, s);
