@@ -593,7 +593,8 @@ bool mas_conv3x3_wide_eligible(const MasConvDesc* d) {
     const long long out_bytes = (long long)d->N * d->Ho * d->Wo * d->Cout * 2;
     if (img_bytes >= 0x7fffffffLL || out_bytes >= 0x7fffffffLL) return false;
     const long long tiles = (long long)d->N * mas_cdiv(d->Ho, 16) * mas_cdiv(d->Wo, 32) * (d->Cout / 128);
-    static const int min_per_cu = mas_env_int("MAS_CONV_WIDE_MIN_TILES_PER_CU", 2);
+    // one tile per CU is enough: 512 -> 512 @32^2 (256 tiles) 0.143 ms on the stream kernel, 0.127 here; step -0.3 ms (profiles/r03_ab_wide_min.txt)
+    static const int min_per_cu = mas_env_int("MAS_CONV_WIDE_MIN_TILES_PER_CU", 1);
     if (tiles < (long long)min_per_cu * mas_num_cus() || tiles > 0x7fffffffLL) return false;
     const long long dmax = std::max<long long>(d->Cout / 128, std::max(mas_cdiv(d->Ho, 16), mas_cdiv(d->Wo, 32)));
     if (tiles * dmax >= 0x100000000LL) return false;       // the kernel's multiply-high tile decode is exact below this
