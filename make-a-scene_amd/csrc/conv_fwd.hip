@@ -614,6 +614,7 @@ bool mas_conv3x3_wide_act_out_ok(const MasConvDesc* d);
 int mas_conv3x3_wide_stat_rows(const MasConvDesc* d);
 int mas_conv1x1_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s);
 int mas_conv_thin_fwd_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s);
+int mas_conv_s2_fwd_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s);
 
 // Can mas_conv_fwd_stats fill the consumer's GroupNorm statistics for this convolution, and with how many table rows per image?
 extern "C" int mas_conv_stat_rows(const MasConvDesc* d) {
@@ -681,6 +682,9 @@ static int conv_fwd_impl(const MasConvDesc* d, const void* x, const float* scale
         if (rc != 0) return rc < 0 ? rc : MAS_OK;
         // 8 -> 128 channels (conv_in's forward, conv_out's data gradient): conv_thin.hip
         rc = mas_conv_thin_fwd_try(d, x, w_packed, bias, residual, y, reinterpret_cast<hipStream_t>(stream));
+        if (rc != 0) return rc < 0 ? rc : MAS_OK;
+        // Downsample (3x3 stride 2): conv_s2.hip
+        rc = mas_conv_s2_fwd_try(d, x, w_packed, bias, residual, y, reinterpret_cast<hipStream_t>(stream));
         if (rc != 0) return rc < 0 ? rc : MAS_OK;
     }
     ConvParams p;

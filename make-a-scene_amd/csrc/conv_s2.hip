@@ -160,6 +160,175 @@ __global__ __launch_bounds__(S2_NT, 1) void wgrad_s2_kernel(S2WgradParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_s2_fwd_kernel -- Downsample's forward:  y[n, i, j, co] = sum w[co][kh][kw][ci] * x[n, 2 i + kh, 2 j + kw, ci] + bias[co].
+// conv_fwd.hip's stride-2 instance stages a (2 x 8 + 1) x (2 x 16 + 2)-pixel x 64-channel patch (74 KiB) per 128 output pixels through
+// registers and runs at ~300 TFLOP/s (0.56 ms for 128 -> 128 @256^2).  A stride-2 patch is 4.4x the bytes per output pixel of a stride-1
+// one, so the tile cannot be the wide kernel's: here a STAGE is one filter row kh of one 32-channel chunk -- the 8 input rows
+// 2 r + kh of the 8 x 32-pixel output tile (8 x 65 pixels x 64 B = 33 KiB; rows are re-fetched per kh, from L2) and that row's 3 taps of
+// weights for 128 couts (24 KiB, gathered by the DMA from the 64-channel K64 image: a lane asks for LOGICAL 16-byte slot 4 h + s of
+// its row) -- double-buffered (116 KiB), both by LDS-DMA, one barrier per stage, 24 MFMAs per wave and stage.
+//   waves: 2 (64 couts) x 4 (output rows 2 p, 2 p + 1); B fragment of pixel (r, c), tap kw = patch pixel r * 65 + 2 c + kw: one
+//   ds_read_b128 whose 16-byte slot is ^ ((pixel >> 1) & 3) (2-way bank conflict: neighbouring lanes sit 128 B apart); weight rows
+//   slot ^ ((row >> 2) & 3) as in conv3x3_wide.hip.  Epilogue as conv3x3_stream.hip (permlane32_swap: 8 consecutive couts per lane).
+struct S2FwdParams {
+    const unsigned char* x; const unsigned char* w; const float* bias; unsigned char* y;
+    int N, H, W, Cin, Ho, Wo, Cout, rows_pad, n_chunks32, tiles_h, tiles_w, n_ct;
+};
+constexpr int F2_TH = 8, F2_TW = 32, F2_PW = 65, F2_NPP = F2_TH * F2_PW;      // 520 patch pixels per stage
+constexpr int F2_PATCH = 33 * 1024;             // 520 x 64 B -> 33 DMA pieces of 16 pixels
+constexpr int F2_WT = 128 * 64;                 // one tap: 128 couts x 64 B
+constexpr int F2_STAGE = F2_PATCH + 3 * F2_WT;  // 58368 B
+constexpr int F2_LDS = 2 * F2_STAGE;
+
+__global__ __launch_bounds__(S2_NT, 1) void conv_s2_fwd_kernel(S2FwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s2_smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)s2_smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31;
+    const int wave_c = wave & 1, wave_p = wave >> 1;
+    int t = blockIdx.x;
+    const int ct = t % p.n_ct; t /= p.n_ct;
+    const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+    const int th_i = t % p.tiles_h, n = t / p.tiles_h;
+    const int oh0 = th_i * F2_TH, ow0 = tw_i * F2_TW, c0 = ct * 128;
+
+    const s2_i32x4 rs_x = s2_rsrc(p.x, (unsigned)((size_t)p.N * p.H * p.W * p.Cin * 2));
+    const s2_i32x4 rs_w = s2_rsrc(p.w, (unsigned)((size_t)(p.Cin / 64 + (p.Cin % 64 ? 1 : 0)) * 9 * p.rows_pad * 128));
+
+    // ---- DMA plan.  Patch piece wave + 8 k (k < 5, piece < 33): pixel P = 16 piece + (lane >> 2) = row P / 65, column P % 65; physical
+    //      16-byte slot lane & 3 holds LOGICAL slot ^ ((P >> 1) & 3).  Weight piece wave + 8 k (k < 3) = tap piece / 8, rows
+    //      16 (piece & 7) + (lane >> 2); physical slot lane & 3 holds logical slot ^ ((row >> 2) & 3), fetched from the K64 image's row
+    //      (128 B, its own swizzle (row >> 1) & 7) at logical 16-byte slot 4 h + s of the 64-channel chunk.
+    int xo[5];                                     // per piece: byte offset of (input row 2 (oh0 + r), column 2 ow0 + pc, channel slot) or out of range
+    unsigned xok = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int piece = wave + 8 * k, P = piece * 16 + (lane >> 2);
+        const int pr = P / F2_PW, pc = P - pr * F2_PW;
+        const int ih = 2 * (oh0 + pr), iw = 2 * ow0 + pc;
+        const bool ok = piece < 33 && P < F2_NPP && iw < p.W;
+        xo[k] = ((n * p.H + ih) * p.W + iw) * p.Cin * 2 + ((((lane & 3) ^ ((P >> 1) & 3))) << 4);
+        if (ok && ih < p.H) xok |= 1u << k;            // row 2 (oh0 + r) + 0 inside the map
+        if (ok && ih + 1 < p.H) xok |= 1u << (8 + k);   // ... + 1
+        if (ok && ih + 2 < p.H) xok |= 1u << (16 + k);  // ... + 2
+    }
+    int wo[3], ws0[3], ws1[3];                     // row part of the source offset; swizzled slot for the low / high 32-channel half
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int piece = wave + 8 * k, tap_w = piece >> 3, row = 16 * (piece & 7) + (lane >> 2);
+        const int ls = (lane & 3) ^ ((row >> 2) & 3);                          // logical slot (0..3) inside the 32-channel half
+        wo[k] = (tap_w * p.rows_pad + c0 + row) * 128;
+        ws0[k] = (ls ^ ((row >> 1) & 7)) << 4;
+        ws1[k] = ((4 + ls) ^ ((row >> 1) & 7)) << 4;
+    }
+    auto issue = [&](int st, int stage) {
+        const int c32 = st / 3, kh = st - 3 * c32;
+        const int c64 = c32 >> 1, h = c32 & 1;
+        const int xs = kh * p.W * p.Cin * 2 + c32 * 64;                        // uniform
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            if (wave + 8 * k < 33) {
+                const bool ok = (xok >> (8 * kh + k)) & 1u;
+                s2_dma16(rs_x, __builtin_amdgcn_readfirstlane(lds0 + stage * F2_STAGE + (wave + 8 * k) * 1024), ok ? xo[k] + xs : S2_OOB);
+            }
+        }
+        const int wb = (c64 * 9 + kh * 3) * p.rows_pad * 128;                  // uniform: chunk c64, taps kh * 3 ..
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            s2_dma16(rs_w, __builtin_amdgcn_readfirstlane(lds0 + stage * F2_STAGE + F2_PATCH + (wave + 8 * k) * 1024), wo[k] + wb + (h ? ws1[k] : ws0[k]));
+    };
+
+    // ---- fragment addresses
+    int aoff[2];                                   // weight row wave_c * 64 + 32 i + l31 (tap kw: + kw * F2_WT), logical slot 2 kk + g
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave_c * 64 + 32 * i + l31;
+        aoff[i] = F2_PATCH + row * 64 + ((g ^ ((row >> 2) & 3)) << 4);
+    }
+    int boff[2][3];                                // output row 2 wave_p + j, column l31, tap kw
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int P = (2 * wave_p + j) * F2_PW + 2 * l31 + kw;
+            boff[j][kw] = P * 64 + ((g ^ ((P >> 1) & 3)) << 4);
+        }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int n_st = p.n_chunks32 * 3;
+    issue(0, 0);
+    auto stage_fn = [&](int st, auto stage_c) {
+        constexpr int ST = decltype(stage_c)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + 1 < n_st) issue(st + 1, ST ^ 1);
+        const unsigned char* sb = s2_smem + ST * F2_STAGE;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 afr[2], bfr[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) afr[i] = *reinterpret_cast<const bf16x8*>(sb + ((aoff[i] + kw * F2_WT) ^ (kk << 5)));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + (boff[j][kw] ^ (kk << 5)));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mma16(acc[i][j], afr[i], bfr[j]);           // D[cout][pixel]
+            }
+    };
+    for (int st = 0; st < n_st; st += 2) {
+        stage_fn(st, std::integral_constant<int, 0>{});
+        if (st + 1 < n_st) stage_fn(st + 1, std::integral_constant<int, 1>{});
+    }
+
+    // ---- epilogue
+    const unsigned out_bytes = (unsigned)((size_t)p.N * p.Ho * p.Wo * p.Cout * 2);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(p.bias ? (void*)p.bias : (void*)p.y, 0, p.bias ? (unsigned)(p.Cout * 4) : 0u, 0x00020000);
+    f32x4 bv[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+            const int cb = (c0 + wave_c * 64 + i * 32 + 16 * qp + 8 * g) * 4;
+            bv[i][qp][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, cb, 0, 0));
+            bv[i][qp][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, cb + 16, 0, 0));
+        }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int oh = oh0 + 2 * wave_p + j, ow = ow0 + l31;
+        const int obase = (oh < p.Ho && ow < p.Wo) ? (((n * p.Ho + oh) * p.Wo + ow) * p.Cout + c0 + wave_c * 64 + 8 * g) * 2 : S2_OOB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float qa = acc[i][j][(2 * qp) * 4 + e], qb = acc[i][j][(2 * qp + 1) * 4 + e];
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(qa), __float_as_uint(qb), false, false);
+                    v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
+                }
+                u32x4 o;
+                bf16_t* ob = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ob[e] = (bf16_t)(v[e] + bv[i][qp][e >> 2][e & 3]);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, obase + (i * 32 + qp * 16) * 2, 0, 0);
+            }
+    }
+}
+
 }  // namespace
 
 static bool s2_wgrad_setup(const MasConvDesc* d, S2WgradParams& p) {
@@ -195,5 +364,30 @@ int mas_wgrad_s2_partial(const MasConvDesc* d, const void* x, const void* dy, fl
     }
     hipLaunchKernelGGL(wgrad_s2_kernel, dim3((unsigned)(p.n_co_t * p.n_ci_t * p.nsplit)), dim3(S2_NT), S2_LDS, s, p);
     MAS_CHECK_LAUNCH("wgrad_s2");
+    return 1;
+}
+
+// Downsample forward (3x3, stride 2, no padding but the one-sided zero row / column): returns 1 if launched, 0 if conv_fwd.hip should take it
+int mas_conv_s2_fwd_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s) {
+    static const int on = mas_env_int("MAS_CONV_S2", 1);
+    if (!on || residual) return 0;
+    if (d->ks != 3 || d->stride != 2 || d->upsample || d->act != MAS_ACT_NONE || d->pad_top != 0 || d->pad_left != 0) return 0;
+    if (d->in_dtype != MAS_BF16 || d->out_dtype != MAS_BF16 || d->w_layout != MAS_WLAYOUT_K64) return 0;
+    if (d->Cin % 32 || d->Cout % 128 || d->Wo < 32) return 0;                   // (narrower maps would idle half of every tile)
+    if ((long long)d->N * d->H * d->W * d->Cin * 2 >= 0x7fffffffLL || (long long)d->N * d->Ho * d->Wo * d->Cout * 2 >= 0x7fffffffLL) return 0;
+    S2FwdParams p;
+    p.x = (const unsigned char*)x; p.w = (const unsigned char*)w_packed; p.bias = bias; p.y = (unsigned char*)y;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+    p.rows_pad = mas_roundup(d->Cout, 128); p.n_chunks32 = d->Cin / 32;
+    p.tiles_h = mas_cdiv(d->Ho, F2_TH); p.tiles_w = mas_cdiv(d->Wo, F2_TW); p.n_ct = d->Cout / 128;
+    const long long grid = (long long)d->N * p.tiles_h * p.tiles_w * p.n_ct;
+    if (grid > 0x7fffffffLL) return 0;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS) != hipSuccess) return 0;
+        attr = true;
+    }
+    hipLaunchKernelGGL(conv_s2_fwd_kernel, dim3((unsigned)grid), dim3(S2_NT), F2_LDS, s, p);
+    MAS_CHECK_LAUNCH("conv_s2_fwd");
     return 1;
 }

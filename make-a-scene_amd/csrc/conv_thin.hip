@@ -260,7 +260,10 @@ __global__ __launch_bounds__(TH_NT, 2) void conv_thin_fwd_kernel(ThinFwdParams p
                     bf16_t* ob = reinterpret_cast<bf16_t*>(&o);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { ob[e] = (bf16_t)(v[e] + b0[e]); ob[4 + e] = (bf16_t)(v[4 + e] + b1[e]); }
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, obase + (32 * i + 16 * qp) * 2, 0, 0);
+#ifndef TF_ST_AUX
+#define TF_ST_AUX 0
+#endif
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, obase + (32 * i + 16 * qp) * 2, 0, TF_ST_AUX);
                 }
         }
     };
