@@ -162,6 +162,10 @@ int mas_wgrad_commit(float* acc, float* dw_oihw, float* dbias, int Cout, int Cin
  * prologue; 3x3 with Cin % 64 == 0, Cout % 128 == 0, or 1x1 with Cin % 128 == 0, Cout % 128 == 0: part is then [nsplit][Cout][ks][ks][Cin]) mas_conv_wgrad_partial writes the nsplit partial sums -- part [nsplit][Cout][3][3][Cin] fp32,
  * part_bias [nsplit][Cout] or NULL, every element exactly once, plain stores, no initialisation required -- and mas_wgrad_reduce adds
  * the slabs in a fixed order into dw_oihw [Cout][Cin][ks][ks] / dbias [Cout]: no atomics, bitwise reproducible run to run.          */
+/* Downsample's data gradient without the zero-stuffed tensor (reference models/modules.py:62-81 under autograd): d describes the
+ * FORWARD convolution (3x3, stride 2, pads 0); w_packed_t = mas_pack_conv_weight_layout(transpose = 1, MAS_WLAYOUT_K64).           */
+int mas_conv_s2_dgrad_supported(const MasConvDesc* d);
+int mas_conv_s2_dgrad(const MasConvDesc* d, const void* dy, const void* w_packed_t, void* dx, void* stream);
 int mas_conv_wgrad_splits(const MasConvDesc* d);
 int mas_conv_wgrad_partial(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy,
                            float* part, float* part_bias, void* stream);

@@ -329,6 +329,166 @@ __global__ __launch_bounds__(S2_NT, 1) void conv_s2_fwd_kernel(S2FwdParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_s2_dgrad_kernel -- Downsample's data gradient  dx[n, u, v, ci] = sum over (kh, kw, co) with u - kh, v - kw even of
+//   w[co][kh][kw][ci] * dy[n, (u - kh) / 2, (v - kw) / 2, co]
+// without the zero-stuffed tensor (round 1: a stride-1 convolution over 4x the pixels, three quarters of its MFMAs multiplying
+// zeros).  A work-group owns ONE parity class (p, q) = (u & 1, v & 1) of an 8 x 32 block of (a, b) = (u >> 1, v >> 1): 256 dx pixels
+// x 128 cins whose taps are kh in {0, 2} (p = 0) or {1} (p = 1), likewise kw -- 4, 2, 2 or 1 taps, the exact FLOPs.  Structure of the
+// forward kernel above: stage = (32-cout chunk, kh): the 8 dy rows a - (kh >> 1) x 33 columns b - 1 .. b + 31 (17 KiB) + the class's
+// 1-2 taps of weights from the TRANSPOSED K64 image (rows = cin, taps flipped: mas_pack_conv_weight_layout), double-buffered LDS-DMA.
+// Heavy classes are dispatched first.
+struct S2DgradParams {
+    const unsigned char* dy; const unsigned char* w; unsigned char* dx;
+    int N, H, W, Cin, Ho, Wo, Cout, rows_pad, n_chunks32, tiles_h, tiles_w, n_ct, per_class;
+};
+constexpr int G2_PW = 33, G2_NPP = 8 * G2_PW;   // 264 patch pixels per stage
+constexpr int G2_PATCH = 17 * 1024;
+constexpr int G2_STAGE = G2_PATCH + 2 * F2_WT;  // 33792 B
+constexpr int G2_LDS = 2 * G2_STAGE;
+
+__global__ __launch_bounds__(S2_NT, 1) void conv_s2_dgrad_kernel(S2DgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s2_smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)s2_smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31;
+    const int wave_c = wave & 1, wave_p = wave >> 1;
+    const int cls = (int)blockIdx.x / p.per_class;                  // 0: (0,0) 4 taps | 1: (0,1) | 2: (1,0) | 3: (1,1) 1 tap
+    const int pp = cls >> 1, qq = cls & 1;
+    int t = (int)blockIdx.x - cls * p.per_class;
+    const int ct = t % p.n_ct; t /= p.n_ct;
+    const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+    const int th_i = t % p.tiles_h, n = t / p.tiles_h;
+    const int a0 = th_i * F2_TH, b0 = tw_i * F2_TW, ci0 = ct * 128;
+    const int nkh = pp ? 1 : 2, nkw = qq ? 1 : 2;
+
+    const s2_i32x4 rs_y = s2_rsrc(p.dy, (unsigned)((size_t)p.N * p.Ho * p.Wo * p.Cout * 2));
+    const s2_i32x4 rs_w = s2_rsrc(p.w, (unsigned)((size_t)((p.Cout + 63) / 64) * 9 * p.rows_pad * 128));
+
+    // ---- DMA plan.  Patch piece wave + 8 k (k < 3, piece < 17): pixel P = 16 piece + (lane >> 2) = row P / 33 (dy row a0 + row - dh),
+    //      column P % 33 (dy column b0 - 1 + column); slot swizzle as the forward kernel.  Weights: piece wave + 8 k = tap slot k, rows
+    //      16 wave + (lane >> 2) of the 128-cin tile.
+    int yo[3];
+    unsigned yok = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int piece = wave + 8 * k, P = piece * 16 + (lane >> 2);
+        const int pr = P / G2_PW, pc = P - pr * G2_PW;
+        const int ar = a0 + pr, bc = b0 - 1 + pc;
+        const bool ok = piece < 17 && P < G2_NPP && bc >= 0 && bc < p.Wo;
+        yo[k] = ((n * p.Ho + ar) * p.Wo + bc) * p.Cout * 2 + ((((lane & 3) ^ ((P >> 1) & 3))) << 4);
+        if (ok && ar < p.Ho) yok |= 1u << k;                              // dh = 0: dy row a0 + row
+        if (ok && ar >= 1 && ar - 1 < p.Ho) yok |= 1u << (8 + k);         // dh = 1: dy row a0 + row - 1
+    }
+    const int wrow = 16 * wave + (lane >> 2);
+    const int wls = (lane & 3) ^ ((wrow >> 2) & 3);
+    const int wo_ = (ci0 + wrow) * 128;
+    const int ws0 = (wls ^ ((wrow >> 1) & 7)) << 4, ws1 = ((4 + wls) ^ ((wrow >> 1) & 7)) << 4;
+    auto issue = [&](int st, int stage) {
+        const int c32 = st / nkh, ikh = st - nkh * c32;
+        const int kh = pp ? 1 : 2 * ikh, dh = kh >> 1;
+        const int c64 = c32 >> 1, h = c32 & 1;
+        const int ys = c32 * 64 - dh * p.Wo * p.Cout * 2;                     // uniform
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (wave + 8 * k < 17) {
+                const bool ok = (yok >> (8 * dh + k)) & 1u;
+                s2_dma16(rs_y, __builtin_amdgcn_readfirstlane(lds0 + stage * G2_STAGE + (wave + 8 * k) * 1024), ok ? yo[k] + ys : S2_OOB);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k < nkw) {
+                const int kw = qq ? 1 : 2 * k;
+                const int tap_img = (2 - kh) * 3 + (2 - kw);                   // the transposed image stores the taps flipped
+                const int wb = ((c64 * 9 + tap_img) * p.rows_pad) * 128;      // uniform
+                s2_dma16(rs_w, __builtin_amdgcn_readfirstlane(lds0 + stage * G2_STAGE + G2_PATCH + (wave + 8 * k) * 1024), wo_ + wb + (h ? ws1 : ws0));
+            }
+        }
+    };
+
+    int aoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave_c * 64 + 32 * i + l31;
+        aoff[i] = G2_PATCH + row * 64 + ((g ^ ((row >> 2) & 3)) << 4);
+    }
+    int boff[2][2];                                // (a, b) row 2 wave_p + j, column l31; tap slot k: dy column b - (kw >> 1) = patch column l31 + 1 - (kw >> 1)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int kw = qq ? 1 : 2 * k;
+            const int P = (2 * wave_p + j) * G2_PW + l31 + 1 - (kw >> 1);
+            boff[j][k] = P * 64 + ((g ^ ((P >> 1) & 3)) << 4);
+        }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int n_st = p.n_chunks32 * nkh;
+    issue(0, 0);
+    auto stage_fn = [&](int st, auto stage_c) {
+        constexpr int ST = decltype(stage_c)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + 1 < n_st) issue(st + 1, ST ^ 1);
+        const unsigned char* sb = s2_smem + ST * G2_STAGE;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k < nkw) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 afr[2], bfr[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) afr[i] = *reinterpret_cast<const bf16x8*>(sb + ((aoff[i] + k * F2_WT) ^ (kk << 5)));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + (boff[j][k] ^ (kk << 5)));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) mma16(acc[i][j], afr[i], bfr[j]);       // D[cin][pixel]
+                }
+            }
+        }
+    };
+    for (int st = 0; st < n_st; st += 2) {
+        stage_fn(st, std::integral_constant<int, 0>{});
+        if (st + 1 < n_st) stage_fn(st + 1, std::integral_constant<int, 1>{});
+    }
+
+    const unsigned out_bytes = (unsigned)((size_t)p.N * p.H * p.W * p.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.dx, 0, out_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int u = 2 * (a0 + 2 * wave_p + j) + pp, v = 2 * (b0 + l31) + qq;
+        const int obase = (u < p.H && v < p.W) ? (((n * p.H + u) * p.W + v) * p.Cin + ci0 + wave_c * 64 + 8 * g) * 2 : S2_OOB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                float vv[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float qa = acc[i][j][(2 * qp) * 4 + e], qb = acc[i][j][(2 * qp + 1) * 4 + e];
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(qa), __float_as_uint(qb), false, false);
+                    vv[e] = __uint_as_float(r[0]); vv[4 + e] = __uint_as_float(r[1]);
+                }
+                u32x4 o;
+                bf16_t* ob = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ob[e] = (bf16_t)vv[e];
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, obase + (i * 32 + qp * 16) * 2, 0, 0);
+            }
+    }
+}
+
 }  // namespace
 
 static bool s2_wgrad_setup(const MasConvDesc* d, S2WgradParams& p) {
@@ -390,4 +550,42 @@ int mas_conv_s2_fwd_try(const MasConvDesc* d, const void* x, const void* w_packe
     hipLaunchKernelGGL(conv_s2_fwd_kernel, dim3((unsigned)grid), dim3(S2_NT), F2_LDS, s, p);
     MAS_CHECK_LAUNCH("conv_s2_fwd");
     return 1;
+}
+
+static bool s2_dgrad_ok(const MasConvDesc* d) {
+    static const int on = mas_env_int("MAS_CONV_S2", 1);
+    if (!on || !d) return false;
+    if (d->ks != 3 || d->stride != 2 || d->upsample || d->act != MAS_ACT_NONE || d->pad_top != 0 || d->pad_left != 0) return false;
+    if (d->in_dtype != MAS_BF16 || d->out_dtype != MAS_BF16) return false;
+    if (d->Cout % 32 || d->Cin % 128 || d->W < 64) return false;                 // (a, b) blocks of 8 x 32: narrower maps idle half of every tile
+    if ((long long)d->N * d->H * d->W * d->Cin * 2 >= 0x7fffffffLL || (long long)d->N * d->Ho * d->Wo * d->Cout * 2 >= 0x7fffffffLL) return false;
+    return true;
+}
+
+// d describes the FORWARD convolution (Downsample: 3x3, stride 2, pads 0, Ho x Wo its output).  1 if mas_conv_s2_dgrad takes it.
+extern "C" int mas_conv_s2_dgrad_supported(const MasConvDesc* d) { return s2_dgrad_ok(d) ? 1 : 0; }
+
+// dx [N, H, W, Cin] = data gradient of that convolution from dy [N, Ho, Wo, Cout] and the TRANSPOSED K64 weight image
+// (mas_pack_conv_weight_layout(..., transpose = 1, MAS_WLAYOUT_K64)): every dx element written exactly once, no zero-stuffed tensor.
+extern "C" int mas_conv_s2_dgrad(const MasConvDesc* d, const void* dy, const void* w_packed_t, void* dx, void* stream) {
+    MAS_ENTER();
+    if (!d || !dy || !w_packed_t || !dx) MAS_FAIL(MAS_EINVAL, "conv_s2_dgrad: null argument");
+    if (!s2_dgrad_ok(d)) MAS_FAIL(MAS_EUNSUPPORTED, "conv_s2_dgrad: unsupported convolution (mas_conv_s2_dgrad_supported == 0)");
+    S2DgradParams p;
+    p.dy = (const unsigned char*)dy; p.w = (const unsigned char*)w_packed_t; p.dx = (unsigned char*)dx;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+    p.rows_pad = mas_roundup(d->Cin, 128); p.n_chunks32 = d->Cout / 32;
+    p.tiles_h = mas_cdiv((d->H + 1) / 2, F2_TH); p.tiles_w = mas_cdiv((d->W + 1) / 2, F2_TW); p.n_ct = d->Cin / 128;
+    const long long per_class = (long long)d->N * p.tiles_h * p.tiles_w * p.n_ct;
+    if (4 * per_class > 0x7fffffffLL) MAS_FAIL(MAS_EUNSUPPORTED, "conv_s2_dgrad: grid too large");
+    p.per_class = (int)per_class;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess)
+            MAS_FAIL(MAS_ELAUNCH, "conv_s2_dgrad: cannot reserve %d bytes of LDS", G2_LDS);
+        attr = true;
+    }
+    hipLaunchKernelGGL(conv_s2_dgrad_kernel, dim3((unsigned)(4 * per_class)), dim3(S2_NT), G2_LDS, reinterpret_cast<hipStream_t>(stream), p);
+    MAS_CHECK_LAUNCH("conv_s2_dgrad");
+    return MAS_OK;
 }

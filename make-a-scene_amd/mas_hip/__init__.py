@@ -57,6 +57,8 @@ _SIGNATURES = {
     "mas_gn_stats_from_partials": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
     "mas_conv_wgrad": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
     "mas_wgrad_commit": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "mas_conv_s2_dgrad_supported": (_i, [C.POINTER(ConvDesc)]),
+    "mas_conv_s2_dgrad": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p]),
     "mas_conv_wgrad_splits": (_i, [C.POINTER(ConvDesc)]),
     "mas_conv_wgrad_partial": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
     "mas_wgrad_reduce": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _p]),

@@ -657,12 +657,21 @@ class _NormActConv(torch.autograd.Function):
         if need_x or need_gn:
             wt = ConvWeight(weight, True, ctx.w_sources)
             hl, wl = (2 * h, 2 * w) if ups else (h, w)
+            da = None
             if stride == 1:
                 d_in, hd, wd = dy, ho, wo
-            else:  # adjoint of the strided read: zero-stuff dy, then a stride-1 conv
-                hd, wd = (ho - 1) * stride + 1, (wo - 1) * stride + 1
-                d_in = zero_stuff2x(dy, hd, wd)
-            da = conv_fwd_raw(d_in, None, wt, None, None, n, hd, wd, cout, hl, wl, cin, ks, 1, ks - 1 - pt, ks - 1 - pl, ACT_NONE, False, cd)
+            else:
+                dfw = _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, cd, cd, ACT_NONE, ups)
+                if ks == 3 and stride == 2 and lib().mas_conv_s2_dgrad_supported(C.byref(dfw)):
+                    # Downsample: the four parity classes of dx straight from dy (conv_s2.hip), exact FLOPs, no zero-stuffed tensor
+                    wpk = _pack_cache.get(weight, True, cd, WLAYOUT_K64, ctx.w_sources)
+                    da = torch.empty((n, cin, h, w), dtype=cd, device=dy.device, memory_format=torch.channels_last)
+                    check(lib().mas_conv_s2_dgrad(C.byref(dfw), _ptr(dy), _ptr(wpk), _ptr(da), _stream()), "conv_s2_dgrad")
+                else:  # adjoint of the strided read: zero-stuff dy, then a stride-1 conv
+                    hd, wd = (ho - 1) * stride + 1, (wo - 1) * stride + 1
+                    d_in = zero_stuff2x(dy, hd, wd)
+            if da is None:
+                da = conv_fwd_raw(d_in, None, wt, None, None, n, hd, wd, cout, hl, wl, cin, ks, 1, ks - 1 - pt, ks - 1 - pl, ACT_NONE, False, cd)
             if ups:
                 da = sumpool2x(da)
             if act != ACT_NONE:

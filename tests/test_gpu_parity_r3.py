@@ -528,11 +528,14 @@ def test_stride2_wgrad_kernel_vs_cpu_fp32(shape):
     assert relerr(outs[0][0], wr.grad) < 2e-3 and relerr(outs[0][1], dy.float().sum((0, 2, 3))) < 2e-3, shape
 
 
-@pytest.mark.parametrize("shape", [(2, 128, 128, 20, 80), (3, 64, 256, 33, 65), (2, 96, 128, 70, 66), (32, 128, 128, 64, 64), (1, 256, 256, 64, 64)])
+@pytest.mark.parametrize("shape", [(2, 128, 128, 20, 80), (3, 64, 256, 33, 65), (2, 96, 128, 70, 66), (32, 128, 128, 64, 64), (1, 256, 256, 64, 64),
+                                   (2, 128, 224, 33, 71), (1, 128, 64, 130, 128)])
 def test_stride2_forward_kernel_vs_cpu_fp32(shape):
     """Downsample's forward (reference models/modules.py:76-79: pad right / bottom by one, 3x3, stride 2) on conv_s2_fwd_kernel: even and
     odd map sizes, ragged 8 x 32 output tiles, 32-channel chunk counts 2 / 3 / 4 / 8 (odd: the low half of the last 64-channel weight
-    chunk only), two cout tiles; forward with bias and the whole backward through the public op, against F.conv2d / autograd on the CPU."""
+    chunk only), two cout tiles; forward with bias and the whole backward through the public op, against F.conv2d / autograd on the CPU.
+    The data gradient of the shapes with Cin % 128 == 0 and W >= 64 runs on conv_s2_dgrad_kernel (four parity classes straight from dy;
+    odd sizes: the last dx row / column belongs to classes with fewer valid taps), the others on the zero-stuffed stride-1 path."""
     from mas_hip import ops
     dev = _dev()
     n, cin, cout, h, w = shape
