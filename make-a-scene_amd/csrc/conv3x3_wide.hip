@@ -412,9 +412,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
                             bfr[b][j] = *reinterpret_cast<const bf16x8*>(pb + (b_addr(pj0 + (j + kh) * W_PWL + kw) ^ kx));
+#ifdef W_ABL_HALF_A   // timing experiment only (wrong results): 2 of the 4 weight fragments per k-step are not re-read -- 0.5 instead of 0.75
+#pragma unroll        // LDS reads per MFMA: what a 128 x 128 register tile would buy (tools/experiments/gpu_r3_41.sh)
+                        for (int i = 0; i < 2; ++i)
+                            afr[b][i] = *reinterpret_cast<const bf16x8*>(wb + kw * W_WT + i * 2048 + (a_off ^ kx));
+                        if (p.N == -12345) { afr[b][2] = afr[b][0]; afr[b][3] = afr[b][1]; }
+#else
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             afr[b][i] = *reinterpret_cast<const bf16x8*>(wb + kw * W_WT + i * 2048 + (a_off ^ kx));
+#endif
                     };
                     ld_k(0, 0);
 #pragma unroll
