@@ -220,7 +220,7 @@ __global__ __launch_bounds__(TH_NT, 2) void conv_thin_fwd_kernel(ThinFwdParams p
         constexpr int ST = decltype(stage_c)::value;
         // this tile's halo pieces have landed; the 16 stores of the previous tile are YOUNGER than them and stay in flight (in-order retirement)
         if (t == first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                 // (2 rows x 8 row-wise stores)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + stride < p.n_tiles) issue(t + stride, ST ^ 1);
@@ -240,8 +240,10 @@ __global__ __launch_bounds__(TH_NT, 2) void conv_thin_fwd_kernel(ThinFwdParams p
 #pragma unroll
                 for (int i = 0; i < 4; ++i) mma16(acc[i], afr[i][kk], bfr);      // D[cout][pixel]
             }
-            const int oh = th_i * TF_TH + 2 * wave + j, ow = tw_i * TF_TW + l31;
-            const int obase = (oh < p.H && ow < p.W) ? (((n * p.H + oh) * p.W + ow) * 128 + 8 * g) * 2 : TH_OOB;
+            // epilogue through a wave-private LDS tile [32 pixels][256 B] (16-byte slot ^ (pixel & 15)): the accumulators hold, per lane, 16-byte
+            // pieces of 32 DIFFERENT pixel rows -- stored directly (first version) the kernel ran at 3.1 TB/s; read back row-wise, one store
+            // instruction writes four whole 256-byte rows
+            unsigned char* ot = th_smem + TF_LDS + wave * 8192;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -260,11 +262,17 @@ __global__ __launch_bounds__(TH_NT, 2) void conv_thin_fwd_kernel(ThinFwdParams p
                     bf16_t* ob = reinterpret_cast<bf16_t*>(&o);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { ob[e] = (bf16_t)(v[e] + b0[e]); ob[4 + e] = (bf16_t)(v[4 + e] + b1[e]); }
-#ifndef TF_ST_AUX
-#define TF_ST_AUX 0
-#endif
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, obase + (32 * i + 16 * qp) * 2, 0, TF_ST_AUX);
+                    *reinterpret_cast<u32x4*>(ot + l31 * 256 + (((4 * i + 2 * qp + g) ^ (l31 & 15)) << 4)) = o;
                 }
+            const int oh = th_i * TF_TH + 2 * wave + j;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = 4 * k + (lane >> 4), sl_ = lane & 15;
+                const u32x4 o = *reinterpret_cast<const u32x4*>(ot + r * 256 + ((sl_ ^ (r & 15)) << 4));
+                const int ow = tw_i * TF_TW + r;
+                const int off = (oh < p.H && ow < p.W) ? ((n * p.H + oh) * p.W + ow) * 256 + sl_ * 16 : TH_OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, off, 0, 0);
+            }
         }
     };
     for (int t = first; t < p.n_tiles; t += 2 * stride) {
@@ -327,7 +335,7 @@ int mas_conv_thin_fwd_try(const MasConvDesc* d, const void* x, const void* w_pac
     p.tiles_h = mas_cdiv(d->H, TF_TH); p.tiles_w = mas_cdiv(d->W, TF_TW); p.n_tiles = d->N * p.tiles_h * p.tiles_w;
     int grid = 8 * mas_num_cus();                                                // two resident work-groups per CU, four rounds
     if (grid > p.n_tiles) grid = p.n_tiles;
-    hipLaunchKernelGGL(conv_thin_fwd_kernel, dim3((unsigned)grid), dim3(TH_NT), TF_LDS, s, p);
+    hipLaunchKernelGGL(conv_thin_fwd_kernel, dim3((unsigned)grid), dim3(TH_NT), TF_LDS + 4 * 8192, s, p);
     MAS_CHECK_LAUNCH("conv_thin_fwd");
     return 1;
 }
