@@ -1,0 +1,111 @@
+"""CPU restatements of the index algebra the round-3 kernels are built on, checked against torch's own convolution / autograd.
+No GPU, no library: these pin the DECOMPOSITIONS (which taps a parity class owns, which way the thin tensor is shifted, how a 1x1
+weight gradient is a pixel-contraction GEMM), so that a GPU parity failure can be told apart from a wrong derivation.
+
+  * conv_s2.hip  conv_s2_dgrad_kernel: dx by parity class (u & 1, v & 1), taps kh in {0, 2} / {1}, dy row (u >> 1) - (kh >> 1)
+  * conv_s2.hip  conv_s2_fwd_kernel / wgrad_s2_kernel: x pixel (2 i + kh, 2 j + kw), zero beyond the map (the one-sided padding)
+  * conv_thin.hip wgrad_thin_kernel: D[(tap, cs)][cb] = sum_p S[p + sgn (tap - 1)][cs] * B[p][cb], sgn = -1 (conv_out) / +1 (conv_in)
+  * conv1x1.hip  wgrad1x1_kernel + mas_wgrad_reduce: split-K over pixel chunks, slabs added in a fixed order
+(reference sites: models/modules.py:62-81 Downsample, :219 conv_in, :345 conv_out, :106-108 / :145-160 the 1x1 layers)"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def _rand(*shape, seed=0):
+    return torch.from_numpy(np.random.default_rng(seed).standard_normal(shape).astype(np.float64))
+
+
+@pytest.mark.parametrize("h,w", [(8, 10), (9, 7), (12, 5)])
+def test_stride2_data_gradient_by_parity_class(h, w):
+    n, cin, cout = 2, 3, 4
+    x = _rand(n, cin, h, w, seed=1).requires_grad_(True)
+    wt = _rand(cout, cin, 3, 3, seed=2)
+    y = F.conv2d(F.pad(x, (0, 1, 0, 1)), wt, stride=2)
+    dy = _rand(*y.shape, seed=3)
+    y.backward(dy)
+    ho, wo = y.shape[2:]
+    dx = torch.zeros_like(x)
+    for p in (0, 1):
+        for q in (0, 1):
+            for kh in ((0, 2) if p == 0 else (1,)):
+                for kw in ((0, 2) if q == 0 else (1,)):
+                    for u in range(p, h, 2):
+                        a = (u >> 1) - (kh >> 1)
+                        if not 0 <= a < ho:
+                            continue
+                        for v in range(q, w, 2):
+                            b = (v >> 1) - (kw >> 1)
+                            if 0 <= b < wo:
+                                dx[:, :, u, v] += torch.einsum("no,oi->ni", dy[:, :, a, b], wt[:, :, kh, kw])
+    assert torch.allclose(dx, x.grad, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("h,w", [(8, 10), (9, 7)])
+def test_stride2_forward_and_weight_gradient_addressing(h, w):
+    n, cin, cout = 2, 3, 4
+    x = _rand(n, cin, h, w, seed=4)
+    wt = _rand(cout, cin, 3, 3, seed=5).requires_grad_(True)
+    y = F.conv2d(F.pad(x, (0, 1, 0, 1)), wt, stride=2)
+    dy = _rand(*y.shape, seed=6)
+    y.backward(dy)
+    ho, wo = y.shape[2:]
+
+    def xat(i, j):                                    # zero beyond the map: the padded row / column is never materialised
+        return x[:, :, i, j] if i < h and j < w else torch.zeros(n, cin, dtype=x.dtype)
+
+    yy = torch.zeros_like(y)
+    dw = torch.zeros_like(wt)
+    for i in range(ho):
+        for j in range(wo):
+            for kh in range(3):
+                for kw in range(3):
+                    xv = xat(2 * i + kh, 2 * j + kw)
+                    yy[:, :, i, j] += torch.einsum("ni,oi->no", xv, wt[:, :, kh, kw].detach())
+                    dw[:, :, kh, kw] += torch.einsum("no,ni->oi", dy[:, :, i, j], xv)
+    assert torch.allclose(yy, y.detach(), rtol=1e-10, atol=1e-10)
+    assert torch.allclose(dw, wt.grad, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("big_is_x", [True, False])
+def test_thin_weight_gradient_is_a_shifted_pixel_contraction(big_is_x):
+    """conv_out (big = x with 128 -> here 6 channels, thin = dy) and conv_in (big = dy, thin = x): one formula, sgn = -1 / +1."""
+    n, h, w, cb, cs = 2, 5, 6, 6, 2
+    cin, cout = (cb, cs) if big_is_x else (cs, cb)
+    x = _rand(n, cin, h, w, seed=7)
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    dy = _rand(n, cout, h, w, seed=8)
+    F.conv2d(x, wt, padding=1).backward(dy)
+    big, thin, sgn = (x, dy, -1) if big_is_x else (dy, x, 1)
+    d = torch.zeros(9, cs, cb, dtype=torch.float64)   # D[(tap, cs)][cb]
+    for tap in range(9):
+        kh, kw = divmod(tap, 3)
+        for i in range(h):
+            for j in range(w):
+                si, sj = i + sgn * (kh - 1), j + sgn * (kw - 1)
+                if 0 <= si < h and 0 <= sj < w:       # out-of-range halo pixels read as zeros
+                    d[tap] += torch.einsum("ns,nb->sb", thin[:, :, si, sj], big[:, :, i, j])
+    got = d.permute(1, 0, 2).reshape(cs, 3, 3, cb).permute(0, 3, 1, 2) if big_is_x else d.permute(2, 1, 0).reshape(cb, cs, 3, 3)
+    assert torch.allclose(got, wt.grad, rtol=1e-10, atol=1e-10)
+
+
+def test_pointwise_weight_gradient_split_k_slabs_in_fixed_order():
+    """dW[co][ci] = sum_p dy[p][co] a[p][ci] over 64-pixel chunks dealt round-robin to nsplit work-groups; the slabs are added in slab
+    order, so the result does not depend on which work-group finishes first -- and equals autograd's up to fp32 summation order."""
+    m, cin, cout, nsplit = 1000, 8, 12, 5
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal((m, cin)).astype(np.float32)
+    dy = rng.standard_normal((m, cout)).astype(np.float32)
+    n_chunks = (m + 63) // 64
+    slabs = np.zeros((nsplit, cout, cin), np.float32)
+    for c in range(n_chunks):
+        sl = slice(64 * c, min(m, 64 * c + 64))
+        slabs[c % nsplit] += dy[sl].T @ a[sl]
+    dw = np.zeros((cout, cin), np.float32)
+    for sp in range(nsplit):                          # fixed order
+        dw = dw + slabs[sp]
+    ref = dy.astype(np.float64).T @ a.astype(np.float64)
+    assert np.abs(dw - ref).max() < 1e-3 * np.abs(ref).max()
+    again = sum(slabs[sp] for sp in range(nsplit))    # the same order again: bitwise the same
+    assert np.array_equal(dw, np.asarray(again, np.float32))
