@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAS_ABI_VERSION 3
+#define MAS_ABI_VERSION 4
 
 enum { MAS_OK = 0, MAS_EINVAL = -1, MAS_EUNSUPPORTED = -2, MAS_ELAUNCH = -3, MAS_EWORKSPACE = -4 };
 enum { MAS_F32 = 0, MAS_BF16 = 1 };
@@ -105,6 +105,17 @@ size_t mas_gn_bwd_workspace(int N, int C);
 int    mas_gn_bwd(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G,
                   int act, const float* gamma, const float* mean_rstd, const float* scale_shift,
                   void* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, void* stream);
+/* mas_gn_bwd runs bf16 tensors as ONE persistent launch (reduce -> finalize -> apply per image group, the groups pipelined; the
+ * apply phase re-reads x / da from the Infinity Cache: HBM sees them once) and hands every other case to mas_gn_bwd_3pass: the same
+ * arithmetic as three launches (x and da read twice).  Same arguments, same workspace; both are bitwise reproducible run to run
+ * (their sums are partitioned differently, so they agree with each other to fp32 rounding, not bit for bit).                      */
+int    mas_gn_bwd_3pass(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G,
+                        int act, const float* gamma, const float* mean_rstd, const float* scale_shift,
+                        void* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, void* stream);
+/* How mas_gn_bwd would run a bf16 tensor on a device with num_cus compute units (host arithmetic only, no device call): returns 1
+ * and fills plan[10] = {threads per work-group, work-groups, row ranges per image, images per group, groups, channel slices per image,
+ * channels per slice, pipeline depth, ring slots, task-owner multiplier} for the one-launch kernel, 0 for the three-launch path.      */
+int    mas_gn_bwd_plan(int N, int HW, int C, int G, int num_cus, int* plan);
 
 /* ---- materialised GroupNorm(+SiLU) output: a [N,HW,C] = act(x * scale + shift), scale_shift [N][C][2] from mas_gn_stats, act
  * MAS_ACT_AFFINE or MAS_ACT_AFFINE_SILU, rounded to `dtype` exactly as the fused loaders of mas_conv_fwd / mas_conv_wgrad round it

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MAS_HIP_LIB") or os.path.join(_HERE, "libmas_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_AFFINE, ACT_AFFINE_SILU = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 WLAYOUT_K64, WLAYOUT_K32 = 0, 1
 
 
@@ -48,6 +48,8 @@ _SIGNATURES = {
     "mas_gn_stats": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _sz, _p]),
     "mas_gn_bwd_workspace": (_sz, [_i, _i]),
     "mas_gn_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "mas_gn_bwd_3pass": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "mas_gn_bwd_plan": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int)]),
     "mas_gn_act": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "mas_conv_fwd": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p]),
     "mas_conv_stat_rows": (_i, [C.POINTER(ConvDesc)]),

@@ -332,15 +332,18 @@ def gn_act(x: torch.Tensor, ss: torch.Tensor, act: int) -> torch.Tensor:
     return a
 
 
-def gn_bwd(x, da, dres, groups, act, gamma, mr, ss):
+def gn_bwd(x, da, dres, groups, act, gamma, mr, ss, three_pass=False):
+    """GroupNorm(+SiLU) backward: (dx [+ dres], dgamma, dbeta).  bf16: one persistent launch that reads x / da from HBM once
+    (``mas_gn_bwd``); ``three_pass`` forces the reduce / finalize / apply launches (``mas_gn_bwd_3pass``: fp32's path, tests, A/B)."""
     n, c, h, w = x.shape
     dx = torch.empty_like(x, memory_format=torch.channels_last)
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
     wsb = lib().mas_gn_bwd_workspace(n, c)
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
-    check(lib().mas_gn_bwd(_ptr(x), _ptr(da), _ptr(dres), _DT[x.dtype], n, h * w, c, groups, act, _ptr(gamma), _ptr(mr), _ptr(ss),
-                           _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), wsb, _stream()), "gn_bwd")
+    fn = lib().mas_gn_bwd_3pass if three_pass else lib().mas_gn_bwd
+    check(fn(_ptr(x), _ptr(da), _ptr(dres), _DT[x.dtype], n, h * w, c, groups, act, _ptr(gamma), _ptr(mr), _ptr(ss),
+             _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), wsb, _stream()), "gn_bwd")
     return dx, dgamma, dbeta
 
 

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--act", type=int, default=0)
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--three", type=int, default=-1, help="gn_bwd: 1 = the three-launch path, 0 = the one-launch kernel, -1 = both")
     ap.add_argument("--dtype", default="bf16")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -75,8 +76,12 @@ def main():
         g, bta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
         mr, ss = ops.gn_stats(x, g, bta, 32, 1e-6)
         da = torch.randn_like(x)
-        ms = timeit(lambda: ops.gn_bwd(x, da, None, 32, a.act or 2, g, mr, ss), a.iters)
-        print(f"gn_bwd n={n} c={c} hw={h}: {ms:.4f} ms  {5*x.numel()*esz/ms/1e6:.1f} GB/s (2 reads x2 + 1 write)")
+        dres = torch.randn_like(x) if a.res else None
+        for three in ((False, True) if a.three < 0 else (bool(a.three),)):
+            ms = timeit(lambda: ops.gn_bwd(x, da, dres, 32, a.act or 2, g, mr, ss, three_pass=three), a.iters)
+            alg = (3 + (1 if a.res else 0)) * x.numel() * esz     # x, da (, dres) read once, dx written once
+            print(f"gn_bwd[{'three launches' if three else 'one launch'}] n={n} c={c} hw={h} res={a.res}: {ms:.4f} ms  "
+                  f"{alg/ms/1e6:.1f} GB/s algorithmic (x + da{' + dres' if a.res else ''} + dx once)")
     elif a.kind == "gn_act":
         g, bta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
         mr, ss = ops.gn_stats(x, g, bta, 32, 1e-6)
