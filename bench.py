@@ -343,8 +343,10 @@ def run_vq(args):
         opt.zero_grad(set_to_none=reducer is None)
         return loss
 
+    torch.cuda.reset_peak_memory_stats(dev)
     dt, final_loss = _timed(step, args, ddp, dev, on_start=lambda on: dom.__setitem__("on", on))
     ops.set_launch_hook(None)
+    peak_gib = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     spread = _replica_spread(model, ddp)
 
     if rank == 0:
@@ -359,6 +361,10 @@ def run_vq(args):
             "final_loss": round(final_loss, 5),
             "replica_weight_checksum_spread": spread,
             "model_tflops_per_gpu": round(value / world * FWD_BWD_GFLOP_PER_IMG / 1e3, 1),
+            # allocator high-water mark of the step: the materialised GroupNorm+SiLU tensors (MAS_GN_MATERIALIZE=1) are saved
+            # for the weight gradients on top of the GroupNorm inputs -- about +12 GiB at batch 32; MAS_GN_MATERIALIZE=0 trades them
+            # for the slower fused loaders ("Memory")
+            "peak_memory_gib": round(peak_gib, 2),
         }
         n_ev = len(dom["plain"]) + len(dom["gn_silu"])
         if n_ev:

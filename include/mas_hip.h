@@ -105,16 +105,23 @@ size_t mas_gn_bwd_workspace(int N, int C);
 int    mas_gn_bwd(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G,
                   int act, const float* gamma, const float* mean_rstd, const float* scale_shift,
                   void* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, void* stream);
-/* mas_gn_bwd runs bf16 tensors as ONE persistent launch (reduce -> finalize -> apply per image group, the groups pipelined; the
- * apply phase re-reads x / da from the Infinity Cache: HBM sees them once) and hands every other case to mas_gn_bwd_3pass: the same
- * arithmetic as three launches (x and da read twice).  Same arguments, same workspace; both are bitwise reproducible run to run
- * (their sums are partitioned differently, so they agree with each other to fp32 rounding, not bit for bit).                      */
+/* Two implementations behind mas_gn_bwd, both callable directly (same arguments, same workspace, both bitwise reproducible run to
+ * run; their sums are partitioned differently, so they agree with each other to fp32 rounding, not bit for bit):
+ *   mas_gn_bwd_3pass  reduce / finalize / apply as three launches; x and da are read twice.  Every dtype and shape.
+ *   mas_gn_bwd_1pass  bf16: ONE persistent launch, reduce -> finalize -> apply per image group with the groups pipelined through
+ *                     in-launch counters; the apply phase re-reads x / da from the Infinity Cache, HBM sees them once.
+ *                     MAS_EUNSUPPORTED when the tensor has no plan (mas_gn_bwd_plan) or the grid would not be co-resident.
+ * mas_gn_bwd picks the one measured faster on MI355X: the three launches (profiles/r04_gn_coop_v1.txt); MAS_GN_BWD_ONE_LAUNCH=1
+ * makes it try mas_gn_bwd_1pass first.                                                                                              */
 int    mas_gn_bwd_3pass(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G,
                         int act, const float* gamma, const float* mean_rstd, const float* scale_shift,
                         void* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, void* stream);
-/* How mas_gn_bwd would run a bf16 tensor on a device with num_cus compute units (host arithmetic only, no device call): returns 1
- * and fills plan[10] = {threads per work-group, work-groups, row ranges per image, images per group, groups, channel slices per image,
- * channels per slice, pipeline depth, ring slots, task-owner multiplier} for the one-launch kernel, 0 for the three-launch path.      */
+int    mas_gn_bwd_1pass(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G,
+                        int act, const float* gamma, const float* mean_rstd, const float* scale_shift,
+                        void* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, void* stream);
+/* How mas_gn_bwd_1pass would run a bf16 tensor on a device with num_cus compute units (host arithmetic only, no device call):
+ * returns 1 and fills plan[10] = {threads per work-group, work-groups, row ranges per image, images per group, groups, channel slices per image,
+ * channels per slice, pipeline depth, ring slots, task-owner multiplier}; 0 when the tensor has no one-launch plan.                  */
 int    mas_gn_bwd_plan(int N, int HW, int C, int G, int num_cus, int* plan);
 
 /* ---- materialised GroupNorm(+SiLU) output: a [N,HW,C] = act(x * scale + shift), scale_shift [N][C][2] from mas_gn_stats, act
@@ -148,16 +155,6 @@ int mas_conv_fwd_stats(const MasConvDesc* d, const void* x, const float* scale_s
 int mas_gn_stats_from_partials(const float* partial, int N, int HW, int C, int G, int rows, float eps, const float* gamma,
                                const float* beta, float* mean_rstd, float* scale_shift, void* stream);
 
-/* Activation side output: mas_conv_fwd_act is mas_conv_fwd (act != NONE) that ALSO writes the activated input it forms in its loader,
- * act_out [N,H,W,Cin] in_dtype = act(x * scale + shift) rounded to in_dtype -- exactly the operand the weight gradient of the same
- * convolution needs (autograd of modules.py:121-128 + the F.conv2d that follows), so that mas_conv_wgrad can run on act_out with
- * act = NONE instead of recomputing GroupNorm+SiLU in its loader.  Every pixel is written by exactly one tile (deterministic).
- * Supported iff mas_conv_act_out_supported(d) != 0 (bf16 3x3 stride-1 "same" convolutions on the wide kernel; act_out < 2 GiB);
- * act_out == NULL makes it mas_conv_fwd.                                                                                            */
-int mas_conv_act_out_supported(const MasConvDesc* d);
-int mas_conv_fwd_act(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed,
-                     const float* bias, const void* residual, void* y, void* act_out, void* stream);
-
 /* ---- convolution weight gradient  (autograd of the F.conv2d sites above)
  *   dw [Cout][ks][ks][Cin] fp32 (caller zero-fills; accumulated with fp32 atomics),
  *   dbias [Cout] fp32 or NULL (same).  x / scale_shift / act as in mas_conv_fwd
@@ -182,14 +179,6 @@ int mas_conv_wgrad_partial(const MasConvDesc* d, const void* x, const float* sca
                            float* part, float* part_bias, void* stream);
 int mas_wgrad_reduce(const float* part, const float* part_bias, int nsplit, float* dw_oihw, float* dbias, int Cout, int Cin, int ks,
                      void* stream);
-
-/* ---- CU partitioning (optional; overlap of HBM-bound passes with MFMA-bound kernels).  mas_stream_create_cu_range returns a HIP
- * stream whose kernels run only on CUs [first, first + count) (hipExtStreamCreateWithCUMask); mas_set_cu_budget(n) makes the
- * split-K weight-gradient grids size themselves for n CUs instead of the whole chip (0 = all).  Streams are the caller's to
- * destroy (mas_stream_destroy).                                                                                                 */
-int mas_set_cu_budget(int cus);
-int mas_stream_create_cu_range(int first, int count, void** stream_out);
-int mas_stream_destroy(void* stream);
 
 /* ---- vector quantiser  (replaces Codebook.forward's distance / argmin / gather / loss,
  * modules.py:501-509; never materialises d[M,K]).

@@ -302,10 +302,11 @@ int mas_conv1x1_try(const MasConvDesc* d, const void* x, const void* w_packed, c
     p.a = (const unsigned char*)x; p.w = (const unsigned char*)w_packed; p.bias = bias; p.res = (const unsigned char*)residual; p.y = (unsigned char*)y;
     p.M = (int)M; p.K = d->Cin; p.N = d->Cout;
     p.rows_pad = mas_roundup(d->Cout, 128); p.n_chunks = d->Cin / 64; p.n_nt = d->Cout / 128;
-    static bool attr = false;                   // (64 KiB of dynamic LDS needs no opt-in on gfx950; kept for symmetry with the other launchers)
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
-        attr = true;
+    static mas_devmask_t attr{0};               // per device, like every other launcher (mas_common.h)
+    unsigned long long attr_bit;
+    if (mas_attr_needed(attr, &attr_bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        mas_attr_done(attr, attr_bit);
     }
     const long long grid = (M + 127) / 128 * p.n_nt;
     hipLaunchKernelGGL(conv1x1_kernel, dim3((unsigned)grid), dim3(PW_NT), PW_LDS, s, p);
@@ -323,7 +324,7 @@ static bool pw_wgrad_setup(const MasConvDesc* d, PwWgradParams& p) {
     p.M = (int)M; p.Cout = d->Cout; p.Cin = d->Cin; p.n_co_t = d->Cout / 128; p.n_ci_t = d->Cin / 128;
     p.n_chunks = (int)((M + 63) / 64);
     const int tiles = p.n_co_t * p.n_ci_t;
-    int ns = mas_cdiv(2 * mas_cu_budget(), tiles);                               // two work-groups per CU
+    int ns = mas_cdiv(2 * mas_num_cus(), tiles);                               // two work-groups per CU
     if (ns > p.n_chunks / 2) ns = p.n_chunks / 2;                                 // at least two chunks per work-group
     if (ns > 256) ns = 256;
     if (ns < 1) ns = 1;

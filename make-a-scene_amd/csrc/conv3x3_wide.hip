@@ -32,7 +32,6 @@ struct WideParams {
     unsigned long long* dbg;                   // -DW_TIMELINE builds only
     const unsigned char* x; const float* ss; const unsigned char* w; const float* bias; const unsigned char* res; unsigned char* y;
     float* stats;                              // optional [N][tiles_h * tiles_w][Cout][2]: per-tile sum / sum of squares of the bf16 OUTPUT (the consumer's GroupNorm statistics)
-    unsigned char* act_out;                    // optional [N,H,W,Cin] bf16 (ACT only): the activated input, written once per pixel as a side output
     int N, H, W, Cin, Ho, Wo, Cout;
     int Hl, Wl, pad_top, pad_left, upsample, act;
     int n_chunks, Cout_pad, tiles_h, tiles_w, n_ct;
@@ -82,14 +81,8 @@ __device__ __forceinline__ void w_wait_barrier(int n) {   // n is a compile-time
 
 // ACT: GroupNorm(+SiLU) prologue (in-place activation of the raw patch).  RES: residual add in the epilogue.
 // STATS: per-tile sum / sum of squares of the output channels (the consumer's GroupNorm statistics) written to p.stats.
-// AOUT (ACT only): the activated input a = act(x * scale + shift), bf16, is also written to p.act_out -- every in-image pixel by
-//        exactly one tile (the tile whose OUTPUT pixels it lies under; cout tile 0 only).  The weight gradient of the same
-//        convolution then reads `a` with a prologue-free loader instead of recomputing GroupNorm+SiLU on x (conv_wgrad_dma.hip:
-//        0.655 ms plain vs 0.79 ms with the prologue at 128->128 @256^2).  The values pass through this thread's registers on
-//        their way back to LDS anyway: the side output costs two VALU and one 16-byte store per slot.
-template <bool ACT, bool RES, bool STATS, bool AOUT = false>
+template <bool ACT, bool RES, bool STATS>
 __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
-    static_assert(ACT || !AOUT, "the activation side output needs the prologue");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const wbuf = smem + W_WBUF;
     unsigned char* const patch = smem + W_PBUF;
@@ -105,9 +98,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.w), 0,
                                                                            (unsigned)(9 * p.n_chunks * p.Cout_pad * 64), 0x00020000);
 
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(AOUT ? p.act_out : p.y, 0,
-                                                                           AOUT ? (unsigned)((size_t)p.N * img_bytes) : 0u, 0x00020000);
-    const int img_b = (int)img_bytes;           // (AOUT: N * img_bytes < 2^31, checked by the host)
 
     // ---- tiles: persistent work-group, static stride.  Divisions by the (runtime) tile-grid extents are multiply-high by
     //      host-made reciprocals: hipcc's generic 32-bit division keeps ~10 SGPRs of loop-invariant temporaries alive per
@@ -197,14 +187,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
     // lets them fly on (a store in front of the DMA would have to be acknowledged before the in-order wait for the DMA returns:
     // measured +0.09 ms per launch).  ALWAYS exactly 5 store instructions per wave (dead slots: out-of-range offset, dropped by the
     // descriptor's bounds check): the counted waits depend on it.
-    u32x4 av[AOUT ? W_NSLOT : 1];
-    int ao[AOUT ? W_NSLOT : 1];
-    auto p_activate = [&](unsigned inb_mask, int buf, const int (&vo_)[W_NSLOT], bool writer) {   // padding pixels were written as zeros by the DMA and stay zero
+    auto p_activate = [&](unsigned inb_mask, int buf) {   // padding pixels were written as zeros by the DMA and stay zero
 #pragma unroll
         for (int k = 0; k < W_NSLOT; ++k) {
             int q, pr, pc;
             const bool live = slot_pix(k, q, pr, pc) && (k < 4 || wave < 7) && ((inb_mask >> k) & 1u);
-            if constexpr (AOUT) { ao[k] = W_OOB; av[k] = u32x4{0u, 0u, 0u, 0u}; }
             if (!live) continue;
             unsigned char* dst = patch + buf * W_PATCH + q * 64 + (((lane & 3) ^ ((q >> 2) & 3)) << 4);
             u32x4 v = *reinterpret_cast<const u32x4*>(dst);
@@ -216,21 +203,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                 for (int q4 = 0; q4 < 4; ++q4) v[q4] = act_pair_bf16<false>(v[q4], f32x2{sc[2 * q4], sc[2 * q4 + 1]}, f32x2{sh[2 * q4], sh[2 * q4 + 1]});
             }
             *reinterpret_cast<u32x4*>(dst) = v;
-            if constexpr (AOUT) {
-                // interior of the tile (the pixels under this tile's outputs): each image pixel belongs to exactly one tile.
-                // vo_[k] addresses the SOURCE slot sl = (lane & 3) ^ ((q >> 2) & 3) of the pixel inside its image; the activated
-                // values are LOGICAL slot lane & 3: flip the two slot bits back
-                const bool inner = (unsigned)(pr - p.pad_top) < 16u && (unsigned)(pc - p.pad_left) < 32u && writer;
-                av[k] = v;
-                ao[k] = inner ? (vo_[k] ^ (((q >> 2) & 3) << 4)) : W_OOB;
-            }
-        }
-    };
-    // rs_a: one descriptor over the whole act_out tensor; soff = the image's byte offset + the chunk's
-    auto aout_store = [&](__amdgpu_buffer_rsrc_t rs_a, int soff) {
-        if constexpr (AOUT) {
-#pragma unroll
-            for (int k = 0; k < W_NSLOT; ++k) __builtin_amdgcn_raw_buffer_store_b128(av[k], rs_a, ao[k], soff, 0);
         }
     };
 
@@ -285,8 +257,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
         ss_stage(n_cur, 0);
         W_WAIT_BARRIER(0);                       // the raw patch of chunk 0 has landed for every wave, the table is visible
         ss_fetch(0, 0);
-        p_activate(inb_cur, 0, vo, c0_cur == 0);
-        aout_store(rs_a, n_cur * img_b);
+        p_activate(inb_cur, 0);
     }
     if (p.stagger > 0) {
         const int n = (int)((blockIdx.x * 5u) % 8u) * p.stagger;
@@ -336,16 +307,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                 //      vmcnt allowance = VMEM operations issued AFTER the weight DMA in the previous stage
                 {
                     constexpr int khp = (kh + 2) % 3;         // filter row of the previous stage
-                    constexpr int allow = khp == 0 ? (ACT ? 5 : 3) : (khp == 1 ? (ACT ? 0 : 2) : (AOUT ? 5 : 0));   // khp == 2: the side-output stores
+                    constexpr int allow = khp == 0 ? (ACT ? 5 : 3) : (khp == 1 ? (ACT ? 0 : 2) : 0);
                     if (s == 0 && pair == 0 && stores_in_flight) {
                         w_wait_barrier(32); stores_in_flight = false;
                         if constexpr (STATS) stats_flush();      // the finished tile's statistics: one store, older than this stage's weight DMA
                     } else w_wait_barrier(allow);      // one store, older than this stage's weight DMA
                 }
                 if (pair < 2) WTS(2 + 3 * (pair * 6 + s));
-                // ---- the next tile's plan, and GroupNorm(+SiLU) in place on the NEXT chunk's raw patch (all of it has landed: allowance 0
-                //      above).  Order: plan first (the shipped schedule) -- except with the activation side output, whose stores of
-                //      chunk B of the last pair still address the CURRENT tile through `vo`
+                // ---- the next tile's plan, and GroupNorm(+SiLU) in place on the NEXT chunk's raw patch (all of it has landed: allowance 0 above)
                 auto plan_blk = [&]() {
                     if (s == 2 && last_pair && has_next) {        // the next tile's plan (used by the chunk-B stages 3, 4); without a next
                         const Tile nt = decode(next_tile);        // tile the current one is re-fetched, harmlessly
@@ -358,7 +327,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                                                                  (unsigned)img_bytes, 0x00020000);
                     }
                 };
-                int aout_soff = 0;
                 auto act_blk = [&]() {
                     if constexpr (ACT) {
                         if (kh == 2) {
@@ -367,18 +335,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                             else ss_fetch(ss_sel, ciA + 64);
                             const bool nxt = cb == 1 && last_pair;                 // chunk 0 of the NEXT tile (its plan is in `vo` since stage 2)
                             // (without a next tile this stage re-activates the current tile's chunk 0 with a scale/shift table that was never
-                            //  staged -- harmless for the convolution, which never reads it, but not to be stored)
-                            const bool writer = AOUT && (nxt ? c0_nxt : c0_cur) == 0 && !(nxt && !has_next);
-                            if constexpr (AOUT) {
-                                const int ch_off = cb == 0 ? (ciA + 32) * 2 : (last_pair ? 0 : (ciA + 64) * 2);
-                                aout_soff = (nxt ? n_nxt : n_cur) * img_b + ch_off;
-                            }
-                            p_activate(nxt ? inb_nxt : inb_cur, cb ^ 1, vo, writer);
+                            //  staged -- harmless: the convolution never reads it)
+                            p_activate(nxt ? inb_nxt : inb_cur, cb ^ 1);
                             asm volatile("" ::: "memory");
                         }
                     }
                 };
-                if constexpr (AOUT) { act_blk(); plan_blk(); } else { plan_blk(); act_blk(); }
+                plan_blk(); act_blk();
                 // ---- weight DMA for the next stage
                 {
                     const int tn = (s < 5) ? (pair * 2 + (s + 1) / 3) * 9 + ((s + 1) % 3) * 3 : (last_pair ? 0 : (pair + 1) * 18);
@@ -386,9 +349,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
                     w_issue(tn, c0n, wsel ^ 1);
                 }
                 asm volatile("" ::: "memory");                // VMEM order = source order: the counted waits depend on it
-                if constexpr (AOUT) {
-                    if (kh == 2) { aout_store(rs_a, aout_soff); asm volatile("" ::: "memory"); }   // 5 stores, the youngest VMEM operations of this stage
-                }
                 // ---- patch DMA for the next chunk (3 pieces in the kh = 0 stage, 2 in the kh = 1 stage)
                 if (kh < 2 && !(ACT && kh == 1)) {
                     // plain: 3 + 2 pieces over the kh = 0, 1 stages.  With the prologue all 5 in the kh = 0 stage: the activation that
@@ -565,9 +525,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
     }
 }
 
-template <bool ACT, bool RES, bool STATS, bool AOUT = false>
+template <bool ACT, bool RES, bool STATS>
 int launch_wide(const WideParams& p, hipStream_t s) {
-    auto kern = conv3x3_wide_kernel<ACT, RES, STATS, AOUT>;
+    auto kern = conv3x3_wide_kernel<ACT, RES, STATS>;
     static mas_devmask_t attr_mask{0};
     unsigned long long attr_bit;
     if (mas_attr_needed(attr_mask, &attr_bit)) {
@@ -611,22 +571,11 @@ bool mas_conv3x3_wide_eligible(const MasConvDesc* d) {
 // rows per image of the statistics table the wide kernel can fill for this convolution (its 16x32-pixel tiles)
 int mas_conv3x3_wide_stat_rows(const MasConvDesc* d) { return mas_cdiv(d->Ho, 16) * mas_cdiv(d->Wo, 32); }
 
-// Can the wide kernel also write the activated input (MasConvDesc.act != NONE) as a side output?
-bool mas_conv3x3_wide_act_out_ok(const MasConvDesc* d) {
-    static const int on = mas_env_int("MAS_CONV_ACT_OUT", 1);
-    if (!on || d->act == MAS_ACT_NONE || d->upsample || !mas_conv3x3_wide_eligible(d)) return false;
-    if (d->Ho != d->H || d->Wo != d->W) return false;                       // "same" convolutions: tile interiors partition the input image
-    return (long long)d->N * d->H * d->W * d->Cin * 2 < 0x7fffffffLL;      // one descriptor + 31-bit offsets over the whole tensor
-}
-
 int mas_conv3x3_wide_launch(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed, const float* bias,
-                            const void* residual, void* y, float* stats, void* act_out, hipStream_t s) {
+                            const void* residual, void* y, float* stats, hipStream_t s) {
     WideParams p;
     p.dbg = nullptr;
     p.stats = stats;
-    p.act_out = (unsigned char*)act_out;
-    if (act_out && (stats || !mas_conv3x3_wide_act_out_ok(d)))
-        MAS_FAIL(MAS_EUNSUPPORTED, "conv3x3_wide: no activation side output for this convolution (mas_conv_act_out_supported == 0, or fused statistics requested)");
 #ifdef W_TIMELINE
     if (const char* e = getenv("MAS_DBG_PTR")) p.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
 #endif
@@ -645,7 +594,6 @@ int mas_conv3x3_wide_launch(const MasConvDesc* d, const void* x, const float* sc
         if (d->act != MAS_ACT_NONE) return residual ? launch_wide<true, true, true>(p, s) : launch_wide<true, false, true>(p, s);
         return residual ? launch_wide<false, true, true>(p, s) : launch_wide<false, false, true>(p, s);
     }
-    if (act_out) return residual ? launch_wide<true, true, false, true>(p, s) : launch_wide<true, false, false, true>(p, s);
     if (d->act != MAS_ACT_NONE) return residual ? launch_wide<true, true, false>(p, s) : launch_wide<true, false, false>(p, s);
     return residual ? launch_wide<false, true, false>(p, s) : launch_wide<false, false, false>(p, s);
 }

@@ -609,8 +609,7 @@ int mas_conv3x3_stream_try(const MasConvDesc* d, const void* x, const float* sca
                            const void* residual, void* y, hipStream_t s);   // conv3x3_stream.hip
 bool mas_conv3x3_wide_eligible(const MasConvDesc* d);                        // conv3x3_wide.hip
 int mas_conv3x3_wide_launch(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed, const float* bias,
-                            const void* residual, void* y, float* stats, void* act_out, hipStream_t s);
-bool mas_conv3x3_wide_act_out_ok(const MasConvDesc* d);
+                            const void* residual, void* y, float* stats, hipStream_t s);
 int mas_conv3x3_wide_stat_rows(const MasConvDesc* d);
 int mas_conv1x1_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s);
 int mas_conv_thin_fwd_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s);
@@ -628,26 +627,11 @@ extern "C" int mas_conv_weight_layout(const MasConvDesc* d) {
 }
 
 static int conv_fwd_impl(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed,
-                         const float* bias, const void* residual, void* y, float* stats, void* act_out, void* stream);
-
-// Can mas_conv_fwd_act also write the activated input act(x * scale + shift) of this convolution (act != NONE) as a side output?
-extern "C" int mas_conv_act_out_supported(const MasConvDesc* d) {
-    if (!d || d->w_layout != MAS_WLAYOUT_K32) return 0;
-    return mas_conv3x3_wide_act_out_ok(d) ? 1 : 0;
-}
+                         const float* bias, const void* residual, void* y, float* stats, void* stream);
 
 extern "C" int mas_conv_fwd(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed,
                             const float* bias, const void* residual, void* y, void* stream) {
-    return conv_fwd_impl(d, x, scale_shift, w_packed, bias, residual, y, nullptr, nullptr, stream);
-}
-
-extern "C" int mas_conv_fwd_act(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed,
-                                const float* bias, const void* residual, void* y, void* act_out, void* stream) {
-    if (act_out && mas_conv_act_out_supported(d) == 0) {
-        MAS_ENTER();
-        MAS_FAIL(MAS_EUNSUPPORTED, "conv_fwd_act: this convolution's kernel has no activation side output (mas_conv_act_out_supported == 0)");
-    }
-    return conv_fwd_impl(d, x, scale_shift, w_packed, bias, residual, y, nullptr, act_out, stream);
+    return conv_fwd_impl(d, x, scale_shift, w_packed, bias, residual, y, nullptr, stream);
 }
 
 extern "C" int mas_conv_fwd_stats(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed,
@@ -656,11 +640,11 @@ extern "C" int mas_conv_fwd_stats(const MasConvDesc* d, const void* x, const flo
         MAS_ENTER();
         MAS_FAIL(MAS_EUNSUPPORTED, "conv_fwd_stats: this convolution does not take a kernel with fused statistics (mas_conv_stat_rows == 0)");
     }
-    return conv_fwd_impl(d, x, scale_shift, w_packed, bias, residual, y, stats_partial, nullptr, stream);
+    return conv_fwd_impl(d, x, scale_shift, w_packed, bias, residual, y, stats_partial, stream);
 }
 
 static int conv_fwd_impl(const MasConvDesc* d, const void* x, const float* scale_shift, const void* w_packed,
-                         const float* bias, const void* residual, void* y, float* stats, void* act_out, void* stream) {
+                         const float* bias, const void* residual, void* y, float* stats, void* stream) {
     MAS_ENTER();
     if (!d || !x || !w_packed || !y) MAS_FAIL(MAS_EINVAL, "conv_fwd: null argument");
     if (d->act != MAS_ACT_NONE && !scale_shift) MAS_FAIL(MAS_EINVAL, "conv_fwd: act prologue needs scale_shift");
@@ -670,7 +654,7 @@ static int conv_fwd_impl(const MasConvDesc* d, const void* x, const float* scale
     if ((long long)d->H * d->W * d->Cin > 0x7fffffffLL) MAS_FAIL(MAS_EUNSUPPORTED, "conv_fwd: one image exceeds 2^31 elements");
     if (d->w_layout == MAS_WLAYOUT_K32) {   // the caller packed for the wide 3x3 kernel (mas_conv_weight_layout said so)
         if (!mas_conv3x3_wide_eligible(d)) MAS_FAIL(MAS_EINVAL, "conv_fwd: w_layout K32 but this convolution does not take the wide kernel");
-        return mas_conv3x3_wide_launch(d, x, scale_shift, w_packed, bias, residual, y, stats, act_out, reinterpret_cast<hipStream_t>(stream));
+        return mas_conv3x3_wide_launch(d, x, scale_shift, w_packed, bias, residual, y, stats, reinterpret_cast<hipStream_t>(stream));
     }
     if (d->w_layout != MAS_WLAYOUT_K64) MAS_FAIL(MAS_EINVAL, "conv_fwd: bad w_layout %d", d->w_layout);
     {   // the FLOP-carrying shapes (3x3, stride 1, bf16, Cin/Cout multiples of 128) take the stream-scheduled kernel

@@ -500,7 +500,7 @@ static bool s2_wgrad_setup(const MasConvDesc* d, S2WgradParams& p) {
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
     p.tiles_h = mas_cdiv(d->Ho, S2_TH); p.tiles_w = mas_cdiv(d->Wo, S2_TW); p.n_tiles = d->N * p.tiles_h * p.tiles_w;
     p.n_co_t = d->Cout / 128; p.n_ci_t = d->Cin / 64;
-    int ns = mas_cdiv(mas_cu_budget(), p.n_co_t * p.n_ci_t);                      // one 108-KiB work-group per CU
+    int ns = mas_cdiv(mas_num_cus(), p.n_co_t * p.n_ci_t);                      // one 108-KiB work-group per CU
     if (ns > p.n_tiles) ns = p.n_tiles;
     if (ns < 1) ns = 1;
     p.nsplit = ns;
@@ -517,10 +517,11 @@ int mas_wgrad_s2_partial(const MasConvDesc* d, const void* x, const void* dy, fl
     S2WgradParams p;
     if (!s2_wgrad_setup(d, p)) return 0;
     p.x = (const unsigned char*)x; p.dy = (const unsigned char*)dy; p.part = part; p.part_bias = part_bias;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_s2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS) != hipSuccess) return 0;
-        attr = true;
+    static mas_devmask_t attr{0};               // the dynamic-LDS limit is a per-DEVICE attribute (mas_common.h)
+    unsigned long long attr_bit;
+    if (mas_attr_needed(attr, &attr_bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_s2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        mas_attr_done(attr, attr_bit);
     }
     hipLaunchKernelGGL(wgrad_s2_kernel, dim3((unsigned)(p.n_co_t * p.n_ci_t * p.nsplit)), dim3(S2_NT), S2_LDS, s, p);
     MAS_CHECK_LAUNCH("wgrad_s2");
@@ -542,10 +543,11 @@ int mas_conv_s2_fwd_try(const MasConvDesc* d, const void* x, const void* w_packe
     p.tiles_h = mas_cdiv(d->Ho, F2_TH); p.tiles_w = mas_cdiv(d->Wo, F2_TW); p.n_ct = d->Cout / 128;
     const long long grid = (long long)d->N * p.tiles_h * p.tiles_w * p.n_ct;
     if (grid > 0x7fffffffLL) return 0;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS) != hipSuccess) return 0;
-        attr = true;
+    static mas_devmask_t attr{0};               // the dynamic-LDS limit is a per-DEVICE attribute (mas_common.h)
+    unsigned long long attr_bit;
+    if (mas_attr_needed(attr, &attr_bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        mas_attr_done(attr, attr_bit);
     }
     hipLaunchKernelGGL(conv_s2_fwd_kernel, dim3((unsigned)grid), dim3(S2_NT), F2_LDS, s, p);
     MAS_CHECK_LAUNCH("conv_s2_fwd");
@@ -579,11 +581,12 @@ extern "C" int mas_conv_s2_dgrad(const MasConvDesc* d, const void* dy, const voi
     const long long per_class = (long long)d->N * p.tiles_h * p.tiles_w * p.n_ct;
     if (4 * per_class > 0x7fffffffLL) MAS_FAIL(MAS_EUNSUPPORTED, "conv_s2_dgrad: grid too large");
     p.per_class = (int)per_class;
-    static bool attr = false;
-    if (!attr) {
+    static mas_devmask_t attr{0};
+    unsigned long long attr_bit;
+    if (mas_attr_needed(attr, &attr_bit)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess)
             MAS_FAIL(MAS_ELAUNCH, "conv_s2_dgrad: cannot reserve %d bytes of LDS", G2_LDS);
-        attr = true;
+        mas_attr_done(attr, attr_bit);
     }
     hipLaunchKernelGGL(conv_s2_dgrad_kernel, dim3((unsigned)(4 * per_class)), dim3(S2_NT), G2_LDS, reinterpret_cast<hipStream_t>(stream), p);
     MAS_CHECK_LAUNCH("conv_s2_dgrad");

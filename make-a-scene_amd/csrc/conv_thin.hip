@@ -299,7 +299,7 @@ static bool thin_wgrad_setup(const MasConvDesc* d, ThinWgradParams& p, bool& big
     } else {             // dW[co = cb][tap][ci = cs]; x pixel = dy pixel + (tap - 1); the bias gradient sums dy = B
         p.sgn = 1; p.col_stride = 72; p.tap_stride = 8; p.cs_stride = 1; p.bias_small = 0;
     }
-    int ns = 2 * mas_cu_budget();
+    int ns = 2 * mas_num_cus();
     if (ns > p.n_tiles / 4) ns = p.n_tiles / 4;
     if (ns < 1) ns = 1;
     p.nsplit = ns;

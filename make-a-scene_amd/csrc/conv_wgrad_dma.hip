@@ -532,7 +532,7 @@ static bool dma_setup(const MasConvDesc* d, DmaWgradParams& p) {
     // and a grid of exactly one work-group per CU runs the displaced ones as a second FULL round; MAS_WGRAD_OVERSUB=2 (bench.py sets
     // it for N > 1) halves the work-groups so the hardware rebalances at half-round granularity, for 2x the split-K partials.
     static const int oversub = mas_env_int("MAS_WGRAD_OVERSUB", 1);
-    int nsplit = mas_cdiv(mas_cu_budget() * (oversub > 0 ? oversub : 1), out_tiles);     // (mas_set_cu_budget: a masked stream's share of the chip)
+    int nsplit = mas_cdiv(mas_num_cus() * (oversub > 0 ? oversub : 1), out_tiles);
     if (nsplit > p.n_pt) nsplit = p.n_pt;
     if (nsplit < 1) nsplit = 1;
     p.nsplit = nsplit;

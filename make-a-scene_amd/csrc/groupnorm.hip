@@ -963,12 +963,11 @@ int gn_coop_blocks_per_cu(int T, size_t lds) {                       // co-resid
 
 // false: this shape stays on the three-launch path
 bool gn_coop_plan(int N, int HW, int C, int G, int ncu, GnCoopPlan* pl) {
-    static const int on = mas_env_int("MAS_GN_COOP", 1);
     static const int threads = mas_env_int("MAS_GN_COOP_THREADS", 512);
     static const int per_cu_env = mas_env_int("MAS_GN_COOP_WGS_PER_CU", 2);
     static const int depth = mas_env_int("MAS_GN_COOP_DEPTH", 2);
     static const int units_per_thread = mas_env_int("MAS_GN_COOP_UNITS", 4);
-    if (!on || C % 8 || C % G) return false;
+    if (C % 8 || C % G) return false;
     const int upp = C / 8, cpg = C / G;
     int T = threads;
     if (T != 256 && T != 512 && T != 1024) T = 512;
@@ -1041,38 +1040,51 @@ static int gn_bwd_check(const void* x, const void* da, const void* dx, int dtype
     return MAS_OK;
 }
 
-extern "C" int mas_gn_bwd(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G, int act,
-                          const float* gamma, const float* mean_rstd, const float* scale_shift, void* dx, float* dgamma,
-                          float* dbeta, void* workspace, size_t ws_bytes, void* stream) {
+// One persistent launch (gn_bwd_coop_kernel).  MAS_EUNSUPPORTED when the shape has no one-launch plan (fp32, channel counts whose
+// 16-byte units do not divide the work-group) or the planned grid would not be co-resident on this device.
+extern "C" int mas_gn_bwd_1pass(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G, int act,
+                                const float* gamma, const float* mean_rstd, const float* scale_shift, void* dx, float* dgamma,
+                                float* dbeta, void* workspace, size_t ws_bytes, void* stream) {
     MAS_ENTER();
     const int rc0 = gn_bwd_check(x, da, dx, dtype, N, HW, C, G, act, mean_rstd, scale_shift, workspace, ws_bytes);
     if (rc0 != MAS_OK) return rc0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool silu = act == MAS_ACT_AFFINE_SILU;
-    // bf16 (the benched mode): ONE persistent launch, x and da read from HBM once (gn_bwd_coop_kernel)
     GnCoopPlan pl;
-    if (dtype == MAS_BF16 && gn_coop_plan(N, HW, C, G, mas_num_cus(), &pl)) {
-        GnCoopParams prm;
-        prm.x = (const bf16_t*)x; prm.da = (const bf16_t*)da; prm.dres = (const bf16_t*)dres; prm.dx = (bf16_t*)dx;
-        prm.mean_rstd = mean_rstd; prm.ss = scale_shift; prm.gamma = gamma;
-        unsigned char* wsp = reinterpret_cast<unsigned char*>(workspace);
-        prm.rows = reinterpret_cast<unsigned long long*>(wsp);
-        wsp += (size_t)pl.R * pl.Gi * pl.nsplit * C * 8;
-        prm.coef = reinterpret_cast<float*>(wsp); wsp += (size_t)N * C * 16;
-        prm.nsum = reinterpret_cast<float*>(wsp); wsp += (size_t)N * C * 8;
-        prm.cnt = reinterpret_cast<unsigned*>(wsp);
-        prm.dgamma = dgamma; prm.dbeta = dbeta;
-        prm.N = N; prm.HW = HW; prm.C = C; prm.G = G; prm.nsplit = pl.nsplit; prm.Gi = pl.Gi; prm.NG = pl.NG; prm.NS = pl.NS; prm.CS = pl.CS;
-        prm.D = pl.D; prm.R = pl.R; prm.mult = pl.mult; prm.rev = gn_reverse();
-        int rc;
-        if (silu && dres) rc = gn_coop_launch<true, true>(pl, prm, s);
-        else if (silu) rc = gn_coop_launch<true, false>(pl, prm, s);
-        else if (dres) rc = gn_coop_launch<false, true>(pl, prm, s);
-        else rc = gn_coop_launch<false, false>(pl, prm, s);
-        if (rc == 0) {
-            MAS_CHECK_LAUNCH("gn_bwd_coop");
-            return MAS_OK;
-        }
+    if (dtype != MAS_BF16 || !gn_coop_plan(N, HW, C, G, mas_num_cus(), &pl)) MAS_FAIL(MAS_EUNSUPPORTED, "gn_bwd_1pass: no one-launch plan for this tensor");
+    GnCoopParams prm;
+    prm.x = (const bf16_t*)x; prm.da = (const bf16_t*)da; prm.dres = (const bf16_t*)dres; prm.dx = (bf16_t*)dx;
+    prm.mean_rstd = mean_rstd; prm.ss = scale_shift; prm.gamma = gamma;
+    unsigned char* wsp = reinterpret_cast<unsigned char*>(workspace);
+    prm.rows = reinterpret_cast<unsigned long long*>(wsp);
+    wsp += (size_t)pl.R * pl.Gi * pl.nsplit * C * 8;
+    prm.coef = reinterpret_cast<float*>(wsp); wsp += (size_t)N * C * 16;
+    prm.nsum = reinterpret_cast<float*>(wsp); wsp += (size_t)N * C * 8;
+    prm.cnt = reinterpret_cast<unsigned*>(wsp);
+    prm.dgamma = dgamma; prm.dbeta = dbeta;
+    prm.N = N; prm.HW = HW; prm.C = C; prm.G = G; prm.nsplit = pl.nsplit; prm.Gi = pl.Gi; prm.NG = pl.NG; prm.NS = pl.NS; prm.CS = pl.CS;
+    prm.D = pl.D; prm.R = pl.R; prm.mult = pl.mult; prm.rev = gn_reverse();
+    int rc;
+    if (silu && dres) rc = gn_coop_launch<true, true>(pl, prm, s);
+    else if (silu) rc = gn_coop_launch<true, false>(pl, prm, s);
+    else if (dres) rc = gn_coop_launch<false, true>(pl, prm, s);
+    else rc = gn_coop_launch<false, false>(pl, prm, s);
+    if (rc != 0) MAS_FAIL(MAS_EUNSUPPORTED, "gn_bwd_1pass: %d work-groups of %d threads would not be co-resident", pl.W, pl.T);
+    MAS_CHECK_LAUNCH("gn_bwd_coop");
+    return MAS_OK;
+}
+
+// The entry point the autograd nodes call: whichever path is faster for the tensor.  Measured on MI355X (profiles/r04_gn_coop_v1.txt):
+// the one-launch kernel reads x / da from HBM once but its per-group hand-offs cost more than the second read saves -- 0.61 vs 0.48 ms
+// at 128 ch @256^2 x 32, slower at every shape of VQ-IMG -- so the three-launch path is the default and MAS_GN_BWD_ONE_LAUNCH=1 selects
+// the persistent kernel where it has a plan.
+extern "C" int mas_gn_bwd(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G, int act,
+                          const float* gamma, const float* mean_rstd, const float* scale_shift, void* dx, float* dgamma,
+                          float* dbeta, void* workspace, size_t ws_bytes, void* stream) {
+    static const int one = mas_env_int("MAS_GN_BWD_ONE_LAUNCH", 0);
+    if (one && dtype == MAS_BF16) {
+        const int rc = mas_gn_bwd_1pass(x, da, dres, dtype, N, HW, C, G, act, gamma, mean_rstd, scale_shift, dx, dgamma, dbeta, workspace, ws_bytes, stream);
+        if (rc != MAS_EUNSUPPORTED) return rc;
     }
     return mas_gn_bwd_3pass(x, da, dres, dtype, N, HW, C, G, act, gamma, mean_rstd, scale_shift, dx, dgamma, dbeta, workspace, ws_bytes, stream);
 }

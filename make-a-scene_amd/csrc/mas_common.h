@@ -26,7 +26,6 @@ void mas_set_error(const char* fmt, ...);
 #define MAS_ENTER() do { (void)hipGetLastError(); } while (0)
 
 int mas_num_cus();   // compute units of the CURRENT device (cached per device)
-int mas_cu_budget(); // CUs the split-K grids size themselves for: mas_set_cu_budget(n), default all of them
 
 // One process per GPU is the contract (include/mas_hip.h), but a second device in the same process (nn.DataParallel,
 // reference train.py:177) must still launch correctly: per-function attributes such as the dynamic-LDS limit are set

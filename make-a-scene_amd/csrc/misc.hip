@@ -24,40 +24,6 @@ int mas_num_cus() {
     return c;
 }
 
-// ---- CU budget / CU-masked streams (overlap of the HBM-bound passes with the MFMA-bound kernels, DESIGN R3.3).  The budget is what
-// the persistent / split-K grids size themselves for instead of the whole chip (0 = all CUs); a masked stream confines the
-// kernels launched on it to CUs [first, first + count) of the runtime's CU enumeration.
-static std::atomic<int> g_cu_budget{0};
-int mas_cu_budget() {
-    const int b = g_cu_budget.load(std::memory_order_relaxed);
-    const int n = mas_num_cus();
-    return (b > 0 && b < n) ? b : n;
-}
-extern "C" int mas_set_cu_budget(int cus) {
-    MAS_ENTER();
-    if (cus < 0) MAS_FAIL(MAS_EINVAL, "set_cu_budget: negative");
-    g_cu_budget.store(cus, std::memory_order_relaxed);
-    return MAS_OK;
-}
-extern "C" int mas_stream_create_cu_range(int first, int count, void** stream_out) {
-    MAS_ENTER();
-    const int n = mas_num_cus();
-    if (!stream_out || first < 0 || count <= 0 || first + count > n) MAS_FAIL(MAS_EINVAL, "stream_create_cu_range: bad range [%d, %d) of %d CUs", first, first + count, n);
-    uint32_t mask[32] = {0};
-    const int words = (n + 31) / 32;
-    for (int i = first; i < first + count; ++i) mask[i >> 5] |= 1u << (i & 31);
-    hipStream_t s = nullptr;
-    const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
-    if (e != hipSuccess) MAS_FAIL(MAS_ELAUNCH, "hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
-    *stream_out = reinterpret_cast<void*>(s);
-    return MAS_OK;
-}
-extern "C" int mas_stream_destroy(void* stream) {
-    MAS_ENTER();
-    if (stream && hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)) != hipSuccess) MAS_FAIL(MAS_ELAUNCH, "hipStreamDestroy failed");
-    return MAS_OK;
-}
-
 extern "C" const char* mas_last_error(void) { return g_err; }
 extern "C" int mas_abi_version(void) {
     MAS_ENTER(); return MAS_ABI_VERSION; }

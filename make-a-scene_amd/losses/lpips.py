@@ -13,7 +13,8 @@ What the reference does at construction and this module cannot: it downloads ``v
 ``LPIPS().state_dict()`` saved from the reference), or from the reference's path if that file exists, plus ``MAS_VGG16_CKPT``
 (torchvision's VGG16 state_dict) for the backbone when the first file holds the heads only -- as the reference's ``vgg.pth``
 does.  Every tensor still at its random initialisation afterwards is named in a warning (``LPIPS.unloaded``;
-``MAS_LPIPS_STRICT=1`` raises instead) -- the loss is then a perceptual distance in name only."""
+an error by default, as in the reference, whose constructor cannot run without its weight files; ``MAS_LPIPS_STRICT=0`` makes it a
+warning) -- the loss is then a perceptual distance in name only."""
 import os
 import warnings
 
@@ -116,8 +117,8 @@ class LPIPS(nn.Module):
         ``vgg.pth`` for the five ``lin<k>`` heads (lpips.py:55-57, ``strict=False``) -- that file alone leaves the 13 backbone
         convolutions untouched.  Here: ``MAS_LPIPS_CKPT`` (or the reference's ``vgg.pth`` path) may hold either the whole module's
         state_dict or the heads only; ``MAS_VGG16_CKPT`` may hold torchvision's ``vgg16().state_dict()`` / ``vgg16().features
-        .state_dict()`` for the backbone.  Whatever is still at its random initialisation afterwards is reported LOUDLY, by name
-        (``self.unloaded``); ``MAS_LPIPS_STRICT=1`` turns that report into an error."""
+        .state_dict()`` for the backbone.  Whatever is still at its random initialisation afterwards is an ERROR naming the tensors
+        (``self.unloaded``); ``MAS_LPIPS_STRICT=0`` turns it into a warning."""
         want = set(self.state_dict().keys()) - {"scaling_layer.shift", "scaling_layer.scale"}
         loaded = set()
         for path in CKPT_PATHS:
@@ -146,8 +147,8 @@ class LPIPS(nn.Module):
                "vgg16 state_dict, or MAS_LPIPS_CKPT to a full state_dict of the reference's LPIPS module; heads: %d of 5 -- "
                "MAS_LPIPS_CKPT / vgg.pth); the perceptual term is NOT a perceptual distance until they are loaded.  Missing: %s"
                % (len(self.unloaded), len(want), len(backbone), len(heads), ", ".join(self.unloaded[:6]) + (" ..." if len(self.unloaded) > 6 else "")))
-        if os.environ.get("MAS_LPIPS_STRICT", "0") == "1":
-            raise RuntimeError(msg)
+        if os.environ.get("MAS_LPIPS_STRICT", "1") == "1":      # the default: the reference fails hard on missing weights too (lpips.py:15,55)
+            raise RuntimeError(msg + "  (MAS_LPIPS_STRICT=0 downgrades this to a warning: tests, arithmetic checks with synthetic weights)")
         if loaded or not LPIPS._warned:       # a PARTIAL load (e.g. vgg.pth alone: heads without backbone) is reported every time
             LPIPS._warned = True
             warnings.warn(msg)

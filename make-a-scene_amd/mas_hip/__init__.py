@@ -49,12 +49,11 @@ _SIGNATURES = {
     "mas_gn_bwd_workspace": (_sz, [_i, _i]),
     "mas_gn_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "mas_gn_bwd_3pass": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "mas_gn_bwd_1pass": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "mas_gn_bwd_plan": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int)]),
     "mas_gn_act": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "mas_conv_fwd": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p]),
     "mas_conv_stat_rows": (_i, [C.POINTER(ConvDesc)]),
-    "mas_conv_act_out_supported": (_i, [C.POINTER(ConvDesc)]),
-    "mas_conv_fwd_act": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
     "mas_conv_fwd_stats": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
     "mas_gn_stats_from_partials": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
     "mas_conv_wgrad": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
@@ -64,9 +63,6 @@ _SIGNATURES = {
     "mas_conv_wgrad_splits": (_i, [C.POINTER(ConvDesc)]),
     "mas_conv_wgrad_partial": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
     "mas_wgrad_reduce": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _p]),
-    "mas_set_cu_budget": (_i, [_i]),
-    "mas_stream_create_cu_range": (_i, [_i, _i, C.POINTER(C.c_void_p)]),
-    "mas_stream_destroy": (_i, [_p]),
     "mas_vq_workspace": (_sz, [_i, _i]),
     "mas_vq_argmin_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "mas_vq_bwd": (_i, [_p, _p, _p, _p, _p, _f, _i, _i, _i, _p, _p, _p]),

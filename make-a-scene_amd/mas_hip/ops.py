@@ -332,16 +332,17 @@ def gn_act(x: torch.Tensor, ss: torch.Tensor, act: int) -> torch.Tensor:
     return a
 
 
-def gn_bwd(x, da, dres, groups, act, gamma, mr, ss, three_pass=False):
-    """GroupNorm(+SiLU) backward: (dx [+ dres], dgamma, dbeta).  bf16: one persistent launch that reads x / da from HBM once
-    (``mas_gn_bwd``); ``three_pass`` forces the reduce / finalize / apply launches (``mas_gn_bwd_3pass``: fp32's path, tests, A/B)."""
+def gn_bwd(x, da, dres, groups, act, gamma, mr, ss, path=None):
+    """GroupNorm(+SiLU) backward: (dx [+ dres], dgamma, dbeta).  ``path`` None: ``mas_gn_bwd`` (the library's choice: the faster of
+    the two on MI355X); "three": reduce / finalize / apply launches (``mas_gn_bwd_3pass``); "one": the persistent kernel that reads
+    x / da from HBM once (``mas_gn_bwd_1pass``, bf16; raises where the tensor has no plan)."""
     n, c, h, w = x.shape
     dx = torch.empty_like(x, memory_format=torch.channels_last)
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
     wsb = lib().mas_gn_bwd_workspace(n, c)
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
-    fn = lib().mas_gn_bwd_3pass if three_pass else lib().mas_gn_bwd
+    fn = {None: lib().mas_gn_bwd, "three": lib().mas_gn_bwd_3pass, "one": lib().mas_gn_bwd_1pass}[path]
     check(fn(_ptr(x), _ptr(da), _ptr(dres), _DT[x.dtype], n, h * w, c, groups, act, _ptr(gamma), _ptr(mr), _ptr(ss),
              _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), wsb, _stream()), "gn_bwd")
     return dx, dgamma, dbeta
@@ -363,45 +364,22 @@ def _preferred_layout(d: ConvDesc) -> int:
 
 
 _stat_rows_memo = {}
-_act_out_memo = {}
-# Activation side output (mas_conv_fwd_act): the forward convolution of a GroupNorm(+SiLU)-fed layer also writes the activated input
-# it forms in its loader; the weight gradient of that layer then runs prologue-free on it instead of recomputing the activation.
-# OFF by default (MAS_CONV_ACT_OUT=1 turns it on).  Measured on one box, VQ-IMG step (profiles/r03_ab_v2.txt): the weight gradients
-# gain 2.3 ms per step (0.73 -> 0.585 ms at 128->128 @256^2), but the 537 MB the producing convolution now also writes cost it
-# +0.10 ms per launch (0.66 -> 0.76 ms, wherever in the stage the stores are issued: with or without a counted wait behind them) =
-# 1.9 ms per step: 67.65 vs 68.06 ms, 0.6 %, for one more saved tensor per layer (12 GB at batch 32) and a dominant-kernel roofline
-# fraction of 0.40 instead of 0.44.  Not worth shipping; kept, tested, as an option.
-_ACT_OUT = os.environ.get("MAS_CONV_ACT_OUT", "0") == "1"
 
 
-def _act_out_supported(d: ConvDesc) -> bool:
-    key = tuple(getattr(d, f) for f, _ in ConvDesc._fields_)
-    ok = _act_out_memo.get(key)
-    if ok is None:
-        fn = getattr(lib(), "mas_conv_act_out_supported", None)
-        ok = _act_out_memo[key] = bool(fn is not None and fn(C.byref(d)))
-    return ok
-
-
-def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, upsample, out_dtype, want_stats=False,
-                 want_act=None):
+def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, upsample, out_dtype, want_stats=False):
     """``wp``: a ``ConvWeight`` (packed here in the layout the library prefers for this convolution) or an already packed
     K64 image from ``pack_conv_weight`` (always accepted; the call then stays on the kernels that read K64).
     ``want_stats``: returns (y, partial, rows) -- the per-tile channel sums of y for the GroupNorm that consumes it
-    (``mas_conv_fwd_stats``), or (y, None, 0) when this convolution's kernel has no fused statistics.
-    ``want_act`` not None: the result tuple gains a last element -- with ``want_act`` true and a prologue, the activated input
-    act(x * scale + shift) in x's dtype and layout as written by the kernel (``mas_conv_fwd_act``); None when ``want_act`` is false or
-    this convolution's kernel has no such side output."""
+    (``mas_conv_fwd_stats``), or (y, None, 0) when this launch has no fused statistics: kernels other than the wide one, and the
+    wide kernel's GroupNorm+SiLU-loader variants (they are at the register limit: the statistics epilogue costs them +0.07 ms per launch
+    against the 0.10 ms pass it removes, with 17 more spilled registers -- profiles/r03_kernel_trace_encoder_fwd.txt)."""
     y = _empty_nhwc(n, cout, ho, wo, out_dtype, x.device)
     d = _desc(n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, x.dtype, out_dtype, act, upsample)
     if isinstance(wp, ConvWeight):
         d.w_layout = _preferred_layout(d)
         wp = _pack_cache.get(wp.w, wp.transpose, x.dtype, d.w_layout, wp.sources)
     partial, rows = None, 0
-    act_out = None
-    if want_act and _ACT_OUT and act != ACT_NONE and not (want_stats and _stats_state["on"]) and _act_out_supported(d):
-        act_out = torch.empty_like(x, memory_format=torch.channels_last)
-    if want_stats and _stats_state["on"]:
+    if want_stats and _stats_state["on"] and act == ACT_NONE:
         key = tuple(getattr(d, f) for f, _ in ConvDesc._fields_)
         rows = _stat_rows_memo.get(key)
         if rows is None:
@@ -410,10 +388,7 @@ def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stri
             partial = torch.empty(n * rows * cout * 2, dtype=torch.float32, device=x.device)
 
     def launch():
-        if act_out is not None:
-            check(lib().mas_conv_fwd_act(C.byref(d), _ptr(x), _ptr(ss), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), _ptr(act_out),
-                                         _stream()), "conv_fwd_act")
-        elif partial is not None:
+        if partial is not None:
             check(lib().mas_conv_fwd_stats(C.byref(d), _ptr(x), _ptr(ss), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), _ptr(partial),
                                            _stream()), "conv_fwd_stats")
         else:
@@ -424,9 +399,8 @@ def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stri
     else:
         launch()
     if want_stats:
-        res = (y, partial, (rows if partial is not None else 0))
-        return res + (act_out,) if want_act is not None else res
-    return (y, act_out) if want_act is not None else y
+        return y, partial, (rows if partial is not None else 0)
+    return y
 
 
 def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, upsample, want_bias):
@@ -513,51 +487,6 @@ _CONV1X1 = os.environ.get("MAS_CONV1X1", "1") == "1"                 # (read by 
 _WGRAD_PARTIALS = os.environ.get("MAS_WGRAD_PARTIALS", "1") == "1"   # 0: the fp32-atomic commit everywhere (A/B switch)
 _wgrad_partials = {}
 
-# --------------------------------------------------------------------------- #
-# overlap of the HBM-bound GroupNorm backward with the MFMA-bound weight gradient (ResnetBlock backward)
-# --------------------------------------------------------------------------- #
-# The backward of a ResnetBlock is a chain  dgrad -> GroupNorm backward -> dgrad -> GroupNorm backward  with two weight gradients
-# hanging off it.  A weight gradient owns every CU it runs on (138 KB of LDS, all VGPRs) and leaves HBM mostly idle; a GroupNorm
-# backward streams 2.7 GB and leaves the matrix cores idle.  With MAS_OVERLAP=1 each weight gradient is launched on a CU-masked
-# stream covering 256 - G compute units and the GroupNorm backward that follows the same layer's data gradient on a second masked
-# stream covering the other G (MAS_OVERLAP_GN_CUS, default 112): the pair runs side by side and is joined back into the caller's
-# stream before the node returns.  tools/probes/overlap_probe.py measures the pair in isolation (profiles/r03_overlap_probe.txt).
-_OVERLAP = os.environ.get("MAS_OVERLAP", "0") == "1"
-_overlap_state = {}
-
-
-def _overlap_streams(device):
-    st = _overlap_state.get(device.index)
-    if st is None:
-        import ctypes
-        from . import lib as _lib
-        gcus = int(os.environ.get("MAS_OVERLAP_GN_CUS", "112"))
-        ncu = torch.cuda.get_device_properties(device).multi_processor_count
-        if not 0 < gcus < ncu:
-            raise RuntimeError(f"MAS_OVERLAP_GN_CUS={gcus}: need 0 < G < {ncu}")
-
-        def mk(first, count):
-            p = ctypes.c_void_p()
-            check(_lib().mas_stream_create_cu_range(first, count, ctypes.byref(p)), "stream_create_cu_range")
-            return torch.cuda.ExternalStream(p.value, device=device)
-
-        st = _overlap_state[device.index] = (mk(0, gcus), mk(gcus, ncu - gcus), ncu - gcus)
-    return st
-
-
-class _cu_budget:
-    """weight gradients launched inside size their split-K grids for `cus` compute units (their masked stream's share)"""
-
-    def __init__(self, cus):
-        self.cus = cus
-
-    def __enter__(self):
-        check(lib().mas_set_cu_budget(self.cus), "set_cu_budget")
-
-    def __exit__(self, *exc):
-        check(lib().mas_set_cu_budget(0), "set_cu_budget")
-
-
 def upsample2x(x):
     n, c, h, w = x.shape
     y = _empty_nhwc(n, c, 2 * h, 2 * w, x.dtype, x.device)
@@ -625,13 +554,19 @@ class _NormActConv(torch.autograd.Function):
         # without a weight gradient to share the tensor with (512 -> 1536 @16^2: 6 + 22 us against 52)
         pointwise = (ks == 1 and stride == 1 and not ups and pt == 0 and pl == 0 and _CONV1X1 and cin % 64 == 0 and cout % 128 == 0
                      and x.dtype == torch.bfloat16 and cfg["out_dtype"] == torch.bfloat16)
-        if act != ACT_NONE and _MATERIALIZE and ((need_wgrad and ks == 3 and not ups) or pointwise) and _gn_act_ok(cin, x.dtype):
-            a = gn_act(x, ss, act)                  # both consumers (this convolution, its weight gradient) run prologue-free on it
+        a = None
+        if act != ACT_NONE and _MATERIALIZE and ((ks == 3 and not ups) or pointwise) and _gn_act_ok(cin, x.dtype):
+            # the activation as a tensor: this convolution (and, with a weight gradient, that too) runs prologue-free on it.  Also
+            # without a second consumer (torch.no_grad(), frozen weights): 0.20 + 0.50 ms beats the fused loader's 0.73 ms at
+            # 128 ch @256^2 (0.20 + 0.60 against 0.93 with the residual epilogue), 6 + 51 us against 74 us at 512 ch @16^2
+            a = gn_act(x, ss, act)
             y, ypart, yrows = conv_fwd_raw(a, None, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ACT_NONE, ups,
                                            cfg["out_dtype"], want_stats=True)
+            if not need_wgrad:
+                a = None                            # nothing in the backward reads it: not saved
         else:
-            y, ypart, yrows, a = conv_fwd_raw(x, ss, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups,
-                                              cfg["out_dtype"], want_stats=True, want_act=bool(need_wgrad and act != ACT_NONE))
+            y, ypart, yrows = conv_fwd_raw(x, ss, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups,
+                                           cfg["out_dtype"], want_stats=True)
         _stats_state["stash"] = (ypart, yrows) if ypart is not None else None
         ctx.cfg = cfg
         ctx.dims = (n, h, w, cin, ho, wo, cout, ks)
@@ -727,16 +662,16 @@ class _ResBlock(torch.autograd.Function):
         f32 = lambda t: t.detach().float()
         mr1, ss1 = gn_stats(x, f32(n1w), f32(n1b), groups, eps, xpart, xrows)
         ng = ctx.needs_input_grad
-        mat = _MATERIALIZE and grad and _gn_act_ok(c, x.dtype)
+        mat = _MATERIALIZE and _gn_act_ok(c, x.dtype)
 
         def conv(inp, ss_, wgt, bia, resid, need_w):
-            """-> (output, statistics table, rows, activated input or None)"""
-            if mat and need_w:
+            """-> (output, statistics table, rows, activated input if the backward wants it)"""
+            if mat:                                  # (with or without a weight gradient to share it with: see _NormActConv.forward)
                 a_ = gn_act(inp, ss_, ACT_AFFINE_SILU)
                 return conv_fwd_raw(a_, None, ConvWeight(wgt, False), f32(bia), resid, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_NONE, False, cd,
-                                    want_stats=True) + (a_,)
+                                    want_stats=True) + (a_ if grad and need_w else None,)
             return conv_fwd_raw(inp, ss_, ConvWeight(wgt, False), f32(bia), resid, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU, False,
-                                cd, want_stats=True, want_act=bool(grad and need_w))
+                                cd, want_stats=True) + (None,)
 
         hh, hpart, hrows, a1 = conv(x, ss1, c1w, c1b, None, ng[3] or ng[4])
         mr2, ss2 = gn_stats(hh, f32(n2w), f32(n2b), groups, eps, hpart, hrows)
@@ -766,43 +701,17 @@ class _ResBlock(torch.autograd.Function):
                 conv_wgrad_raw(x, ss1, dh_, *geo, ACT_AFFINE_SILU, False, True)
 
         need_x = ng[0] or ng[1] or ng[2]
-        if _OVERLAP and (ng[7] or ng[8]) and (ng[3] or ng[4]) and need_x:
-            # (see _OVERLAP above) main: dgrad2 | sg: GN2 backward  ||  sw: wgrad2 | main: dgrad1 | sg: GN1 backward  ||  sw: wgrad1 | join
-            main = torch.cuda.current_stream()
-            sg, sw, wcus = _overlap_streams(x.device)
-            da2 = conv_fwd_raw(dy, None, ConvWeight(c2w, True), None, None, *geo, ACT_NONE, False, cd)
-            e1 = torch.cuda.Event(); e1.record(main)
-            sg.wait_event(e1); sw.wait_event(e1)
-            with torch.cuda.stream(sg):
-                dh, dg2w, dg2b = gn_bwd(hh, da2, None, groups, ACT_AFFINE_SILU, n2w.detach().float(), mr2, ss2)
-                e2 = torch.cuda.Event(); e2.record(sg)
-            with torch.cuda.stream(sw), _cu_budget(wcus):
-                dw2, db2 = wgrad2()
-            main.wait_event(e2)
+        # conv2 / norm2
+        if ng[7] or ng[8]:       # (a2 / a1: the activated inputs the forward left behind -> prologue-free weight gradients)
+            dw2, db2 = wgrad2()
+        da2 = conv_fwd_raw(dy, None, ConvWeight(c2w, True), None, None, *geo, ACT_NONE, False, cd)
+        dh, dg2w, dg2b = gn_bwd(hh, da2, None, groups, ACT_AFFINE_SILU, n2w.detach().float(), mr2, ss2)
+        # conv1 / norm1 (+ the skip connection's gradient, fused into the GroupNorm-backward apply pass)
+        if ng[3] or ng[4]:
+            dw1, db1 = wgrad1(dh)
+        if need_x:
             da1 = conv_fwd_raw(dh, None, ConvWeight(c1w, True), None, None, *geo, ACT_NONE, False, cd)
-            e3 = torch.cuda.Event(); e3.record(main)
-            sg.wait_event(e3); sw.wait_event(e3)
-            with torch.cuda.stream(sg):
-                dx, dg1w, dg1b = gn_bwd(x, da1, dy, groups, ACT_AFFINE_SILU, n1w.detach().float(), mr1, ss1)
-                e4 = torch.cuda.Event(); e4.record(sg)
-            with torch.cuda.stream(sw), _cu_budget(wcus):
-                dw1, db1 = wgrad1(dh)
-                e5 = torch.cuda.Event(); e5.record(sw)
-            main.wait_event(e4); main.wait_event(e5)                # everything joined: the caller's stream owns all results again
-            for t in (dx, dg1w, dg1b, dg2w, dg2b, dw1, db1, dw2, db2):
-                t.record_stream(main)                                # (allocated on the side streams, consumed on the caller's)
-        else:
-            # conv2 / norm2
-            if ng[7] or ng[8]:       # (a2 / a1: the activated inputs the forward left behind -> prologue-free weight gradients)
-                dw2, db2 = wgrad2()
-            da2 = conv_fwd_raw(dy, None, ConvWeight(c2w, True), None, None, *geo, ACT_NONE, False, cd)
-            dh, dg2w, dg2b = gn_bwd(hh, da2, None, groups, ACT_AFFINE_SILU, n2w.detach().float(), mr2, ss2)
-            # conv1 / norm1 (+ the skip connection's gradient, fused into the GroupNorm-backward apply pass)
-            if ng[3] or ng[4]:
-                dw1, db1 = wgrad1(dh)
-            if need_x:
-                da1 = conv_fwd_raw(dh, None, ConvWeight(c1w, True), None, None, *geo, ACT_NONE, False, cd)
-                dx, dg1w, dg1b = gn_bwd(x, da1, dy, groups, ACT_AFFINE_SILU, n1w.detach().float(), mr1, ss1)
+            dx, dg1w, dg1b = gn_bwd(x, da1, dy, groups, ACT_AFFINE_SILU, n1w.detach().float(), mr1, ss1)
         cast = lambda g, ref: g.to(ref.dtype) if g is not None else None
         return (dx, cast(dg1w, n1w), cast(dg1b, n1w), cast(dw1, c1w), cast(db1, c1w), cast(dg2w, n2w), cast(dg2b, n2w),
                 cast(dw2, c2w), cast(db2, c2w), None, None, None, None, None, None)

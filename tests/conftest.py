@@ -9,6 +9,9 @@ for p in (PKG, ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# no pretrained LPIPS / VGG16 weights exist offline: the suite checks arithmetic and layout with synthetic weights, so the "weights
+# missing" error of losses/lpips.py is a warning here (tests/test_losses_host.py checks the strict default explicitly)
+os.environ.setdefault("MAS_LPIPS_STRICT", "0")
 
 
 def pytest_configure(config):

@@ -79,7 +79,7 @@ def test_surface_matches_reference_contract():
     import losses
     from losses.loss_img import VQLPIPSWithDiscriminator, hinge_d_loss, vanilla_d_loss, adopt_weight  # noqa: F401
     from losses.discriminator import Discriminator, weights_init  # noqa: F401
-    assert losses.VQLPIPSWithDiscriminator is VQLPIPSWithDiscriminator and hasattr(losses, "BCELossWithQuant")
+    assert losses.VQLPIPSWithDiscriminator is VQLPIPSWithDiscriminator
     assert len(Discriminator().state_dict()) == 22
     assert hasattr(m, "encode_to_indices") and hasattr(m, "decode_code")
 
@@ -104,3 +104,30 @@ def test_optimizer_steps_are_part_of_the_parameter_stamp():
     sp, sq = ops._param_stamp(p), ops._param_stamp(q)
     opt.step()
     assert ops._param_stamp(p)[2] == sp[2] + 1 and ops._param_stamp(q) == sq        # only the optimizer's own parameters are marked
+
+
+def test_loss_seg_falls_through_to_the_reference_module(monkeypatch):
+    """``losses.loss_seg`` is off the hot path and is not restated: the package's ``__path__`` falls through to the reference
+    checkout's own file (``MAS_REFERENCE_ROOT`` or a later ``sys.path`` entry); without a checkout the error says so."""
+    import importlib
+    import sys
+    import losses
+    ref = "/root/reference"
+    for k in [k for k in sys.modules if k == "losses.loss_seg"]:
+        del sys.modules[k]
+    losses.__path__[:] = losses.__path__[:1]
+    monkeypatch.delenv("MAS_REFERENCE_ROOT", raising=False)
+    if not any(os.path.isfile(os.path.join(p or ".", "losses", "loss_seg.py")) and os.path.abspath(os.path.join(p or ".", "losses")) != losses._HERE
+               for p in sys.path):
+        with pytest.raises(AttributeError, match="MAS_REFERENCE_ROOT"):
+            losses.BCELossWithQuant
+    if not os.path.isdir(ref):
+        pytest.skip("no reference checkout in this environment")
+    monkeypatch.setenv("MAS_REFERENCE_ROOT", ref)
+    cls = losses.VQVAEWithBCELoss
+    mod = importlib.import_module("losses.loss_seg")
+    assert mod.__file__.startswith(ref) and cls is mod.VQVAEWithBCELoss and losses.BCELossWithQuant is mod.BCELossWithQuant
+    q, t, pr = torch.tensor(0.5), torch.rand(2, 159, 4, 4), torch.randn(2, 159, 4, 4)
+    assert torch.isfinite(cls()(q, t, pr))
+    del sys.modules["losses.loss_seg"]
+    losses.__path__[:] = losses.__path__[:1]

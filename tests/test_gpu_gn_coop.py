@@ -1,4 +1,4 @@
-"""GroupNorm(+SiLU) backward as ONE persistent launch (``mas_gn_bwd`` -> ``gn_bwd_coop_kernel``, groupnorm.hip): autograd of the
+"""GroupNorm(+SiLU) backward as ONE persistent launch (``mas_gn_bwd_1pass`` -> ``gn_bwd_coop_kernel``, groupnorm.hip): autograd of the
 reference's ``Normalize`` + ``nonlinearity`` (models/modules.py:35-41,121-128) with the skip-connection gradient added in the same pass.
 
 Checked against (i) torch's fp32 autograd of group_norm (+ SiLU) on the CPU, on the bf16-rounded operands the kernel sees; (ii) the
@@ -44,13 +44,13 @@ def _reference(x, da, dres, gamma, beta, act):
     return dx, gr.grad, br.grad
 
 
-def _run(dev, x, da, dres, gamma, beta, act, three_pass=False):
+def _run(dev, x, da, dres, gamma, beta, act, path="one"):
     from mas_hip import ops
     cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last) if t is not None else None
     xd, dad, drd = cl(x), cl(da), cl(dres)
     gd, bd = gamma.to(dev), beta.to(dev)
     mr, ss = ops.gn_stats(xd, gd, bd, 32, 1e-6)
-    return ops.gn_bwd(xd, dad, drd, 32, act, gd, mr, ss, three_pass=three_pass)
+    return ops.gn_bwd(xd, dad, drd, 32, act, gd, mr, ss, path=path)
 
 
 # n, c, h, w: one work-group ... several groups through the ring (8 x 128 x 128^2 -> 2 images per group at the default plan;
@@ -68,7 +68,7 @@ def test_one_launch_backward_vs_cpu_fp32_and_three_pass(shape, act, res):
     x, da, dres, gamma, beta = _case(n, c, h, w, act, res, seed=n * 1000 + c + h)
     dx_ref, dg_ref, db_ref = _reference(x, da, dres, gamma, beta, act)
     dx, dg, db = _run(dev, x, da, dres, gamma, beta, act)
-    dx3, dg3, db3 = _run(dev, x, da, dres, gamma, beta, act, three_pass=True)
+    dx3, dg3, db3 = _run(dev, x, da, dres, gamma, beta, act, path="three")
     torch.cuda.synchronize()
     assert torch.isfinite(dg).all() and torch.isfinite(db).all()          # (NaN = a work-group gave up waiting: see the kernel's header)
     # dx is stored in bf16: 2^-8 relative per element; the fp32 parameter gradients are sums of <= 4e5 rounded terms
@@ -112,8 +112,8 @@ def test_one_launch_backward_full_size_matches_three_pass():
     beta = 0.1 * torch.randn(c, device=dev, generator=g)
     mr, ss = ops.gn_stats(x, gamma, beta, 32, 1e-6)
     for res in (None, dres):
-        dx, dg, db = ops.gn_bwd(x, da, res, 32, 2, gamma, mr, ss)
-        dx3, dg3, db3 = ops.gn_bwd(x, da, res, 32, 2, gamma, mr, ss, three_pass=True)
+        dx, dg, db = ops.gn_bwd(x, da, res, 32, 2, gamma, mr, ss, path="one")
+        dx3, dg3, db3 = ops.gn_bwd(x, da, res, 32, 2, gamma, mr, ss, path="three")
         torch.cuda.synchronize()
         assert torch.isfinite(dg).all()
         assert _rel(dg, dg3) < 1e-4 and _rel(db, db3) < 1e-4

@@ -110,17 +110,16 @@ def test_dominant_conv_wide_real_shape_vs_cpu_fp32(monkeypatch):
                               n, *geo, 0, False, bf)
         dw0, db0 = ops.conv_wgrad_raw(xd, None, dyd, n, *geo, 0, False, True)
         dw2, db2 = ops.conv_wgrad_raw(xd, ssd, dyd, n, *geo, 2, False, True)
-        # the optional path (MAS_CONV_ACT_OUT=1): the forward also writes the activated input (mas_conv_fwd_act), the weight gradient runs
-        # prologue-free on it
-        monkeypatch.setattr(ops, "_ACT_OUT", True)
-        y1a, a_out = ops.conv_fwd_raw(xd, ssd, ops.ConvWeight(wd, False), bd, None, n, *geo, 2, False, bf, want_act=True)
-        assert a_out is not None and torch.equal(y1a, y1)
+        # the training path: the activation as a tensor (mas_gn_act); the convolution and the weight gradient run prologue-free on it
+        a_out = ops.gn_act(xd, ssd, 2)
+        y1a = ops.conv_fwd_raw(a_out, None, ops.ConvWeight(wd, False), bd, None, n, *geo, 0, False, bf)
         dw3, db3 = ops.conv_wgrad_raw(a_out, None, dyd, n, *geo, 0, False, True)
     finally:
         ops.set_launch_hook(None)
     torch.cuda.synchronize()
     assert [k for k, _ in seen] == ["conv_fwd"] * 4 + ["conv_wgrad"] * 2 + ["conv_fwd", "conv_wgrad"]
-    e = relerr(a_out, af); print("activation side output vs CPU silu(gn(x)) in bf16: %.3e" % e); assert e < 1e-2
+    e = relerr(a_out, af); print("materialised activation vs CPU silu(gn(x)) in bf16: %.3e" % e); assert e < 1e-2
+    assert torch.equal(y1a, y1)                      # conv(gn_act(x)) == conv with the fused loader, bit for bit
     ref0 = F.conv2d(xf, w, b, padding=1)
     e = relerr(y0, ref0); print("wide fwd plain, 2 tiles per work-group: %.3e" % e); assert e < 1e-2
     del ref0
@@ -131,7 +130,7 @@ def test_dominant_conv_wide_real_shape_vs_cpu_fp32(monkeypatch):
     refd = F.conv2d(dy.float(), w, None, padding=1)                        # `da` convolves dy with the EFFECTIVE filter w
     e = relerr(da, refd); print("wide dgrad packing: %.3e" % e); assert e < 1e-2
     del refd
-    for act, a_in, dw, db in ((0, xf, dw0, db0), (2, af, dw2, db2), (3, af, dw3, db3)):      # 3: prologue-free on the side output
+    for act, a_in, dw, db in ((0, xf, dw0, db0), (2, af, dw2, db2), (3, af, dw3, db3)):      # 3: prologue-free on the materialised activation
         wr = torch.zeros(c, c, 3, 3, requires_grad=True)
         F.conv2d(a_in, wr, None, padding=1).backward(dy.float())
         e_w, e_b = relerr(dw, wr.grad), relerr(db, dy.float().sum((0, 2, 3)))

@@ -17,12 +17,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_wide_kernel_small_shapes_vs_cpu():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    env = dict(os.environ, MAS_CONV_WIDE_MIN_TILES_PER_CU="0", MAS_CONV_WIDE_ANY_WIDTH="1", MAS_CONV_ACT_OUT="1")   # (+ the optional side output)
+    env = dict(os.environ, MAS_CONV_WIDE_MIN_TILES_PER_CU="0", MAS_CONV_WIDE_ANY_WIDTH="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "wide_check.py")], env=env,
                        capture_output=True, text=True, timeout=600)
     print(r.stdout[-4000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert r.stdout.count("ok   ") >= 13 and r.stdout.count("act_out max-rel") >= 4
+    assert r.stdout.count("ok   ") >= 13
 
 
 def test_wide_kernel_persistent_multi_tile_walk_vs_cpu():
@@ -31,12 +31,12 @@ def test_wide_kernel_persistent_multi_tile_walk_vs_cpu():
     change mid-walk, cross-tile DMA, vmcnt(32) store wait.  The helper asserts tiles > grid from the launch geometry."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    env = dict(os.environ, MAS_CONV_WIDE_MIN_TILES_PER_CU="0", MAS_CONV_WIDE_ANY_WIDTH="1", MAS_CONV_WGS_PER_CU="1", MAS_CONV_ACT_OUT="1")
+    env = dict(os.environ, MAS_CONV_WIDE_MIN_TILES_PER_CU="0", MAS_CONV_WIDE_ANY_WIDTH="1", MAS_CONV_WGS_PER_CU="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "wide_check.py"), "multi"], env=env,
                        capture_output=True, text=True, timeout=900)
     print(r.stdout[-4000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert r.stdout.count("ok   ") >= 8 and "multi-tile mode" in r.stdout and r.stdout.count("act_out max-rel") >= 4
+    assert r.stdout.count("ok   ") >= 8 and "multi-tile mode" in r.stdout
 
 
 def test_weight_layout_query_and_k64_is_always_accepted():

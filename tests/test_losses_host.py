@@ -50,6 +50,18 @@ def test_yaml_loss_block_builds_the_reference_objective():
     assert l0.perceptual_loss is None and not rec2
 
 
+def test_default_construction_without_weights_is_an_error(monkeypatch):
+    """a default run must not optimise a random-feature 'perceptual' term silently -- without MAS_LPIPS_CKPT /
+    MAS_VGG16_CKPT the default constructor raises, like the reference's (whose weight files are absolute paths, lpips.py:15)."""
+    from losses import loss_img, lpips
+    monkeypatch.delenv("MAS_LPIPS_STRICT", raising=False)
+    monkeypatch.delenv("MAS_VGG16_CKPT", raising=False)
+    monkeypatch.setattr(lpips, "CKPT_PATHS", ())
+    with pytest.raises(RuntimeError, match="RANDOM initialisation"):
+        loss_img.VQLPIPSWithDiscriminator(disc_start=0, face_loss=None)
+    loss_img.VQLPIPSWithDiscriminator(disc_start=0, perceptual_loss=None, face_loss=None)      # the explicit opt-out builds
+
+
 def test_lpips_partial_checkpoint_is_reported(tmp_path, monkeypatch):
     """the reference's vgg.pth holds the five lin heads only (its backbone comes from torchvision); loading it -- or any
     partial MAS_LPIPS_CKPT -- must not pass for a loaded network.  MAS_VGG16_CKPT supplies the backbone in torchvision's key

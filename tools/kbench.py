@@ -78,7 +78,7 @@ def main():
         da = torch.randn_like(x)
         dres = torch.randn_like(x) if a.res else None
         for three in ((False, True) if a.three < 0 else (bool(a.three),)):
-            ms = timeit(lambda: ops.gn_bwd(x, da, dres, 32, a.act or 2, g, mr, ss, three_pass=three), a.iters)
+            ms = timeit(lambda: ops.gn_bwd(x, da, dres, 32, a.act or 2, g, mr, ss, path="three" if three else "one"), a.iters)
             alg = (3 + (1 if a.res else 0)) * x.numel() * esz     # x, da (, dres) read once, dx written once
             print(f"gn_bwd[{'three launches' if three else 'one launch'}] n={n} c={c} hw={h} res={a.res}: {ms:.4f} ms  "
                   f"{alg/ms/1e6:.1f} GB/s algorithmic (x + da{' + dres' if a.res else ''} + dx once)")
