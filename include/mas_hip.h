@@ -55,6 +55,9 @@ typedef struct MasConvDesc {
 
 int         mas_abi_version(void);
 const char* mas_last_error(void);
+/* Name of the kernel the calling thread's last successful launch ran ("conv3x3_wide", "conv_s2_fwd", "wgrad_thin", ...; "" before
+ * the first one): every entry point dispatches on shape, and tests / per-shape profiles assert which kernel a shape really took.   */
+const char* mas_last_kernel(void);
 
 /* ---- weight packing (host-visible layout contract) -------------------------------
  * Packs an OIHW fp32 parameter (nn.Conv2d.weight, e.g. modules.py:93-104) into the

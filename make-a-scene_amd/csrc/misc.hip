@@ -25,6 +25,9 @@ int mas_num_cus() {
 }
 
 extern "C" const char* mas_last_error(void) { return g_err; }
+static thread_local const char* g_last_kernel = "";
+void mas_note_kernel(const char* name) { g_last_kernel = name; }
+extern "C" const char* mas_last_kernel(void) { return g_last_kernel; }
 extern "C" int mas_abi_version(void) {
     MAS_ENTER(); return MAS_ABI_VERSION; }
 

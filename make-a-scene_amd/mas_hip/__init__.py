@@ -38,6 +38,7 @@ _p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _SIGNATURES = {
     "mas_abi_version": (C.c_int, []),
     "mas_last_error": (C.c_char_p, []),
+    "mas_last_kernel": (C.c_char_p, []),
     "mas_packed_weight_elems": (_sz, [_i, _i, _i]),
     "mas_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "mas_conv_weight_layout": (_i, [C.POINTER(ConvDesc)]),

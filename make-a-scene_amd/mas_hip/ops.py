@@ -41,6 +41,11 @@ def set_launch_hook(fn) -> None:
     _launch_hook = fn
 
 
+def last_kernel() -> str:
+    """the kernel this thread's last launch ran (``mas_last_kernel``): the library dispatches on shape; tests assert the choice"""
+    return lib().mas_last_kernel().decode()
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -10,4 +10,4 @@ timeout 300 python bench.py --steps 20 --warmup 12 --no-cpu-baseline --no-also >
 timeout 200 python tools/probes/op_origin.py --mode enc_fwd > $O/op_origin_enc.txt 2>&1; tail -25 $O/op_origin_enc.txt
 timeout 200 python tools/probes/op_origin.py --mode step > $O/op_origin_step.txt 2>&1; tail -25 $O/op_origin_step.txt
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pf_enc -o enc -- python $GRAFT_REPO_ROOT/tools/enc_fwd.py > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT && python tools/rocprof_summary.py /tmp/pf_enc > $O/kernel_trace_encoder_fwd.txt 2>&1; head -30 $O/kernel_trace_encoder_fwd.txt | cut -c1-180
+cd $GRAFT_REPO_ROOT && python tools/rocprof_summary.py $(find /tmp/pf_enc -name "*.db" | head -1) $O/kernel_trace_encoder_fwd.txt > /dev/null 2>&1; head -30 $O/kernel_trace_encoder_fwd.txt | cut -c1-180
