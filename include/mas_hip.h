@@ -55,8 +55,9 @@ typedef struct MasConvDesc {
 
 int         mas_abi_version(void);
 const char* mas_last_error(void);
-/* Name of the kernel the calling thread's last successful launch ran ("conv3x3_wide", "conv_s2_fwd", "wgrad_thin", ...; "" before
- * the first one): every entry point dispatches on shape, and tests / per-shape profiles assert which kernel a shape really took.   */
+/* Name of the kernel the last successful launch of this process ran ("conv3x3_wide", "conv_s2_fwd", "wgrad_thin", ...; "" before the
+ * first one; process-wide, because a backward pass launches from autograd's threads): every entry point dispatches on shape, and
+ * tests / per-shape profiles assert which kernel a shape really took.  A diagnostic: meaningful while one thread launches at a time. */
 const char* mas_last_kernel(void);
 
 /* ---- weight packing (host-visible layout contract) -------------------------------

@@ -19,7 +19,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 // ---- error plumbing (host) -------------------------------------------------------
 void mas_set_error(const char* fmt, ...);
 #define MAS_FAIL(code, ...) do { mas_set_error(__VA_ARGS__); return (code); } while (0)
-void mas_note_kernel(const char* name);      // thread-local: which kernel the last successful launch of this thread was (mas_last_kernel)
+void mas_note_kernel(const char* name);      // which kernel the last successful launch of this process was (mas_last_kernel)
 #define MAS_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
     if (e_ != hipSuccess) MAS_FAIL(MAS_ELAUNCH, "%s: launch failed: %s", name, hipGetErrorString(e_)); mas_note_kernel(name); } while (0)
 

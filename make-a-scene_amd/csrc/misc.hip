@@ -25,9 +25,9 @@ int mas_num_cus() {
 }
 
 extern "C" const char* mas_last_error(void) { return g_err; }
-static thread_local const char* g_last_kernel = "";
-void mas_note_kernel(const char* name) { g_last_kernel = name; }
-extern "C" const char* mas_last_kernel(void) { return g_last_kernel; }
+static std::atomic<const char*> g_last_kernel{""};          // process-wide: the backward's launches come from autograd's own threads
+void mas_note_kernel(const char* name) { g_last_kernel.store(name, std::memory_order_relaxed); }
+extern "C" const char* mas_last_kernel(void) { return g_last_kernel.load(std::memory_order_relaxed); }
 extern "C" int mas_abi_version(void) {
     MAS_ENTER(); return MAS_ABI_VERSION; }
 

@@ -42,7 +42,7 @@ def set_launch_hook(fn) -> None:
 
 
 def last_kernel() -> str:
-    """the kernel this thread's last launch ran (``mas_last_kernel``): the library dispatches on shape; tests assert the choice"""
+    """the kernel the process's last launch ran (``mas_last_kernel``): the library dispatches on shape; tests assert the choice"""
     return lib().mas_last_kernel().decode()
 
 
