@@ -92,6 +92,18 @@ typedef struct MasPackItem {
 int    mas_pack_batch_blocks(int Cout, int Cin, int ks, int transpose, int dtype, int layout);
 int    mas_pack_conv_weight_batch(const MasPackItem* items_device, int n_items, int total_blocks, void* stream);
 
+/* The bf16 images of many parameters in ONE launch, each parameter READ ONCE: a work-group stages a 64 x 64 x taps tile of the OIHW
+ * tensor in LDS (coalesced runs) and writes every image the item lists -- forward / data-gradient operand, K64 / K32 -- from it,
+ * zero padding included.  Bitwise the images of mas_pack_conv_weight_layout.  Item i covers work-groups [first_block, first_block +
+ * mas_pack_tile_blocks(Cout, Cin, ks)), items in ascending first_block order; max_ks = the largest ks in the table (sizes the LDS).    */
+typedef struct MasPackTileItem {
+    const float* w_oihw; void* img[4];
+    int transpose[4], layout[4];
+    int n_img, Cout, Cin, ks, first_block, pad_;
+} MasPackTileItem;
+int    mas_pack_tile_blocks(int Cout, int Cin, int ks);
+int    mas_pack_conv_weight_tiles(const MasPackTileItem* items_device, int n_items, int total_blocks, int max_ks, void* stream);
+
 /* ---- GroupNorm statistics (replaces the reduction half of torch.nn.GroupNorm,
  * modules.py:40-41).  x: [N,HW,C] NHWC.  Outputs:
  *   mean_rstd [N][G][2] fp32, scale_shift [N][C][2] fp32 with

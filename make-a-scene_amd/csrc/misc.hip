@@ -133,6 +133,105 @@ __global__ __launch_bounds__(NT) void pack_weight_batch_kernel(const MasPackItem
         pack_weight_body<float>(it.w_oihw, (float*)it.packed, it.Cout, it.Cin, it.ks, it.transpose, rows_pad, cdiv(cols, 32), first, stride);
 }
 
+// ---- every bf16 image of a parameter from ONE read of it, tile-transposed through LDS (mas_pack_conv_weight_tiles) ------------------
+// The gather kernels above produce a 16-byte slot from 8 reads at a 36-byte stride (3x3), once per image: 0.65 ms for the ~160 images
+// of a VQ-IMG step.  Here a work-group owns a 64 (cout) x 64 (cin) x taps tile of the OIHW parameter: its 64 rows are contiguous runs
+// of 64 * taps floats (coalesced 16-byte loads), staged once in LDS as bf16, and every image the parameter has -- forward and data-
+// gradient operand, K64 or K32 layout -- is written from there with whole 16-byte slots in the image's own order (1 KiB+ runs).  The
+// tile grid covers the PADDED extents (rows up to the next multiple of 128 of either image), so the zero padding the convolution
+// kernels rely on is rewritten too.  Same bytes as the gather kernels (tests/test_gpu_pack_tiles.py: bit for bit).
+__device__ __forceinline__ unsigned pk2(const bf16_t* l, int a, int b) {   // two LDS bf16 -> one dword
+    return (unsigned)reinterpret_cast<const unsigned short*>(l)[a] | ((unsigned)reinterpret_cast<const unsigned short*>(l)[b] << 16);
+}
+__global__ __launch_bounds__(NT) void pack_weight_tiles_kernel(const MasPackTileItem* __restrict__ items, int n_items) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+    bf16_t* L = reinterpret_cast<bf16_t*>(tsm);                    // [64 o][64 i][kk]  (a straight copy of the 64 source runs)
+    int lo = 0, hi = n_items - 1;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    const MasPackTileItem it = items[lo];
+    const int Cout = it.Cout, Cin = it.Cin, kk = it.ks * it.ks;
+    const int tiles_i = (Cin + 127) / 128 * 2;
+    const int tb = b - it.first_block, o0 = (tb / tiles_i) * 64, i0 = (tb % tiles_i) * 64;
+    const int run = 64 * kk;                                       // floats of one row's 64-channel run
+    // ---- stage: row ol = the run W[o0 + ol][i0 .. i0 + 63][all taps]; zero outside the parameter
+    const bool full = i0 + 64 <= Cin && ((size_t)Cin * kk) % 4 == 0 && (reinterpret_cast<uintptr_t>(it.w_oihw) & 15) == 0;
+    if (full) {
+        const int v4 = run / 4;                                    // 16 * kk float4 per row
+        for (int u = tid; u < 64 * v4; u += NT) {
+            const int ol = u / v4, q = u - ol * v4;
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (o0 + ol < Cout) v = *reinterpret_cast<const f32x4*>(it.w_oihw + ((size_t)(o0 + ol) * Cin + i0) * kk + 4 * q);
+            const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            *reinterpret_cast<bf16x4*>(L + (size_t)ol * run + 4 * q) = o;
+        }
+    } else {
+        const int valid = i0 < Cin ? (Cin - i0 < 64 ? Cin - i0 : 64) * kk : 0;
+        for (int u = tid; u < 64 * run; u += NT) {
+            const int ol = u / run, f = u - ol * run;
+            float v = 0.0f;
+            if (o0 + ol < Cout && f < valid) v = it.w_oihw[((size_t)(o0 + ol) * Cin + i0) * kk + f];
+            L[u] = (bf16_t)v;
+        }
+    }
+    __syncthreads();
+    // ---- emit every image.  A slot = 8 consecutive columns of one (row, tap): forward image rows = couts, columns = cins;
+    //      data-gradient image rows = cins, columns = couts, taps flipped (see mas_pack_conv_weight)
+    for (int im = 0; im < it.n_img; ++im) {
+        const int tr = it.transpose[im], k32 = it.layout[im] == MAS_WLAYOUT_K32;
+        const int rows = tr ? Cin : Cout, cols = tr ? Cout : Cin;
+        const int r0 = tr ? i0 : o0, c0 = tr ? o0 : i0;            // this tile's rows / columns in the image's terms
+        const int rows_pad = (rows + 127) / 128 * 128;
+        if (r0 >= rows_pad) continue;
+        unsigned char* out = reinterpret_cast<unsigned char*>(it.img[im]);
+        if (!k32) {
+            const int ch = c0 / 64;
+            if (ch >= (cols + 63) / 64) continue;
+            for (int u = tid; u < kk * 512; u += NT) {             // (tap, row, slot position): 8 KiB contiguous per tap
+                const int t = u >> 9, row_l = (u >> 3) & 63, sp = u & 7;
+                const int row = r0 + row_l, ls = sp ^ ((row >> 1) & 7);
+                const int ts = tr ? kk - 1 - t : t;
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ca = ls * 8 + 2 * e, cb = ca + 1;    // column inside the tile
+                    const int ia = tr ? (ca * 64 + row_l) * kk + ts : (row_l * 64 + ca) * kk + ts;
+                    const int ib = tr ? (cb * 64 + row_l) * kk + ts : (row_l * 64 + cb) * kk + ts;
+                    o[e] = pk2(L, ia, ib);
+                }
+                *reinterpret_cast<u32x4*>(out + ((size_t)(ch * kk + t) * rows_pad + row) * 128 + sp * 16) = o;
+            }
+        } else {
+            // K32: 64-byte rows; inside every 128-row block LDS row 32 i + l holds filter row 4 l + i; this tile holds filter rows
+            // [r0, r0 + 64) = l in [16 half, 16 half + 16), i = 0..3: four runs of 16 rows (1 KiB each) per (chunk, tap)
+            const int half = (r0 >> 6) & 1, base = r0 & ~127;
+            for (int h = 0; h < 2; ++h) {
+                const int ch = c0 / 32 + h;
+                if (ch >= (cols + 31) / 32) continue;
+                for (int u = tid; u < kk * 256; u += NT) {         // (tap, i, l, slot position)
+                    const int t = u >> 8, i_ = (u >> 6) & 3, l16 = (u >> 2) & 15, sp = u & 3;
+                    const int row = base + 32 * i_ + l16 + 16 * half;          // LDS row of the image
+                    const int row_l = 4 * l16 + i_;                             // filter row inside the tile (0..63)
+                    const int ls = sp ^ ((row >> 2) & 3);
+                    const int ts = tr ? kk - 1 - t : t;
+                    u32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ca = h * 32 + ls * 8 + 2 * e, cb = ca + 1;
+                        const int ia = tr ? (ca * 64 + row_l) * kk + ts : (row_l * 64 + ca) * kk + ts;
+                        const int ib = tr ? (cb * 64 + row_l) * kk + ts : (row_l * 64 + cb) * kk + ts;
+                        o[e] = pk2(L, ia, ib);
+                    }
+                    *reinterpret_cast<u32x4*>(out + ((size_t)(ch * kk + t) * rows_pad + row) * 64 + sp * 16) = o;
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT) void upsample2x_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C) {
     // one thread per 16-byte unit of the OUTPUT
@@ -281,6 +380,27 @@ extern "C" int mas_pack_conv_weight_batch(const MasPackItem* items_device, int n
     if (!items_device || n_items <= 0 || total_blocks <= 0) MAS_FAIL(MAS_EINVAL, "pack_conv_weight_batch: empty batch");
     hipLaunchKernelGGL(pack_weight_batch_kernel, dim3((unsigned)total_blocks), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), items_device, n_items);
     MAS_CHECK_LAUNCH("pack_conv_weight_batch");
+    return MAS_OK;
+}
+
+extern "C" int mas_pack_tile_blocks(int Cout, int Cin, int ks) {
+    if (Cout <= 0 || Cin <= 0 || ks < 1 || ks > 4) return 0;
+    return ((Cout + 127) / 128 * 2) * ((Cin + 127) / 128 * 2);
+}
+
+extern "C" int mas_pack_conv_weight_tiles(const MasPackTileItem* items_device, int n_items, int total_blocks, int max_ks, void* stream) {
+    MAS_ENTER();
+    if (!items_device || n_items <= 0 || total_blocks <= 0 || max_ks < 1 || max_ks > 4) MAS_FAIL(MAS_EINVAL, "pack_conv_weight_tiles: bad batch");
+    const size_t lds = (size_t)64 * 64 * max_ks * max_ks * 2;
+    static mas_devmask_t attr{0};
+    unsigned long long bit;
+    if (mas_attr_needed(attr, &bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(pack_weight_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 64 * 16 * 2) != hipSuccess)
+            MAS_FAIL(MAS_ELAUNCH, "pack_conv_weight_tiles: cannot reserve LDS");
+        mas_attr_done(attr, bit);
+    }
+    hipLaunchKernelGGL(pack_weight_tiles_kernel, dim3((unsigned)total_blocks), dim3(NT), lds, reinterpret_cast<hipStream_t>(stream), items_device, n_items);
+    MAS_CHECK_LAUNCH("pack_conv_weight_tiles");
     return MAS_OK;
 }
 

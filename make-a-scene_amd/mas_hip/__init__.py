@@ -34,6 +34,12 @@ class PackItem(C.Structure):
         "Cout", "Cin", "ks", "transpose", "dtype", "layout", "first_block", "n_blocks")]
 
 
+class PackTileItem(C.Structure):
+    """Mirror of ``MasPackTileItem`` (include/mas_hip.h): one parameter and up to four bf16 images of it."""
+    _fields_ = [("w_oihw", C.c_void_p), ("img", C.c_void_p * 4), ("transpose", C.c_int32 * 4), ("layout", C.c_int32 * 4)] + \
+               [(n, C.c_int32) for n in ("n_img", "Cout", "Cin", "ks", "first_block", "pad_")]
+
+
 _p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _SIGNATURES = {
     "mas_abi_version": (C.c_int, []),
@@ -45,6 +51,8 @@ _SIGNATURES = {
     "mas_pack_conv_weight_layout": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mas_pack_batch_blocks": (_i, [_i, _i, _i, _i, _i, _i]),
     "mas_pack_conv_weight_batch": (_i, [_p, _i, _i, _p]),
+    "mas_pack_tile_blocks": (_i, [_i, _i, _i]),
+    "mas_pack_conv_weight_tiles": (_i, [_p, _i, _i, _i, _p]),
     "mas_gn_stats_workspace": (_sz, [_i, _i]),
     "mas_gn_stats": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _sz, _p]),
     "mas_gn_bwd_workspace": (_sz, [_i, _i]),

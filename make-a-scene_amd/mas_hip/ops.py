@@ -14,7 +14,7 @@ from typing import Optional
 
 import torch
 
-from . import ACT_AFFINE, ACT_AFFINE_SILU, ACT_NONE, BF16, F32, WLAYOUT_K64, ConvDesc, PackItem, check, lib
+from . import ACT_AFFINE, ACT_AFFINE_SILU, ACT_NONE, BF16, F32, WLAYOUT_K64, ConvDesc, PackItem, PackTileItem, check, lib
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 _state = {"compute_dtype": torch.bfloat16 if os.environ.get("MAS_COMPUTE_DTYPE", "bf16") == "bf16" else torch.float32}
@@ -110,7 +110,6 @@ def _param_stamp(p: torch.Tensor):
     return (p._version, p.data_ptr(), _param_generation.get(id(p), 0))
 
 
-_PACK_BATCH = os.environ.get("MAS_PACK_BATCH", "1") == "1"
 # debugging aid for writes the stamp cannot see (``w.data.copy_(...)`` without invalidate_weight_cache()): every cache hit compares a
 # checksum of the live parameter with the one taken when its image was packed (one device sync per conv call: never on by default)
 _CACHE_CHECK = os.environ.get("MAS_WEIGHT_CACHE_CHECK", "0") == "1"
@@ -129,13 +128,12 @@ class _PackCache:
         self.store = {}
         self.derived = {}                            # images of tensors DERIVED from several parameters (AttnBlock's q|k|v stack)
         self.sums = {}                               # MAS_WEIGHT_CACHE_CHECK=1 only
-        self._table = None
-        self._table_sig = None
+        self._tables = {}                            # device-resident item tables of the batched pack launches
 
     def clear(self):
         self.store.clear()
         self.derived.clear()
-        self._table = self._table_sig = None
+        self._tables.clear()
 
     def drop(self, w: torch.Tensor):
         """forget every image made from parameter ``w`` (its module was switched train()/eval() or reloaded)"""
@@ -177,50 +175,63 @@ class _PackCache:
         return self.store[key][2]
 
     def _refresh_stale(self, device):
-        """Repacks EVERY stale entry on ``device`` in one launch (``mas_pack_conv_weight_batch``): after an optimizer step all of a
-        model's images are stale at once, and one launch replaces ~160 dependent 8-us launches per VQ-IMG step.  The packed
-        buffers are refreshed in place (nothing saves them for backward: the backward asks the cache again)."""
-        items, first, fresh = [], 0, []
+        """Repacks EVERY stale entry on ``device``: after an optimizer step all of a model's images are stale at once.  The bf16 images
+        of a parameter (forward / data-gradient operand, K64 / K32) are written together from ONE tiled read of it
+        (``mas_pack_conv_weight_tiles``: one launch for the whole model); fp32 images (the parity mode) keep the gather kernel
+        (``mas_pack_conv_weight_batch``, also one launch).  The packed buffers are refreshed in place (nothing saves them for backward:
+        the backward asks the cache again)."""
+        groups, items, first, fresh, keep = {}, [], 0, [], []
         for key, ent in list(self.store.items()):                                  # (a weakref callback may pop entries meanwhile)
-            _wid, transpose, dtype, layout = key
+            wid, transpose, dtype, layout = key
             w = ent[0]()
             if w is None or w.device != device or ent[1] == _param_stamp(w):
                 continue
             cout, cin, ks, _ = w.shape
-            nb = lib().mas_pack_batch_blocks(cout, cin, ks, int(transpose), _DT[dtype], int(layout))
-            if nb <= 0:
-                raise RuntimeError(f"pack_conv_weight: unsupported weight shape {tuple(w.shape)}")
             wf = w.detach()
             if wf.dtype != torch.float32 or not wf.is_contiguous():
                 wf = wf.contiguous().float()
-                ent.append(wf)                                 # keep the temporary alive until the launch has been issued
-            items.append(PackItem(wf.data_ptr(), ent[2].data_ptr(), cout, cin, ks, int(transpose), _DT[dtype], int(layout), first, nb))
-            first += nb
+                keep.append(wf)                                # keep the temporary alive until the launches have been issued
             ent[1] = None                                      # not valid until the launch below has been accepted
             fresh.append((ent, _param_stamp(w)))
             if _CACHE_CHECK:
                 self.sums[key] = _checksum(w)
-        if not items:
-            return
-        if not _PACK_BATCH:                                      # A/B switch: one launch per image
-            for it, (ent, stamp) in zip(items, fresh):
-                check(lib().mas_pack_conv_weight_layout(it.w_oihw, it.packed, it.Cout, it.Cin, it.ks, it.transpose, it.dtype, it.layout,
-                                                        _stream()), "pack_conv_weight")
-                ent[1] = stamp
-            for ent in list(self.store.values()):
-                del ent[3:]
-            return
-        arr = (PackItem * len(items))(*items)
-        raw = bytes(memoryview(arr))
-        sig = (device.index, raw)
-        if self._table_sig != sig:                               # pointers and shapes repeat step after step: one upload, then reuse
-            self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
-            self._table_sig = sig
-        check(lib().mas_pack_conv_weight_batch(_ptr(self._table), len(items), first, _stream()), "pack_conv_weight_batch")
+            g = groups.get(wid)
+            if dtype == torch.bfloat16 and ks <= 4 and (g is None or len(g[2]) < 4):
+                if g is None:
+                    g = groups[wid] = (wf, (cout, cin, ks), [])
+                g[2].append((ent[2].data_ptr(), int(transpose), int(layout)))
+                continue
+            nb = lib().mas_pack_batch_blocks(cout, cin, ks, int(transpose), _DT[dtype], int(layout))
+            if nb <= 0:
+                raise RuntimeError(f"pack_conv_weight: unsupported weight shape {tuple(w.shape)}")
+            items.append(PackItem(wf.data_ptr(), ent[2].data_ptr(), cout, cin, ks, int(transpose), _DT[dtype], int(layout), first, nb))
+            first += nb
+        if groups:
+            titems, tfirst, max_ks = [], 0, 1
+            for wf, (cout, cin, ks), imgs in groups.values():
+                it = PackTileItem()
+                it.w_oihw, it.n_img, it.Cout, it.Cin, it.ks, it.first_block = wf.data_ptr(), len(imgs), cout, cin, ks, tfirst
+                for k, (ptr, tr, lay) in enumerate(imgs):
+                    it.img[k], it.transpose[k], it.layout[k] = ptr, tr, lay
+                titems.append(it)
+                tfirst += lib().mas_pack_tile_blocks(cout, cin, ks)
+                max_ks = max(max_ks, ks)
+            table = self._upload("tiles", device, (PackTileItem * len(titems))(*titems))
+            check(lib().mas_pack_conv_weight_tiles(_ptr(table), len(titems), tfirst, max_ks, _stream()), "pack_conv_weight_tiles")
+        if items:
+            table = self._upload("batch", device, (PackItem * len(items))(*items))
+            check(lib().mas_pack_conv_weight_batch(_ptr(table), len(items), first, _stream()), "pack_conv_weight_batch")
         for ent, stamp in fresh:                                 # (a failed launch raised above: the entries stay invalid)
             ent[1] = stamp
-        for ent in list(self.store.values()):
-            del ent[3:]
+
+    def _upload(self, which, device, arr):
+        """the item table on the device; pointers and shapes repeat step after step: one upload, then reuse"""
+        raw = bytes(memoryview(arr))
+        sig = (device.index, raw)
+        hit = self._tables.get(which)
+        if hit is None or hit[0] != sig:
+            hit = self._tables[which] = (sig, torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device))
+        return hit[1]
 
 
 _pack_cache = _PackCache()

@@ -31,7 +31,7 @@ def main():
         tiles = n * ((h + 15) // 16) * ((w + 31) // 32) * (cout // 128)
         grid = min(tiles, per_cu * cus)
         ga, be = 1.0 + 0.1 * torch.randn(cout, device=dev, generator=g), 0.1 * torch.randn(cout, device=dev, generator=g)
-        ok = part is not None and kern == "conv3x3_wide" and tiles >= 4 * grid
+        ok = part is not None and kern == "conv3x3_wide" and tiles >= 3 * grid
         if ok:
             mr_f, ss_f = ops.gn_stats(y, ga, be, 32, 1e-6, part, rows)
             mr_s, ss_s = ops.gn_stats(y, ga, be, 32, 1e-6)

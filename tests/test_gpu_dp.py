@@ -164,6 +164,36 @@ def test_bench_py_multi_rank_branch_end_to_end():
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]   # only rank 0 prints
 
 
+def test_bench_py_eight_ranks_through_the_drivers_launcher():
+    """the command line the driver uses for N = 8 -- ``python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...`` -- as a dry run: eight ranks share the one GPU over gloo
+    (MAS_BENCH_SHARE_GPU / MAS_BENCH_BACKEND), so that the first real 8-GPU RCCL run is not also the first 8-rank run of the
+    argument / rendezvous / reducer-bucket / SyncBatchNorm / max-over-ranks plumbing.  Checked: the line's shape (n_gpus 8, global batch
+    8 x per-GPU batch, weak scaling), identical replicas after the steps (checksum spread 0), one JSON line (rank 0 only)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MAS_BENCH_SHARE_GPU="1", MAS_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["config"]["global_batch"] == 16 and j["config"]["per_gpu_batch"] == 2 and j["scaling"] == "weak"
+    assert j["steps"] == 2 and j["warmup"] == 1 and j["value"] > 0 and abs(j["value"] - 16 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-2 * j["value"]
+    assert j["replica_weight_checksum_spread"] == 0.0
+    assert "dp8" in j["config"]["parallelism"]
+
+
 def test_bench_py_multi_rank_gradient_accumulation_no_sync():
     """the accumulation branch of the N > 1 path -- GradReducer.no_sync() on all but the last micro-batch, as the
     reference accumulates (conf/img_config.yaml:13) -- end to end through `bench.py --workload e2e` (frozen VQ encode -> transformer,
