@@ -37,8 +37,14 @@ def test_tiled_pack_equals_the_gather_kernel(shape):
     for (tr, lay), img in got.items():
         ref = ops.pack_conv_weight(w.detach(), tr, torch.bfloat16, lay)
         assert img.shape == ref.shape
-        same = torch.equal(img.view(torch.int16), ref.view(torch.int16))
-        assert same, (shape, tr, lay, int((img.view(torch.int16) != ref.view(torch.int16)).sum()))
+        # the image proper: [chunks of CK columns][taps][rows padded to 128][CK]; the buffer (mas_packed_weight_elems: sized for either
+        # orientation) may be longer -- what lies behind the image is never read by a kernel
+        rows, cols = (cin, cout) if tr else (cout, cin)
+        ck = 32 if lay == mas_hip.WLAYOUT_K32 else 64
+        used = ks * ks * -(-cols // ck) * (-(-rows // 128) * 128) * ck
+        a, b = img.view(torch.int16)[:used], ref.view(torch.int16)[:used]
+        assert torch.equal(a, b), (shape, tr, lay, int((a != b).sum()), used)
+        assert not torch.isnan(img[:used].float()).any()           # all of it written (the buffer was poisoned)
 
 
 def test_tiled_pack_follows_the_optimizer():

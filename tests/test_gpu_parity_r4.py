@@ -200,3 +200,50 @@ def test_fused_statistics_with_one_work_group_per_cu():
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("ok   ") >= 4
+
+
+# --------------------------------------------------------------------------------------------------------------
+# 4. tensors of 2^31 bytes and more (per-GPU batches >= 128 at 128 ch @256^2: conf/img_config.yaml:17 hints at 192)
+# --------------------------------------------------------------------------------------------------------------
+def test_large_batch_stays_on_the_fast_kernels():
+    """N = 160 at the dominant shape: x / y are 2.68 GB each, beyond the 31-bit byte offsets of the fast kernels' buffer descriptors.
+    ops cuts such launches into batch slices below the limit (images are independent): the forward must run on conv3x3_wide and the
+    weight gradient on conv_wgrad_dma (asserted), the forward must match F.conv2d fp32 on images sampled from both slices, the weight
+    gradient must equal the sum of the two halves' weight gradients computed as ordinary (single-slice) launches -- linearity in the
+    batch -- and the fused GroupNorm statistics must equal the stand-alone pass over the whole 2.68 GB tensor."""
+    from mas_hip import ops
+    dev = _dev()
+    bf = torch.bfloat16
+    n, c, h = 160, 128, 256
+    assert len(ops._batch_slices(n, h * h * c * 2, h * h * c * 2)) == 2
+    g = torch.Generator(device=dev).manual_seed(21)
+    x = torch.randn(n, c, h, h, device=dev, generator=g).to(bf).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.randn(c, c, 3, 3, device=dev, generator=g) / (9 * c) ** 0.5)
+    b = 0.1 * torch.randn(c, device=dev, generator=g)
+    geo = (h, h, c, h, h, c, 3, 1, 1, 1)
+    seen = []
+    ops.set_launch_hook(lambda kind, shape, launch: (launch(), seen.append((kind, ops.last_kernel()))))
+    try:
+        ops._stats_state["on"] = True
+        y, part, rows = ops.conv_fwd_raw(x, None, ops.ConvWeight(w, False), b, None, n, *geo, 0, False, bf, want_stats=True)
+        ga, be = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+        mr_f, ss_f = ops.gn_stats(y, ga, be, 32, 1e-6, part, rows)
+        mr_s, ss_s = ops.gn_stats(y, ga, be, 32, 1e-6)
+        dy = torch.randn(n, c, h, h, device=dev, generator=g).to(bf).contiguous(memory_format=torch.channels_last)
+        dw, db = ops.conv_wgrad_raw(x, None, dy, n, *geo, 0, False, True)
+        dwa, dba = ops.conv_wgrad_raw(x[:80], None, dy[:80], 80, *geo, 0, False, True)
+        dwb, dbb = ops.conv_wgrad_raw(x[80:], None, dy[80:], 80, *geo, 0, False, True)
+    finally:
+        ops.set_launch_hook(None)
+    torch.cuda.synchronize()
+    assert seen[0] == ("conv_fwd", "conv3x3_wide") and [k for k in seen if k[0] == "conv_wgrad"] == [("conv_wgrad", "conv_wgrad_dma")] * 3, seen
+    assert part is not None and float((mr_f - mr_s).abs().max() / mr_s.abs().max()) < 1e-4 and float((ss_f - ss_s).abs().max() / ss_s.abs().max()) < 1e-4
+    sample = [0, 79, 80, 159]
+    ref = F.conv2d(x[sample].float().cpu(), w.detach().bfloat16().float().cpu(), b.cpu(), padding=1)
+    e = relerr(y[sample], ref)
+    print("N=160 wide forward on sampled images of both slices: %.3e" % e)
+    assert e < 1e-2
+    e_w = float((dw - (dwa + dwb)).abs().max() / dw.abs().max())
+    e_b = float((db - (dba + dbb)).abs().max() / db.abs().max())
+    print("N=160 weight gradient vs the sum of its two halves: %.3e, bias %.3e" % (e_w, e_b))
+    assert e_w < 1e-5 and e_b < 1e-5

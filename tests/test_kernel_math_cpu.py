@@ -109,3 +109,19 @@ def test_pointwise_weight_gradient_split_k_slabs_in_fixed_order():
     assert np.abs(dw - ref).max() < 1e-3 * np.abs(ref).max()
     again = sum(slabs[sp] for sp in range(nsplit))    # the same order again: bitwise the same
     assert np.array_equal(dw, np.asarray(again, np.float32))
+
+
+def test_batch_slices_keep_every_tensor_below_2_to_the_31():
+    """ops._batch_slices (host arithmetic): launches whose tensors reach 2^31 bytes are cut into even batch slices below the limit the
+    fast kernels' 31-bit buffer offsets impose; smaller launches are left alone"""
+    from mas_hip import ops
+    img = 256 * 256 * 128 * 2
+    assert ops._batch_slices(32, img, img) == [(0, 32)]
+    assert ops._batch_slices(127, img, img) == [(0, 127)]
+    assert ops._batch_slices(128, img, img) == [(0, 64), (64, 128)]
+    assert ops._batch_slices(160, img, img) == [(0, 80), (80, 160)]
+    for n, a, b in ((192, img, img), (300, img, 2 * img), (7, 700_000_000, 1), (1, 3_000_000_000, 1), (1000, img // 4, img)):
+        sl = ops._batch_slices(n, a, b)
+        assert sl[0][0] == 0 and sl[-1][1] == n and all(p[1] == q[0] for p, q in zip(sl, sl[1:]))
+        assert all((n1 - n0) * max(a, b) <= (1 << 31) - 1 or n1 - n0 == 1 for n0, n1 in sl)
+        assert max(n1 - n0 for n0, n1 in sl) - min(n1 - n0 for n0, n1 in sl) <= max(1, len(sl))

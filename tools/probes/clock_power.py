@@ -14,9 +14,26 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def _my_card():
+    """the DRM card of HIP device 0 of THIS process (the box has many GPUs; card0 is usually somebody else's): matched by PCI address"""
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; p = torch.cuda.get_device_properties(0); "
+                            "print('%04x:%02x:%02x' % (getattr(p, 'pci_domain_id', 0), p.pci_bus_id, p.pci_device_id))"],
+                           capture_output=True, text=True, timeout=300)
+        want = r.stdout.strip().splitlines()[-1].lower()
+    except Exception:
+        return None
+    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        if os.path.basename(os.path.realpath(card)).lower().startswith(want):
+            return card
+    return None
+
+
 def _find():
     out = {"sclk": None, "power": None, "dpm": None}
-    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+    mine = _my_card()
+    print("HIP device 0 is", mine)
+    for card in ([mine] if mine else sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))):
         for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
             for k, names in (("sclk", ("freq1_input",)), ("power", ("power1_average", "power1_input"))):
                 for n in names:
