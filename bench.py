@@ -248,6 +248,57 @@ def _wrap_dp(model, args, ddp, local_rank):
     return net, reducer
 
 
+class _ClockPower:
+    """Shader clock and package power of the benched GPU over the timed region, from the amdgpu hwmon files of the card
+    the HIP device maps to (matched by PCI address; profiles/r04_clock_power.txt shows the same files per kernel).  A daemon thread
+    reads two small sysfs files every 20 ms: no GPU work, no synchronisation.  Everything is None where the files are not readable."""
+
+    def __init__(self, dev):
+        import glob
+        import threading
+        self.rows, self.on, self.files, self._th = [], False, None, None
+        try:
+            p = torch.cuda.get_device_properties(dev)
+            want = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+            for card in glob.glob("/sys/class/drm/card[0-9]*/device"):
+                if os.path.basename(os.path.realpath(card)).lower().startswith(want):
+                    for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
+                        f, w = os.path.join(hw, "freq1_input"), os.path.join(hw, "power1_input")
+                        if os.path.exists(f):
+                            self.files = (f, w if os.path.exists(w) else os.path.join(hw, "power1_average"))
+            if self.files:
+                self._th = threading.Thread(target=self._run, daemon=True)
+        except Exception:
+            self.files = None
+
+    def _run(self):
+        while self.on:
+            try:
+                with open(self.files[0]) as f:
+                    hz = int(f.read())
+                with open(self.files[1]) as f:
+                    uw = int(f.read())
+                self.rows.append((hz / 1e6, uw / 1e6))
+            except (OSError, ValueError):
+                pass
+            time.sleep(0.02)
+
+    def start(self):
+        if self._th is not None:
+            self.on = True
+            self._th.start()
+
+    def stop(self):
+        self.on = False
+        if self._th is not None:
+            self._th.join(timeout=1.0)
+        if not self.rows:
+            return None
+        mhz, w = [r[0] for r in self.rows], [r[1] for r in self.rows]
+        return {"sustained_clock_mhz": round(sum(mhz) / len(mhz), 0), "min_clock_mhz": round(min(mhz), 0),
+                "package_power_w": round(sum(w) / len(w), 0), "max_package_power_w": round(max(w), 0), "samples": len(mhz)}
+
+
 def _timed(step, args, ddp, dev, on_start=None):
     for _ in range(args.warmup):
         step()
@@ -344,7 +395,15 @@ def run_vq(args):
         return loss
 
     torch.cuda.reset_peak_memory_stats(dev)
-    dt, final_loss = _timed(step, args, ddp, dev, on_start=lambda on: dom.__setitem__("on", on))
+    cp = _ClockPower(dev) if rank == 0 else None
+
+    def on_start(on):
+        dom["on"] = on
+        if cp is not None and on:
+            cp.start()
+
+    dt, final_loss = _timed(step, args, ddp, dev, on_start=on_start)
+    clock_power = cp.stop() if cp is not None else None
     ops.set_launch_hook(None)
     peak_gib = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     spread = _replica_spread(model, ddp)
@@ -401,6 +460,17 @@ def run_vq(args):
             # compiled out (profiles/r02_wide_store_ablation.txt / DESIGN R2.2: 0.466 ms at the ~1.6 GHz the chip sustains under this
             # load = 1.33 PFLOP/s): the vendor peak `frac` is priced against assumes 2.4 GHz
             out["roofline"]["mfma_only_floor_ms"] = 0.466
+            # the whole step's shader clock and package power (hwmon, sampled every 20 ms over the timed region): the convolution kernels
+            # run into the ~1.4 kW package cap and the firmware lowers the clock (profiles/r04_clock_power.txt: 1.70-1.76 GHz under the wide
+            # kernel); `frac` above is priced against the vendor peak at 2.4 GHz, `frac_of_peak_at_sustained_clock` against the same matrix
+            # cores at the clock this step actually sustained
+            if clock_power:
+                out["roofline"].update(clock_power)
+                peak_s = peak * clock_power["sustained_clock_mhz"] / 2400.0
+                out["roofline"]["peak_at_sustained_clock"] = round(peak_s, 1)
+                out["roofline"]["frac_of_peak_at_sustained_clock"] = round(ach / peak_s, 4)
+            else:
+                out["roofline"]["sustained_clock_mhz"] = None
             out["roofline"]["mfma_only_floor_source"] = "committed ablation (kbench, MFMA + LDS reads only), not measured by this run"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch, all_cores=args.cpu_baseline_all_cores)

@@ -34,11 +34,8 @@ struct AttnParams {
 // 1.5 rounds of the 1024 resident work-groups.  With the tile index in blockIdx.x the dispatcher hands out heavy and light work-groups
 // interleaved, head by head, and the last heads' heaviest tiles START late: makespan ~ 7 + 24 tile-times where the balanced load is
 // 19.5.  With (B * H) in blockIdx.x and the heaviest tile in blockIdx.y = 0 the dispatch order is longest-processing-time-first, and
-// a head's work-groups all land on XCD (head % 8): its K / V stay in one L2.  MAS_ATTN_LPT=0 restores the old order.
-static int fa_lpt() {
-    static const int v = mas_env_int("MAS_ATTN_LPT", 1);
-    return v;
-}
+// a head's work-groups all land on XCD (head % 8): its K / V stay in one L2 (49.0 -> 46.2 ms per MakeAScene step, profiles/r03_attn_lpt.txt).
+static int fa_lpt() { return 1; }
 
 template <typename T, int HD>
 __global__ __launch_bounds__(NT) void attn_causal_fwd_kernel(AttnParams p) {
@@ -599,7 +596,7 @@ int launch_fwd_fast(const AttnParams& p, hipStream_t s) {
     return MAS_OK;
 }
 
-inline bool attn_generic() { static const int v = mas_env_int("MAS_ATTN_GENERIC", 0); return v != 0; }   // A/B knob
+inline bool attn_generic() { return false; }
 inline bool fa_aligned(const void* ptr, long long bs, int ld) {
     return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && (bs % 8) == 0 && (ld % 8) == 0;
 }
@@ -1242,9 +1239,8 @@ extern "C" int mas_attn_causal_fwd(const void* q, const void* k, const void* v, 
                           (reinterpret_cast<uintptr_t>(o) & 7) == 0 && !attn_generic();
         if (fast) {
             // v2 (DMA staging, swizzled unpadded LDS, 4 work-groups per CU) needs 31-bit byte offsets inside one (batch, head) slab
-            static const int v2 = mas_env_int("MAS_ATTN_FWD_V2", 1);
             const bool small = (long long)S * ld_k * 2 < 0x7fffffffLL && (long long)S * ld_v * 2 < 0x7fffffffLL;
-            if (hd == 64 && v2 && small) return launch_fwd_fast_v2(p, s);
+            if (hd == 64 && small) return launch_fwd_fast_v2(p, s);
             return hd == 64 ? launch_fwd_fast<64>(p, s) : launch_fwd_fast<128>(p, s);
         }
         return launch_hd<bf16_t>(p, hd, s);

@@ -35,7 +35,6 @@ struct WideParams {
     int N, H, W, Cin, Ho, Wo, Cout;
     int Hl, Wl, pad_top, pad_left, upsample, act;
     int n_chunks, Cout_pad, tiles_h, tiles_w, n_ct;
-    int stagger;                               // experiment: work-group b sleeps (b * 5 % 8) * stagger * 8128 cycles before its first tile
     unsigned m_ct, m_tw, m_th;                 // ceil(2^32 / d) for d = n_ct, tiles_w, tiles_h: t / d == umulhi(t, m) (host checks t * d < 2^32)
 };
 
@@ -258,10 +257,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
         W_WAIT_BARRIER(0);                       // the raw patch of chunk 0 has landed for every wave, the table is visible
         ss_fetch(0, 0);
         p_activate(inb_cur, 0);
-    }
-    if (p.stagger > 0) {
-        const int n = (int)((blockIdx.x * 5u) % 8u) * p.stagger;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
     }
     // fused GroupNorm statistics (p.stats): the epilogue leaves per-wave partial sums in LDS; after the next work-group barrier 256
     // threads add the 8 waves in a fixed order and write the tile's row of the statistics table (no atomics: deterministic)
@@ -586,8 +581,6 @@ int mas_conv3x3_wide_launch(const MasConvDesc* d, const void* x, const float* sc
     p.pad_top = d->pad_top; p.pad_left = d->pad_left; p.upsample = d->upsample; p.act = d->act;
     p.n_chunks = d->Cin / 32; p.Cout_pad = mas_roundup(d->Cout, 128);
     p.tiles_h = mas_cdiv(d->Ho, 16); p.tiles_w = mas_cdiv(d->Wo, 32); p.n_ct = d->Cout / 128;
-    static const int stagger = mas_env_int("MAS_CONV_WIDE_STAGGER", 0);
-    p.stagger = stagger;
     auto magic = [](int dv) { return (unsigned)((0x100000000ULL + (unsigned)dv - 1) / (unsigned)dv); };   // (d = 1 handled in the kernel)
     p.m_ct = magic(p.n_ct); p.m_tw = magic(p.tiles_w); p.m_th = magic(p.tiles_h);
     if (stats) {

@@ -529,8 +529,6 @@ int launch_v(const ConvParams& p0, hipStream_t s) {
     p.tiles_h = mas_cdiv(p.Ho, G::TH); p.tiles_w = mas_cdiv(p.Wo, TW);
     constexpr int TPS = (BIG == 1 && KS == 3) ? 3 : 1;
     size_t lds = (size_t)G::PATCH_BYTES + 2 * TPS * BC * 128;
-    static const int lds_pad = mas_env_int("MAS_CONV_LDS_PAD", 0);            // experiment knob: lower residency
-    lds += (size_t)lds_pad;
     auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, BC, WC, VEC, BIG>;
     static mas_devmask_t attr_mask{0};
     unsigned long long attr_bit;
@@ -549,7 +547,7 @@ int launch_v(const ConvParams& p0, hipStream_t s) {
     // displaced work-groups as a second full round (2x), this runs them as a fifth quarter-round (1.25x).  Measured cost
     // of the 4x on an idle GPU: < 0.5 % (kbench / bench.py).
     long long resident = 4LL * (BIG ? 1LL : 2LL) * mas_num_cus();
-    static const int wgs_per_cu = mas_env_int("MAS_CONV_WGS_PER_CU", 0);      // experiment knob: grid size in work-groups per CU
+    static const int wgs_per_cu = mas_env_int("MAS_CONV_WGS_PER_CU", 0);      // tests: one work-group per CU -> several tiles per work-group
     if (wgs_per_cu > 0) resident = (long long)wgs_per_cu * mas_num_cus();
     const unsigned blocks = (unsigned)(tiles < resident ? tiles : resident);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, s, q);
@@ -564,10 +562,8 @@ int launch(const ConvParams& p, hipStream_t s) {
             // 16x16 tiles when they still fill the chip at one (8-wave) work-group per CU
             const long long big_tiles = (long long)p.N * mas_cdiv(p.Ho, 16) * mas_cdiv(p.Wo, TW) * mas_cdiv(p.Cout, BC);
             const long long huge_tiles = (long long)p.N * mas_cdiv(p.Ho, 32) * mas_cdiv(p.Wo, TW) * mas_cdiv(p.Cout, BC);
-            static const int force = mas_env_int("MAS_CONV_TILE", -1);   // experiment knob: 0 / 1 / 2
-            (void)huge_tiles;   // level 2 spills today (acc 128 + prefetch 40 + fragments 48 VGPRs): experiment only
-            if (force == 2) return launch_v<T, TO, KS, STRIDE, BC, WC, true, 2>(p, s);
-            if (force >= 0 ? force == 1 : (big_tiles >= 2LL * mas_num_cus())) return launch_v<T, TO, KS, STRIDE, BC, WC, true, 1>(p, s);
+            (void)huge_tiles;   // (a 32x16 level spills: acc 128 + prefetch 40 + fragments 48 VGPRs; never dispatched)
+            if (big_tiles >= 2LL * mas_num_cus()) return launch_v<T, TO, KS, STRIDE, BC, WC, true, 1>(p, s);
         }
         return launch_v<T, TO, KS, STRIDE, BC, WC, true, 0>(p, s);
     }
@@ -580,9 +576,8 @@ int launch_bc(const ConvParams& p, hipStream_t s) {
     if (p.Cout <= 64) return launch<T, TO, KS, STRIDE, 64, 1>(p, s);
     // Small maps (the 16x16 level of the encoder / decoder: 512 -> 512 at batch 32 is 256 tiles of 8x16 pixels x 128 couts) leave half
     // of the chip's 2 x 256 work-group slots empty -- one wave per SIMD, nothing to overlap with; 64-cout tiles double the work-groups
-    // (the packed weight image is row-addressed: any 64-row window of it is a valid tile).  MAS_CONV_BC64=0: always 128.
-    static const int bc64 = mas_env_int("MAS_CONV_BC64", 1);
-    if (bc64 && STRIDE == 1) {                  // (stride 2 measured slower with 64-cout tiles: 0.114 vs 0.083 ms at 512 -> 512 @32^2)
+    // (the packed weight image is row-addressed: any 64-row window of it is a valid tile): -0.5 ms per VQ-IMG step (DESIGN history R3).
+    if (STRIDE == 1) {                  // (stride 2 measured slower with 64-cout tiles: 0.114 vs 0.083 ms at 512 -> 512 @32^2)
         const long long tiles128 = (long long)p.N * mas_cdiv(p.Ho, 8) * mas_cdiv(p.Wo, TW) * mas_cdiv(p.Cout, 128);
         if (tiles128 < 2LL * mas_num_cus()) return launch<T, TO, KS, STRIDE, 64, 1>(p, s);
     }

@@ -767,8 +767,7 @@ int launch(WgradParams p, hipStream_t s) {
 template <typename T>
 int launch_t(const WgradParams& p, int ks, int stride, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
-        static const int no_tr = mas_env_int("MAS_WGRAD_NO_TR", 0);        // A/B knob: the transposed-staging kernel for every shape
-        if (stride == 1 && (p.Cout % 8) == 0 && (p.Cin % 8) == 0 && !no_tr) {
+        if (stride == 1 && (p.Cout % 8) == 0 && (p.Cin % 8) == 0) {
             if (ks == 3) return launch_tr<3>(p, s);
             if (ks == 1) return launch_tr<1>(p, s);
             // discriminator geometries (reference losses/discriminator.py:20-36): 4x4 stride 1 directly (32-channel input

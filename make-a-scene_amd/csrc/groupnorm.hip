@@ -859,16 +859,12 @@ __global__ __launch_bounds__(512, 4) void gn_bwd_queue_kernel(GnQueueParams p) {
 // Pass ordering against the Infinity Cache (256 MiB, memory side): the tensors of the 256x256 / 128x128 levels are 134-537 MB, so a
 // pass that re-walks a tensor in the SAME direction as the pass before it finds everything it needs already evicted, while the
 // opposite direction starts on the most recently touched ~quarter.  Convolutions and the backward apply pass walk images front
-// to back; the two reduction passes (statistics, backward partial sums) walk back to front.  MAS_GN_REVERSE=0 restores
-// front-to-back everywhere (A/B knob).
-int gn_reverse() {
-    static const int r = mas_env_int("MAS_GN_REVERSE", 1);
-    return r;
-}
+// to back; the two reduction passes (statistics, backward partial sums) walk back to front (+0.1 ms per step, DESIGN history R3).
+int gn_reverse() { return 1; }
 
 int pick_split(int N, int HW, int max_split = MAX_SPLIT) {
     // enough blocks to fill 256 CUs a few times over, but >= 64 pixels per block
-    static const int target = mas_env_int("MAS_GN_SPLIT_BLOCKS", 1024);
+    constexpr int target = 1024;                    // (512 / 2048 measured within 1 %: profiles/r03_gn_streaming.txt)
     int s = mas_cdiv(target, N);
     if (s > max_split) s = max_split;
     const int cap = HW / 64 > 0 ? HW / 64 : 1;
@@ -1098,7 +1094,7 @@ extern "C" int mas_gn_bwd_3pass(const void* x, const void* da, const void* dres,
     const size_t lds1 = ((size_t)2 * C + (size_t)NT * epu * 2) * sizeof(float);
     const bool pk = dtype == MAS_BF16;                               // (NT % (C / 8) == 0 was checked above)
     const long long units_per_n = (long long)HW * C / epu;
-    static const int apply_blocks = mas_env_int("MAS_GN_APPLY_BLOCKS", 4096);
+    constexpr int apply_blocks = 4096;
     const int nsplit = pick_split(N, HW);
     if (pk && silu)
         hipLaunchKernelGGL(gn_bwd_partial_pk<true>, dim3(N * nsplit), dim3(NT), lds1, s, (const bf16_t*)x, (const bf16_t*)da, HW, C, G, nsplit, mean_rstd, scale_shift, partial, gn_reverse());

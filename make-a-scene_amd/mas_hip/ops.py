@@ -1078,27 +1078,6 @@ def colsum(x2d: torch.Tensor) -> torch.Tensor:
     return out
 
 
-# MAS_LINEAR_FP32_DW=1: weight gradients straight from the GEMM's fp32 accumulators (torch.mm(..., out_dtype=float32): no bf16
-# rounding, no cast kernel).  Off by default: that call is outside TunableOp, so the K = 12288 weight-gradient shapes fall back to the
-# library's default solution (148 us instead of the tuned 103-125 us): 53.4 ms per MakeAScene step with it, 52.3 ms without.
-_mm_fp32_out = {"ok": None if os.environ.get("MAS_LINEAR_FP32_DW", "0") == "1" else False}
-
-
-def _mm_to_fp32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a @ b (bf16 operands) with an fp32 result: straight from the GEMM's fp32 accumulators where the library build supports an
-    fp32 output for bf16 inputs (no bf16 rounding of the weight gradient, no cast kernel), else GEMM + cast."""
-    if _mm_fp32_out["ok"] is not False:
-        try:
-            out = torch.mm(a, b, out_dtype=torch.float32)
-            _mm_fp32_out["ok"] = True
-            return out
-        except (TypeError, RuntimeError):
-            if _mm_fp32_out["ok"]:
-                raise
-            _mm_fp32_out["ok"] = False
-    return torch.mm(a, b).float()
-
-
 class _Bf16Shadows:
     """bf16 copies of the fp32 parameters of every registered Linear layer, refreshed TOGETHER: the first layer that finds its copy
     stale (an optimizer step or an in-place write changed its stamp) recasts every stale parameter in one multi-tensor launch
@@ -1149,7 +1128,7 @@ class _LinearBf16(torch.autograd.Function):
     """y = x W^T + b with bf16 operands / fp32 accumulation (what ``torch.autocast(bfloat16)`` makes of nn.Linear, reference
     models/transformer.py:31,34,125,126), as ONE autograd node: forward and the two backward products are the library GEMMs,
     the bias gradient is ``mas_colsum`` (fp32, fixed order) instead of a generic reduction + cast; the weight gradient is the
-    GEMM's bf16 result cast to fp32 (or, ``MAS_LINEAR_FP32_DW=1``, its fp32 accumulators directly)."""
+    GEMM's bf16 result cast to fp32."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -1176,7 +1155,7 @@ class _LinearBf16(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = torch.mm(dy2, wb).view(ctx.in_shape).to(ctx.in_dtype)
             if ctx.needs_input_grad[1]:
-                dw = _mm_to_fp32(dy2.t(), x2)
+                dw = torch.mm(dy2.t(), x2).float()     # (fp32 straight from the accumulators is outside TunableOp: +1 ms per step, DESIGN history R2)
             if ctx.needs_input_grad[2]:
                 db = colsum(dy2)
         return dx, dw, db

@@ -32,9 +32,6 @@ def gelu(x):
     return ops.gelu_tanh(x)
 
 
-_LN_FORK = os.environ.get("MAS_LN_FORK", "1") == "1"      # A/B switch: pre-LayerNorm + skip connection as one autograd node
-
-
 class LayerNorm(nn.LayerNorm):
     """nn.LayerNorm parameters / state_dict keys, HIP forward + backward; ``residual`` fuses the ``x + LN(.)`` of the
     sandwich LayerNorms (reference transformer.py:201-203,207-209)."""
@@ -195,7 +192,7 @@ class TransformerLayer(nn.Module):
     def forward(self, x, mask, cache=None, use_cache=False, mlp_cache=False):
         if use_cache:
             return self._forward_cached(x, cache)
-        fork = _LN_FORK and not self.cogview_layernorm_prescale      # (the prescale variant divides x before the LayerNorm: plain path)
+        fork = not self.cogview_layernorm_prescale      # (the prescale variant divides x before the LayerNorm: plain path)
         ln, skip = self.ln_in.fork(x) if fork else (self.ln_in(self._prescale(x)), x)
         attn_out, new_cache = self.attn(ln, mask, False, cache)
         if self.cogview_sandwich_layernorm:
