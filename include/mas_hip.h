@@ -146,6 +146,14 @@ int    mas_gn_bwd_plan(int N, int HW, int C, int G, int num_cus, int* plan);
  * which the convolution and its weight gradient run prologue-free (act = NONE) on `a`.                                          */
 int mas_gn_act(const void* x, void* a, int dtype, int N, int HW, int C, int act, const float* scale_shift, void* stream);
 
+/* Small maps (bf16, h*w <= 1024 pixels, C % 64 == 0, whole groups inside a 64-channel block: mas_gn_small_supported != 0): the
+ * statistics of mas_gn_stats AND the tensor of mas_gn_act in ONE launch -- a work-group keeps an (image, 64-channel block) slab in
+ * registers between the reduction and the element-wise phase; three dependent launches become one.  mas_gn_bwd takes the matching
+ * backward kernel for such tensors by itself (one launch + the batch sums for dgamma / dbeta).                                     */
+int mas_gn_small_supported(int dtype, int HW, int C, int G);
+int mas_gn_stats_act(const void* x, void* a, int dtype, int N, int HW, int C, int G, float eps, const float* gamma,
+                     const float* beta, int act, float* mean_rstd, float* scale_shift, void* stream);
+
 /* ---- convolution forward  (replaces F.conv2d at modules.py:49,68,93,100,113,145-160,
  * 219,236,345,364 and vqvae.py:15,18, with the GroupNorm-apply/SiLU of modules.py:121-128
  * fused into the input loader and bias / residual add (modules.py:136,191) into the epilogue).

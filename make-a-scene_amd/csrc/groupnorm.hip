@@ -571,6 +571,224 @@ __global__ __launch_bounds__(NT) void gn_act_kernel(const T* __restrict__ x, T* 
 }
 
 // ---------------------------------------------------------------------------------------
+// Small maps (h*w <= 1024 pixels: the 16x16 and 32x32 levels, 47 of the 67 GroupNorms of VQ-IMG): one work-group owns the slab
+// (image n, 64-channel block) -- 32 KB at 16x16, 128 KB at 32x32 -- and KEEPS IT IN REGISTERS between the reduction and the
+// element-wise phase.  The groups of a block lie inside it (64 % (C / G) == 0), so nothing is exchanged between work-groups:
+//   forward : statistics + finalize + activation as ONE launch instead of three (gn_stats_partial 16 us + gn_stats_finalize 6.5 us +
+//             gn_act 6 us at 512 ch @16^2 x 32: three dependent launches whose latency is their cost), x read once;
+//   backward: partial sums + coefficients + apply as ONE launch instead of three, x / da read once; the sums over the batch for
+//             dgamma / dbeta follow as a second, tiny launch (fixed order: bitwise reproducible, no atomics).
+// A pixel's 64 channels of the block are 128 contiguous bytes = 8 units of 16 bytes: thread t owns unit t % 8 of pixels t / 8,
+// t / 8 + T / 8, ... (a wave reads 8 whole 128-byte lines per load instruction).
+constexpr int GS_MAXU = 16;                         // 16-byte units a thread holds per tensor: 1024 pixels x 8 units / 512 threads
+
+struct GnSmallParams {
+    const bf16_t* x; const bf16_t* da; const bf16_t* dres; bf16_t* out;      // out: a (forward) or dx (backward)
+    const float* gamma; const float* beta;
+    float* mean_rstd; float* ss; float* nsum;                                // forward WRITES mean_rstd / ss, backward reads them
+    int N, HW, C, G, act;
+    float eps;
+};
+
+// CB = channels of the block (64: a pixel's block is one 128-byte line = 8 units; 32: 4 units -- the backward at 32x32, whose two
+// tensors would not fit the registers at 64): thread t owns unit t % (CB / 8) of pixels t / (CB / 8), + TP, + 2 TP, ...
+template <int UNITS, int CB>
+__device__ __forceinline__ void gs_load(u32x4 (&v)[UNITS], const bf16_t* base, int C, int HW, int pl, int cu, int TP) {
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+        const int px = pl + k * TP;
+        v[k] = u32x4{0u, 0u, 0u, 0u};
+        if (px < HW) v[k] = *reinterpret_cast<const u32x4*>(base + (size_t)px * C + cu * 8);
+    }
+}
+
+// per-channel sums over the pixel lanes, fixed order: slots [TP][CB][2] -> tot [CB][2] (fp32), visible after the trailing barrier
+template <int CB>
+__device__ __forceinline__ void gs_fold(float* slots, float* tot, const f32x2 (&a)[4], const f32x2 (&b)[4], int pl, int cu, int TP, int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            slots[((size_t)pl * CB + cu * 8 + 2 * q + h) * 2 + 0] = a[q][h];
+            slots[((size_t)pl * CB + cu * 8 + 2 * q + h) * 2 + 1] = b[q][h];
+        }
+    __syncthreads();
+    if (tid < 2 * CB) {
+        float acc = 0.0f;
+        for (int k = 0; k < TP; ++k) acc += slots[(size_t)k * 2 * CB + tid];
+        tot[tid] = acc;
+    }
+    __syncthreads();
+}
+
+template <int UNITS>
+__global__ __launch_bounds__(512) void gn_small_fwd_kernel(GnSmallParams p) {
+    constexpr int CB = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ssm[];
+    float* slots = reinterpret_cast<float*>(ssm);                    // [TP][CB][2]
+    const int tid = threadIdx.x, TP = blockDim.x / (CB / 8);
+    float* tot = slots + (size_t)TP * 2 * CB;                        // [CB][2] sum, sum of squares
+    float* cof = tot + 2 * CB;                                       // [CB][2] scale, shift
+    const int C = p.C, HW = p.HW, cpg = C / p.G, nb = C / CB;
+    const int n = blockIdx.x / nb, c0 = (blockIdx.x % nb) * CB;
+    const int cu = tid % (CB / 8), pl = tid / (CB / 8);
+    const bf16_t* xb = p.x + (size_t)n * HW * C + c0;
+    u32x4 xv[UNITS];
+    gs_load<UNITS, CB>(xv, xb, C, HW, pl, cu, TP);
+    f32x2 s[4], q2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s[q] = f32x2{0.0f, 0.0f}; q2[q] = f32x2{0.0f, 0.0f}; }
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const f32x2 v = bf16pair_f32(xv[k][q]); s[q] += v; q2[q] += v * v; }
+    gs_fold<CB>(slots, tot, s, q2, pl, cu, TP, tid);
+    if (tid < CB) {                                                  // thread = channel c0 + tid: its group's statistics (fp64 combination)
+        const int g0 = (tid / cpg) * cpg;
+        double sm = 0.0, sq = 0.0;
+        for (int j = 0; j < cpg; ++j) { sm += (double)tot[2 * (g0 + j)]; sq += (double)tot[2 * (g0 + j) + 1]; }
+        const double m = (double)cpg * (double)HW, mean = sm / m;
+        double var = sq / m - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        const int c = c0 + tid;
+        const float ga = p.gamma ? p.gamma[c] : 1.0f, be = p.beta ? p.beta[c] : 0.0f;
+        const float sc = rstd * ga, sh = be - (float)mean * sc;
+        cof[2 * tid] = sc; cof[2 * tid + 1] = sh;
+        p.ss[((size_t)n * C + c) * 2 + 0] = sc; p.ss[((size_t)n * C + c) * 2 + 1] = sh;
+        if (tid % cpg == 0) {
+            p.mean_rstd[((size_t)n * p.G + c / cpg) * 2 + 0] = (float)mean;
+            p.mean_rstd[((size_t)n * p.G + c / cpg) * 2 + 1] = rstd;
+        }
+    }
+    __syncthreads();
+    f32x2 sc[4], sh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sc[q] = f32x2{cof[2 * (cu * 8 + 2 * q)], cof[2 * (cu * 8 + 2 * q + 1)]};
+        sh[q] = f32x2{cof[2 * (cu * 8 + 2 * q) + 1], cof[2 * (cu * 8 + 2 * q + 1) + 1]};
+    }
+    bf16_t* ab = p.out + (size_t)n * HW * C + c0;
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+        const int px = pl + k * TP;
+        if (px >= HW) continue;
+        u32x4 v = xv[k];
+        if (p.act == MAS_ACT_AFFINE_SILU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = act_pair_bf16<true>(v[q], sc[q], sh[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = act_pair_bf16<false>(v[q], sc[q], sh[q]);
+        }
+        *reinterpret_cast<u32x4*>(ab + (size_t)px * C + cu * 8) = v;
+    }
+}
+
+template <int UNITS, int CB, bool SILU, bool RES>
+__global__ __launch_bounds__(512) void gn_small_bwd_kernel(GnSmallParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ssm[];
+    float* slots = reinterpret_cast<float*>(ssm);
+    const int tid = threadIdx.x, TP = blockDim.x / (CB / 8);
+    float* tot = slots + (size_t)TP * 2 * CB;                        // [CB][2] S1 (sum du), S2 (sum du * xhat)
+    float* cof = tot + 2 * CB;                                       // [CB][4] c1, k2, k3
+    const int C = p.C, HW = p.HW, cpg = C / p.G, nb = C / CB;
+    const int n = blockIdx.x / nb, c0 = (blockIdx.x % nb) * CB;
+    const int cu = tid % (CB / 8), pl = tid / (CB / 8);
+    const size_t ib = (size_t)n * HW * C + c0;
+    u32x4 xv[UNITS], dv[UNITS];
+    gs_load<UNITS, CB>(xv, p.x + ib, C, HW, pl, cu, TP);
+    gs_load<UNITS, CB>(dv, p.da + ib, C, HW, pl, cu, TP);
+    f32x2 sc[4], sh[4], xr[4], xb[4], s1[4], s2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = c0 + cu * 8 + 2 * q + h;
+            sc[q][h] = p.ss[((size_t)n * C + c) * 2 + 0]; sh[q][h] = p.ss[((size_t)n * C + c) * 2 + 1];
+            const float mu = p.mean_rstd[((size_t)n * p.G + c / cpg) * 2 + 0], rs = p.mean_rstd[((size_t)n * p.G + c / cpg) * 2 + 1];
+            xr[q][h] = rs; xb[q][h] = -mu * rs;
+            s1[q][h] = 0.0f; s2[q][h] = 0.0f;
+        }
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                                // (pixels beyond HW were loaded as zeros: they add nothing)
+            const f32x2 xe = bf16pair_f32(xv[k][q]);
+            f32x2 du = bf16pair_f32(dv[k][q]);
+            if constexpr (SILU) du = du * dsilu2_f(xe * sc[q] + sh[q]);
+            s1[q] += du; s2[q] += du * (xe * xr[q] + xb[q]);
+        }
+    gs_fold<CB>(slots, tot, s1, s2, pl, cu, TP, tid);
+    if (tid < CB) {
+        const int c = c0 + tid, g0 = (tid / cpg) * cpg;
+        double A = 0.0, B = 0.0;
+        for (int j = 0; j < cpg; ++j) {
+            const double ga = p.gamma ? (double)p.gamma[c0 + g0 + j] : 1.0;
+            A += ga * (double)tot[2 * (g0 + j)]; B += ga * (double)tot[2 * (g0 + j) + 1];
+        }
+        const double mean = p.mean_rstd[((size_t)n * p.G + c / cpg) * 2 + 0], rstd = p.mean_rstd[((size_t)n * p.G + c / cpg) * 2 + 1];
+        const double m = (double)cpg * (double)HW;
+        cof[4 * tid + 0] = (float)(rstd * (p.gamma ? (double)p.gamma[c] : 1.0));
+        cof[4 * tid + 1] = (float)(-rstd * rstd * B / m);
+        cof[4 * tid + 2] = (float)(rstd * (mean * rstd * B - A) / m);
+        p.nsum[((size_t)n * C + c) * 2 + 0] = tot[2 * tid + 1];      // -> dgamma
+        p.nsum[((size_t)n * C + c) * 2 + 1] = tot[2 * tid];          // -> dbeta
+    }
+    __syncthreads();
+    f32x2 k0[4], k1[4], k2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int cl = cu * 8 + 2 * q + h;
+            k0[q][h] = cof[4 * cl]; k1[q][h] = cof[4 * cl + 1]; k2[q][h] = cof[4 * cl + 2];
+        }
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+        const int px = pl + k * TP;
+        if (px >= HW) continue;
+        const size_t off = ib + (size_t)px * C + cu * 8;
+        u32x4 rr = {0u, 0u, 0u, 0u};
+        if constexpr (RES) rr = *reinterpret_cast<const u32x4*>(p.dres + off);
+        u32x4 ov;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x2 xe = bf16pair_f32(xv[k][q]);
+            f32x2 du = bf16pair_f32(dv[k][q]);
+            if constexpr (SILU) du = du * dsilu2_f(xe * sc[q] + sh[q]);
+            f32x2 v = k0[q] * du + (k1[q] * xe + k2[q]);
+            if constexpr (RES) v = v + bf16pair_f32(rr[q]);
+            ov[q] = f32pair_bf16(v);
+        }
+        *reinterpret_cast<u32x4*>(p.out + off) = ov;
+    }
+}
+
+// dgamma / dbeta = sums over the batch of nsum [N][C][2] (fp64, image order)
+__global__ __launch_bounds__(NT) void gn_param_reduce_kernel(const float* __restrict__ nsum, int N, int C, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int m = 0; m < N; ++m) { a += (double)nsum[((size_t)m * C + c) * 2 + 0]; b += (double)nsum[((size_t)m * C + c) * 2 + 1]; }
+    if (dgamma) dgamma[c] = (float)a;
+    if (dbeta) dbeta[c] = (float)b;
+}
+
+// the small-map kernels take bf16 tensors of at most 1024 pixels whose channel count is a multiple of 64 with whole groups per block
+inline bool gn_small_ok(int dtype, int HW, int C, int G) {
+    static const int on = mas_env_int("MAS_GN_SMALL", 1);
+    return on && dtype == MAS_BF16 && HW >= 1 && HW <= 1024 && C % 64 == 0 && C % G == 0 && 64 % (C / G) == 0 && 32 % (C / G) == 0;
+}
+// forward: 64-channel blocks, <= 16 units per thread;  backward: <= 8 units of each of x / da per thread -- 64-channel blocks up to 512
+// pixels, 32-channel blocks above
+inline int gn_small_threads(int HW) { return HW <= 256 ? 256 : 512; }
+inline int gn_small_bwd_cb(int HW) { return HW <= 512 ? 64 : 32; }
+inline int gn_small_units(int HW, int cb) { const int t = gn_small_threads(HW); return (HW * (cb / 8) + t - 1) / t; }
+inline size_t gn_small_lds(int HW, int cb) { return ((size_t)gn_small_threads(HW) / (cb / 8) * 2 * cb + 2 * cb + 4 * cb) * sizeof(float); }
+
+// ---------------------------------------------------------------------------------------
 // GroupNorm(+SiLU) backward as ONE persistent launch (bf16): reduce -> finalize -> apply per IMAGE GROUP, the groups pipelined through
 // the launch, so that the apply phase re-reads x / da while the group still sits in the 256 MiB Infinity Cache instead of from HBM: HBM
 // sees x and da once.  The three-launch scheme above reads both twice (2.7 GB instead of 1.6 GB at 128 ch @256^2 x 32), and walking
@@ -937,6 +1155,49 @@ extern "C" int mas_gn_act(const void* x, void* a, int dtype, int N, int HW, int 
     return MAS_OK;
 }
 
+// ---- small maps: statistics + finalize + activation in one launch; the backward in one launch + the batch sums ----
+namespace {
+template <int UNITS>
+void gn_small_fwd_launch(const GnSmallParams& p, int T, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL(gn_small_fwd_kernel<UNITS>, dim3((unsigned)(p.N * (p.C / 64))), dim3(T), lds, s, p);
+}
+template <int UNITS, int CB>
+void gn_small_bwd_launch(const GnSmallParams& p, int T, size_t lds, hipStream_t s) {
+    const dim3 grid((unsigned)(p.N * (p.C / CB)));
+    const bool silu = p.act == MAS_ACT_AFFINE_SILU;
+    if (silu && p.dres) hipLaunchKernelGGL((gn_small_bwd_kernel<UNITS, CB, true, true>), grid, dim3(T), lds, s, p);
+    else if (silu) hipLaunchKernelGGL((gn_small_bwd_kernel<UNITS, CB, true, false>), grid, dim3(T), lds, s, p);
+    else if (p.dres) hipLaunchKernelGGL((gn_small_bwd_kernel<UNITS, CB, false, true>), grid, dim3(T), lds, s, p);
+    else hipLaunchKernelGGL((gn_small_bwd_kernel<UNITS, CB, false, false>), grid, dim3(T), lds, s, p);
+}
+}  // namespace
+
+extern "C" int mas_gn_small_supported(int dtype, int HW, int C, int G) { return (G > 0 && C > 0 && gn_small_ok(dtype, HW, C, G)) ? 1 : 0; }
+
+// GroupNorm statistics AND the materialised activation in one launch (small maps: mas_gn_small_supported): the same mean_rstd /
+// scale_shift as mas_gn_stats (up to the summation order) and a = act(x * scale + shift) exactly as mas_gn_act forms it from them.
+extern "C" int mas_gn_stats_act(const void* x, void* a, int dtype, int N, int HW, int C, int G, float eps, const float* gamma,
+                                const float* beta, int act, float* mean_rstd, float* scale_shift, void* stream) {
+    MAS_ENTER();
+    if (!x || !a || !mean_rstd || !scale_shift) MAS_FAIL(MAS_EINVAL, "gn_stats_act: null argument");
+    if (act != MAS_ACT_AFFINE && act != MAS_ACT_AFFINE_SILU) MAS_FAIL(MAS_EINVAL, "gn_stats_act: bad act %d", act);
+    if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G) MAS_FAIL(MAS_EINVAL, "gn_stats_act: bad shape");
+    if (!gn_small_ok(dtype, HW, C, G)) MAS_FAIL(MAS_EUNSUPPORTED, "gn_stats_act: needs bf16, h*w <= 1024, C %% 64 == 0, 64 %% (C / G) == 0");
+    GnSmallParams p{};
+    p.x = (const bf16_t*)x; p.out = (bf16_t*)a; p.gamma = gamma; p.beta = beta; p.mean_rstd = mean_rstd; p.ss = scale_shift;
+    p.N = N; p.HW = HW; p.C = C; p.G = G; p.act = act; p.eps = eps;
+    const int T = gn_small_threads(HW), u = gn_small_units(HW, 64);
+    const size_t lds = gn_small_lds(HW, 64);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (u <= 1) gn_small_fwd_launch<1>(p, T, lds, s);
+    else if (u <= 2) gn_small_fwd_launch<2>(p, T, lds, s);
+    else if (u <= 4) gn_small_fwd_launch<4>(p, T, lds, s);
+    else if (u <= 8) gn_small_fwd_launch<8>(p, T, lds, s);
+    else gn_small_fwd_launch<GS_MAXU>(p, T, lds, s);
+    MAS_CHECK_LAUNCH("gn_small_fwd");
+    return MAS_OK;
+}
+
 // ---- host side of the one-launch backward (gn_bwd_queue_kernel) ----
 namespace {
 constexpr int Q_MAX_LEAD = 4;                                        // ring of L + 2 group slots
@@ -1058,6 +1319,29 @@ extern "C" int mas_gn_bwd_1pass(const void* x, const void* da, const void* dres,
 extern "C" int mas_gn_bwd(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G, int act,
                           const float* gamma, const float* mean_rstd, const float* scale_shift, void* dx, float* dgamma,
                           float* dbeta, void* workspace, size_t ws_bytes, void* stream) {
+    if (x && da && dx && mean_rstd && scale_shift && workspace && N > 0 && G > 0 && C > 0 && C % G == 0 && (act == MAS_ACT_AFFINE || act == MAS_ACT_AFFINE_SILU) &&
+        gn_small_ok(dtype, HW, C, G) && ws_bytes >= mas_gn_bwd_workspace(N, C)) {
+        // small maps: the (image, 64-channel block) slab lives in registers between the sums and the element-wise phase (gn_small_bwd_kernel)
+        MAS_ENTER();
+        GnSmallParams p{};
+        p.x = (const bf16_t*)x; p.da = (const bf16_t*)da; p.dres = (const bf16_t*)dres; p.out = (bf16_t*)dx; p.gamma = gamma;
+        p.mean_rstd = const_cast<float*>(mean_rstd); p.ss = const_cast<float*>(scale_shift); p.nsum = reinterpret_cast<float*>(workspace);
+        p.N = N; p.HW = HW; p.C = C; p.G = G; p.act = act;
+        const int T = gn_small_threads(HW), cb = gn_small_bwd_cb(HW), u = gn_small_units(HW, cb);
+        const size_t lds = gn_small_lds(HW, cb);
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        if (cb == 32) gn_small_bwd_launch<8, 32>(p, T, lds, s);
+        else if (u <= 1) gn_small_bwd_launch<1, 64>(p, T, lds, s);
+        else if (u <= 2) gn_small_bwd_launch<2, 64>(p, T, lds, s);
+        else if (u <= 4) gn_small_bwd_launch<4, 64>(p, T, lds, s);
+        else gn_small_bwd_launch<8, 64>(p, T, lds, s);
+        MAS_CHECK_LAUNCH("gn_small_bwd");
+        if (dgamma || dbeta) {
+            hipLaunchKernelGGL(gn_param_reduce_kernel, dim3((unsigned)((C + NT - 1) / NT)), dim3(NT), 0, s, p.nsum, N, C, dgamma, dbeta);
+            MAS_CHECK_LAUNCH("gn_param_reduce");
+        }
+        return MAS_OK;
+    }
     static const int one = mas_env_int("MAS_GN_BWD_ONE_LAUNCH", 0);
     if (one && dtype == MAS_BF16) {
         const int rc = mas_gn_bwd_1pass(x, da, dres, dtype, N, HW, C, G, act, gamma, mean_rstd, scale_shift, dx, dgamma, dbeta, workspace, ws_bytes, stream);

@@ -61,6 +61,8 @@ _SIGNATURES = {
     "mas_gn_bwd_1pass": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "mas_gn_bwd_plan": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int)]),
     "mas_gn_act": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "mas_gn_small_supported": (_i, [_i, _i, _i, _i]),
+    "mas_gn_stats_act": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _i, _p, _p, _p]),
     "mas_conv_fwd": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p]),
     "mas_conv_stat_rows": (_i, [C.POINTER(ConvDesc)]),
     "mas_conv_fwd_stats": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -348,10 +348,36 @@ def gn_act(x: torch.Tensor, ss: torch.Tensor, act: int) -> torch.Tensor:
     return a
 
 
+_small_memo = {}
+
+
+def gn_small_ok(x: torch.Tensor, groups: int) -> bool:
+    """does the tensor take the small-map GroupNorm kernels (``mas_gn_small_supported``: bf16, h*w <= 1024, C % 64 == 0)?"""
+    n, c, h, w = x.shape
+    key = (x.dtype, h * w, c, groups)
+    ok = _small_memo.get(key)
+    if ok is None:
+        ok = _small_memo[key] = bool(x.dtype in _DT and lib().mas_gn_small_supported(_DT[x.dtype], h * w, c, groups))
+    return ok
+
+
+def gn_stats_act(x: torch.Tensor, gamma, beta, groups: int, eps: float, act: int):
+    """(mean_rstd, scale_shift, act(gn(x))) in ONE launch for small maps (``mas_gn_stats_act``; see ``gn_small_ok``): replaces
+    ``gn_stats`` + ``gn_act`` (three dependent launches) where the producing convolution left no fused statistics."""
+    n, c, h, w = x.shape
+    mr = torch.empty((n, groups, 2), dtype=torch.float32, device=x.device)
+    ss = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+    a = torch.empty_like(x, memory_format=torch.channels_last)
+    check(lib().mas_gn_stats_act(_ptr(x), _ptr(a), _DT[x.dtype], n, h * w, c, groups, float(eps), _ptr(gamma), _ptr(beta), act, _ptr(mr),
+                                 _ptr(ss), _stream()), "gn_stats_act")
+    return mr, ss, a
+
+
 def gn_bwd(x, da, dres, groups, act, gamma, mr, ss, path=None):
-    """GroupNorm(+SiLU) backward: (dx [+ dres], dgamma, dbeta).  ``path`` None: ``mas_gn_bwd`` (the library's choice: the faster of
-    the two on MI355X); "three": reduce / finalize / apply launches (``mas_gn_bwd_3pass``); "one": the persistent kernel that reads
-    x / da from HBM once (``mas_gn_bwd_1pass``, bf16; raises where the tensor has no plan)."""
+    """GroupNorm(+SiLU) backward: (dx [+ dres], dgamma, dbeta).  ``path`` None: ``mas_gn_bwd`` (the library's choice: the small-map
+    kernel up to 32x32 pixels, else the faster of the two below on MI355X); "three": reduce / finalize / apply launches
+    (``mas_gn_bwd_3pass``); "one": the persistent kernel that reads x / da from HBM once (``mas_gn_bwd_1pass``, bf16; raises where the
+    tensor has no plan)."""
     n, c, h, w = x.shape
     dx = torch.empty_like(x, memory_format=torch.channels_last)
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
@@ -577,25 +603,30 @@ class _NormActConv(torch.autograd.Function):
         ho = (hl + pt + pb - ks) // stride + 1
         wo = (wl + pl + pr_ - ks) // stride + 1
         act = cfg["act"]
-        mr = ss = None
+        mr = ss = a = None
+        pointwise = (ks == 1 and stride == 1 and not ups and pt == 0 and pl == 0 and _CONV1X1 and cin % 64 == 0 and cout % 128 == 0
+                     and x.dtype == torch.bfloat16 and cfg["out_dtype"] == torch.bfloat16)
+        mat = act != ACT_NONE and _MATERIALIZE and ((ks == 3 and not ups) or pointwise) and _gn_act_ok(cin, x.dtype)
         if act != ACT_NONE:
-            mr, ss = gn_stats(x, gn_w.detach().float(), gn_b.detach().float(), cfg["groups"], cfg["eps"], xpart, xrows)
+            if mat and xpart is None and gn_small_ok(x, cfg["groups"]):
+                # small map, no statistics from the producer: statistics + activation in one launch (three otherwise)
+                mr, ss, a = gn_stats_act(x, gn_w.detach().float(), gn_b.detach().float(), cfg["groups"], cfg["eps"], act)
+            else:
+                mr, ss = gn_stats(x, gn_w.detach().float(), gn_b.detach().float(), cfg["groups"], cfg["eps"], xpart, xrows)
         ctx.w_sources = getattr(weight, "_mas_sources", None)      # (the saved tensor comes back as another Python object)
         wp = ConvWeight(weight, False, ctx.w_sources)
         b32 = bias.detach().float() if bias is not None else None
         res = nhwc(residual, cd) if residual is not None else None
         # (needs_input_grad reflects requires_grad of the inputs even under torch.no_grad(); cfg["grad"] is the caller's grad mode)
         need_wgrad = cfg["grad"] and (ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]))
-        # 1x1: the GEMM kernel (conv1x1.hip) has no prologue; one small pass + GEMM beats conv_fwd.hip's fused KS = 1 instance with or
-        # without a weight gradient to share the tensor with (512 -> 1536 @16^2: 6 + 22 us against 52)
-        pointwise = (ks == 1 and stride == 1 and not ups and pt == 0 and pl == 0 and _CONV1X1 and cin % 64 == 0 and cout % 128 == 0
-                     and x.dtype == torch.bfloat16 and cfg["out_dtype"] == torch.bfloat16)
-        a = None
-        if act != ACT_NONE and _MATERIALIZE and ((ks == 3 and not ups) or pointwise) and _gn_act_ok(cin, x.dtype):
+        # (1x1: the GEMM kernel (conv1x1.hip) has no prologue; one small pass + GEMM beats conv_fwd.hip's fused KS = 1 instance with or
+        #  without a weight gradient to share the tensor with: 512 -> 1536 @16^2: 6 + 22 us against 52)
+        if mat:
             # the activation as a tensor: this convolution (and, with a weight gradient, that too) runs prologue-free on it.  Also
             # without a second consumer (torch.no_grad(), frozen weights): 0.20 + 0.50 ms beats the fused loader's 0.73 ms at
             # 128 ch @256^2 (0.20 + 0.60 against 0.93 with the residual epilogue), 6 + 51 us against 74 us at 512 ch @16^2
-            a = gn_act(x, ss, act)
+            if a is None:
+                a = gn_act(x, ss, act)
             y, ypart, yrows = conv_fwd_raw(a, None, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ACT_NONE, ups,
                                            cfg["out_dtype"], want_stats=True)
             if not need_wgrad:
@@ -699,22 +730,29 @@ class _ResBlock(torch.autograd.Function):
         x = nhwc(x, cd)
         n, c, h, w = x.shape
         f32 = lambda t: t.detach().float()
-        mr1, ss1 = gn_stats(x, f32(n1w), f32(n1b), groups, eps, xpart, xrows)
         ng = ctx.needs_input_grad
         mat = _MATERIALIZE and _gn_act_ok(c, x.dtype)
 
-        def conv(inp, ss_, wgt, bia, resid, need_w):
+        def norm(inp, gw, gb, part, rows):
+            """-> (mean_rstd, scale_shift, activated tensor or None): small maps without statistics from the producer take ONE launch"""
+            if mat and part is None and gn_small_ok(inp, groups):
+                return gn_stats_act(inp, f32(gw), f32(gb), groups, eps, ACT_AFFINE_SILU)
+            return gn_stats(inp, f32(gw), f32(gb), groups, eps, part, rows) + (None,)
+
+        def conv(inp, ss_, a_, wgt, bia, resid, need_w):
             """-> (output, statistics table, rows, activated input if the backward wants it)"""
             if mat:                                  # (with or without a weight gradient to share it with: see _NormActConv.forward)
-                a_ = gn_act(inp, ss_, ACT_AFFINE_SILU)
+                if a_ is None:
+                    a_ = gn_act(inp, ss_, ACT_AFFINE_SILU)
                 return conv_fwd_raw(a_, None, ConvWeight(wgt, False), f32(bia), resid, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_NONE, False, cd,
                                     want_stats=True) + (a_ if grad and need_w else None,)
             return conv_fwd_raw(inp, ss_, ConvWeight(wgt, False), f32(bia), resid, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU, False,
                                 cd, want_stats=True) + (None,)
 
-        hh, hpart, hrows, a1 = conv(x, ss1, c1w, c1b, None, ng[3] or ng[4])
-        mr2, ss2 = gn_stats(hh, f32(n2w), f32(n2b), groups, eps, hpart, hrows)
-        y, ypart, yrows, a2 = conv(hh, ss2, c2w, c2b, x, ng[7] or ng[8])
+        mr1, ss1, act1 = norm(x, n1w, n1b, xpart, xrows)
+        hh, hpart, hrows, a1 = conv(x, ss1, act1, c1w, c1b, None, ng[3] or ng[4])
+        mr2, ss2, act2 = norm(hh, n2w, n2b, hpart, hrows)
+        y, ypart, yrows, a2 = conv(hh, ss2, act2, c2w, c2b, x, ng[7] or ng[8])
         _stats_state["stash"] = (ypart, yrows) if ypart is not None else None
         ctx.groups, ctx.cd = groups, cd
         ctx.save_for_backward(x, hh, mr1, ss1, mr2, ss2, n1w, c1w, n2w, c2w, a1, a2)

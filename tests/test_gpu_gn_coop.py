@@ -126,3 +126,56 @@ def test_one_launch_backward_full_size_matches_three_pass():
         du = da.float() * (s * (1 + u * (1 - s)))
         assert _rel(db, du.sum(dim=(0, 2, 3))) < 1e-4
         del u, s, du
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# small maps (h*w <= 1024): statistics + finalize + activation in ONE launch, the backward in one launch + the batch sums
+# ---------------------------------------------------------------------------------------------------------------------------------
+SMALL = [(32, 512, 16, 16), (4, 512, 32, 32), (3, 256, 32, 32), (2, 128, 8, 8), (5, 64, 12, 20), (2, 256, 20, 20), (3, 128, 31, 33), (1, 64, 1, 1)]
+
+
+@pytest.mark.parametrize("act", [1, 2])
+@pytest.mark.parametrize("shape", SMALL)
+def test_small_map_forward_is_stats_plus_act(shape, act):
+    """``mas_gn_stats_act`` (one launch) against ``mas_gn_stats`` + ``mas_gn_act`` (three) and against torch's group_norm (+ SiLU) in
+    fp32 on the CPU.  The statistics differ by the summation order only; given its own scale / shift the activation is formed exactly
+    as ``mas_gn_act`` forms it (bitwise, checked by feeding the small kernel's scale / shift to mas_gn_act)."""
+    from mas_hip import ops
+    dev = _dev()
+    n, c, h, w = shape
+    x, _, _, gamma, beta = _case(n, c, h, w, act, False, seed=c + h * w)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    gd, bd = gamma.to(dev), beta.to(dev)
+    assert ops.gn_small_ok(xd, 32)
+    mr, ss, a = ops.gn_stats_act(xd, gd, bd, 32, 1e-6, act)
+    assert ops.last_kernel() == "gn_small_fwd"
+    mr3, ss3 = ops.gn_stats(xd, gd, bd, 32, 1e-6)
+    a3 = ops.gn_act(xd, ss, act)
+    torch.cuda.synchronize()
+    assert _rel(mr[..., 0], mr3[..., 0]) < 1e-5 and _rel(mr[..., 1], mr3[..., 1]) < 1e-4 and _rel(ss, ss3) < 1e-4
+    assert torch.equal(a, a3)
+    ref = F.group_norm(x.float(), 32, gamma, beta, eps=1e-6)
+    if act == 2:
+        ref = ref * torch.sigmoid(ref)
+    assert _rel(a, ref) < 1e-2
+
+
+@pytest.mark.parametrize("res", [False, True])
+@pytest.mark.parametrize("act", [1, 2])
+@pytest.mark.parametrize("shape", SMALL)
+def test_small_map_backward_vs_cpu_fp32_and_three_pass(shape, act, res):
+    """the default ``mas_gn_bwd`` takes gn_small_bwd_kernel for these tensors (asserted): against torch's fp32 autograd on the CPU and
+    against the three-launch path; bitwise run to run (no atomics: the batch sums are a second, fixed-order launch)."""
+    from mas_hip import ops
+    dev = _dev()
+    n, c, h, w = shape
+    x, da, dres, gamma, beta = _case(n, c, h, w, act, res, seed=7 * c + h + w)
+    dx_ref, dg_ref, db_ref = _reference(x, da, dres, gamma, beta, act)
+    dx, dg, db = _run(dev, x, da, dres, gamma, beta, act, path=None)
+    assert ops.last_kernel() == "gn_param_reduce"
+    dx2, dg2, db2 = _run(dev, x, da, dres, gamma, beta, act, path=None)
+    dx3, dg3, db3 = _run(dev, x, da, dres, gamma, beta, act, path="three")
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+    assert _rel(dx, dx_ref) < 1.2e-2 and _rel(dg, dg_ref) < 2e-3 and _rel(db, db_ref) < 2e-3
+    assert _rel(dg, dg3) < 1e-4 and _rel(db, db3) < 1e-4 and _rel(dx, dx3) < 8e-3

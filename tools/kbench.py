@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--act", type=int, default=0)
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--three", type=int, default=-1, help="gn_bwd: 1 = the three-launch path, 0 = the one-launch kernel, -1 = both")
+    ap.add_argument("--three", type=int, default=-1, help="gn_bwd: 1 = the three-launch path, 0 = the one-launch queue kernel, 2 = the library default, -1 = all")
     ap.add_argument("--dtype", default="bf16")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -77,11 +77,22 @@ def main():
         mr, ss = ops.gn_stats(x, g, bta, 32, 1e-6)
         da = torch.randn_like(x)
         dres = torch.randn_like(x) if a.res else None
-        for three in ((False, True) if a.three < 0 else (bool(a.three),)):
-            ms = timeit(lambda: ops.gn_bwd(x, da, dres, 32, a.act or 2, g, mr, ss, path="three" if three else "one"), a.iters)
-            alg = (3 + (1 if a.res else 0)) * x.numel() * esz     # x, da (, dres) read once, dx written once
-            print(f"gn_bwd[{'three launches' if three else 'one launch'}] n={n} c={c} hw={h} res={a.res}: {ms:.4f} ms  "
+        alg = (3 + (1 if a.res else 0)) * x.numel() * esz         # x, da (, dres) read once, dx written once
+        for path in ((None, "three", "one") if a.three < 0 else (("three",) if a.three == 1 else (("one",) if a.three == 0 else (None,)))):
+            ms = timeit(lambda: ops.gn_bwd(x, da, dres, 32, a.act or 2, g, mr, ss, path=path), a.iters)
+            name = {None: "default: " + ops.last_kernel(), "three": "three launches", "one": "one launch (queue)"}[path]
+            print(f"gn_bwd[{name}] n={n} c={c} hw={h} res={a.res}: {ms:.4f} ms  "
                   f"{alg/ms/1e6:.1f} GB/s algorithmic (x + da{' + dres' if a.res else ''} + dx once)")
+    elif a.kind == "gn_fwd":
+        g, bta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+        def three():
+            mr, ss = ops.gn_stats(x, g, bta, 32, 1e-6)
+            return ops.gn_act(x, ss, a.act or 2)
+        ms3 = timeit(three, a.iters)
+        print(f"gn_fwd[stats + finalize + act: three launches] n={n} c={c} hw={h}: {ms3:.4f} ms")
+        if ops.gn_small_ok(x, 32):
+            ms1 = timeit(lambda: ops.gn_stats_act(x, g, bta, 32, 1e-6, a.act or 2), a.iters)
+            print(f"gn_fwd[{ops.last_kernel()}: one launch] n={n} c={c} hw={h}: {ms1:.4f} ms")
     elif a.kind == "gn_act":
         g, bta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
         mr, ss = ops.gn_stats(x, g, bta, 32, 1e-6)
