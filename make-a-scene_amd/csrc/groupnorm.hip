@@ -576,8 +576,8 @@ __global__ __launch_bounds__(NT) void gn_act_kernel(const T* __restrict__ x, T* 
 // element-wise phase.  The groups of a block lie inside it (64 % (C / G) == 0), so nothing is exchanged between work-groups:
 //   forward : statistics + finalize + activation as ONE launch instead of three (gn_stats_partial 16 us + gn_stats_finalize 6.5 us +
 //             gn_act 6 us at 512 ch @16^2 x 32: three dependent launches whose latency is their cost), x read once;
-//   backward: partial sums + coefficients + apply as ONE launch instead of three, x / da read once; the sums over the batch for
-//             dgamma / dbeta follow as a second, tiny launch (fixed order: bitwise reproducible, no atomics).
+//   backward: (h*w <= 512) partial sums + coefficients + apply as ONE launch instead of three, x / da read once; the sums over the batch
+//             for dgamma / dbeta follow as a second, tiny launch (fixed order: bitwise reproducible, no atomics).
 // A pixel's 64 channels of the block are 128 contiguous bytes = 8 units of 16 bytes: thread t owns unit t % 8 of pixels t / 8,
 // t / 8 + T / 8, ... (a wave reads 8 whole 128-byte lines per load instruction).
 constexpr int GS_MAXU = 16;                         // 16-byte units a thread holds per tensor: 1024 pixels x 8 units / 512 threads
@@ -590,8 +590,8 @@ struct GnSmallParams {
     float eps;
 };
 
-// CB = channels of the block (64: a pixel's block is one 128-byte line = 8 units; 32: 4 units -- the backward at 32x32, whose two
-// tensors would not fit the registers at 64): thread t owns unit t % (CB / 8) of pixels t / (CB / 8), + TP, + 2 TP, ...
+// CB = channels of the block (64: a pixel's block is one 128-byte line = 8 units): thread t owns unit t % (CB / 8) of pixels
+// t / (CB / 8), + TP, + 2 TP, ...
 template <int UNITS, int CB>
 __device__ __forceinline__ void gs_load(u32x4 (&v)[UNITS], const bf16_t* base, int C, int HW, int pl, int cu, int TP) {
 #pragma unroll
@@ -779,12 +779,13 @@ __global__ __launch_bounds__(NT) void gn_param_reduce_kernel(const float* __rest
 // the small-map kernels take bf16 tensors of at most 1024 pixels whose channel count is a multiple of 64 with whole groups per block
 inline bool gn_small_ok(int dtype, int HW, int C, int G) {
     static const int on = mas_env_int("MAS_GN_SMALL", 1);
-    return on && dtype == MAS_BF16 && HW >= 1 && HW <= 1024 && C % 64 == 0 && C % G == 0 && 64 % (C / G) == 0 && 32 % (C / G) == 0;
+    return on && dtype == MAS_BF16 && HW >= 1 && HW <= 1024 && C % 64 == 0 && C % G == 0 && 64 % (C / G) == 0;
 }
-// forward: 64-channel blocks, <= 16 units per thread;  backward: <= 8 units of each of x / da per thread -- 64-channel blocks up to 512
-// pixels, 32-channel blocks above
+// forward: 64-channel blocks, <= 16 units per thread (h*w <= 1024).  backward: x AND da in registers, <= 8 units of each per thread:
+// h*w <= 512.  (The backward at 32x32 on 32-channel blocks measured 0.050 ms against the three launches' 0.047 at 512 channels, 0.029
+// against 0.032 at 256: not worth a second geometry -- 32x32 keeps the three launches; profiles/r04_gn_small.txt.)
 inline int gn_small_threads(int HW) { return HW <= 256 ? 256 : 512; }
-inline int gn_small_bwd_cb(int HW) { return HW <= 512 ? 64 : 32; }
+inline bool gn_small_bwd_ok(int dtype, int HW, int C, int G) { return HW <= 512 && gn_small_ok(dtype, HW, C, G); }
 inline int gn_small_units(int HW, int cb) { const int t = gn_small_threads(HW); return (HW * (cb / 8) + t - 1) / t; }
 inline size_t gn_small_lds(int HW, int cb) { return ((size_t)gn_small_threads(HW) / (cb / 8) * 2 * cb + 2 * cb + 4 * cb) * sizeof(float); }
 
@@ -1320,18 +1321,17 @@ extern "C" int mas_gn_bwd(const void* x, const void* da, const void* dres, int d
                           const float* gamma, const float* mean_rstd, const float* scale_shift, void* dx, float* dgamma,
                           float* dbeta, void* workspace, size_t ws_bytes, void* stream) {
     if (x && da && dx && mean_rstd && scale_shift && workspace && N > 0 && G > 0 && C > 0 && C % G == 0 && (act == MAS_ACT_AFFINE || act == MAS_ACT_AFFINE_SILU) &&
-        gn_small_ok(dtype, HW, C, G) && ws_bytes >= mas_gn_bwd_workspace(N, C)) {
+        gn_small_bwd_ok(dtype, HW, C, G) && ws_bytes >= mas_gn_bwd_workspace(N, C)) {
         // small maps: the (image, 64-channel block) slab lives in registers between the sums and the element-wise phase (gn_small_bwd_kernel)
         MAS_ENTER();
         GnSmallParams p{};
         p.x = (const bf16_t*)x; p.da = (const bf16_t*)da; p.dres = (const bf16_t*)dres; p.out = (bf16_t*)dx; p.gamma = gamma;
         p.mean_rstd = const_cast<float*>(mean_rstd); p.ss = const_cast<float*>(scale_shift); p.nsum = reinterpret_cast<float*>(workspace);
         p.N = N; p.HW = HW; p.C = C; p.G = G; p.act = act;
-        const int T = gn_small_threads(HW), cb = gn_small_bwd_cb(HW), u = gn_small_units(HW, cb);
-        const size_t lds = gn_small_lds(HW, cb);
+        const int T = gn_small_threads(HW), u = gn_small_units(HW, 64);
+        const size_t lds = gn_small_lds(HW, 64);
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-        if (cb == 32) gn_small_bwd_launch<8, 32>(p, T, lds, s);
-        else if (u <= 1) gn_small_bwd_launch<1, 64>(p, T, lds, s);
+        if (u <= 1) gn_small_bwd_launch<1, 64>(p, T, lds, s);
         else if (u <= 2) gn_small_bwd_launch<2, 64>(p, T, lds, s);
         else if (u <= 4) gn_small_bwd_launch<4, 64>(p, T, lds, s);
         else gn_small_bwd_launch<8, 64>(p, T, lds, s);
