@@ -32,6 +32,10 @@ def relmax(got, ref):
     (1, 128, 5, 7),       # 35 tokens: ragged second 32-token block
     (2, 32, 4, 4),        # fewer tokens than one block, one channel tile
     (1, 64, 16, 16),
+    (32, 512, 16, 16),    # the benched launch: 256 work-groups, XCD-aware block order, every rotation of the tile walk
+    (1, 96, 6, 6),        # 12 units per row (the unit -> (row, column) walk carries), channels padded 96 -> 128 in LDS
+    (2, 160, 9, 9),       # two channel groups, the second one a quarter full; 81 tokens
+    (1, 384, 16, 16),     # three channel groups: one ring slot per tile loads a clamped line and skips its MFMAs
 ])
 def test_spatial_attention_fwd_bwd_vs_torch(case):
     from mas_hip import ops

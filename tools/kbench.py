@@ -110,6 +110,33 @@ def main():
             ops.causal_attention(qkv, h).backward(go)
         ms2 = timeit(fb, a.iters)
         print(f"attn fwd+bwd: {ms2:.4f} ms  {3.5*fl/ms2/1e9:.1f} TFLOP/s (fwd 1x + bwd 2.5x causal FLOPs)")
+    elif a.kind == "sp_attn":
+        cc = c if c != 128 else 512
+        hh = h if h != 256 else 16
+        qkv = torch.randn(n, 3 * cc, hh, hh, device=dev).to(dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        fl = 4.0 * n * (hh * hh) ** 2 * cc
+        ms = timeit(lambda: ops.spatial_attention(qkv.detach(), cc), a.iters)
+        print(f"sp_attn fwd n={n} S={hh*hh} C={cc}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s")
+        go = torch.randn(n, cc, hh, hh, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
+        def fb():
+            qkv.grad = None
+            ops.spatial_attention(qkv, cc).backward(go)
+        ms2 = timeit(fb, a.iters)
+        print(f"sp_attn fwd+bwd: {ms2*1e3:.1f} us  {3.5*fl/ms2/1e9:.1f} TFLOP/s (backward = 2.5x forward FLOPs)")
+        import ctypes
+        from mas_hip import lib
+        tr = getattr(lib(), "mas_sp_trace", None)           # only in a -DSP_TRACE variant build
+        if tr is not None:
+            ops.spatial_attention(qkv.detach(), cc); torch.cuda.synchronize()
+            buf = (ctypes.c_longlong * 32)()
+            tr.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
+            tr(buf)
+            t = list(buf)
+            names = ["stage Q + prod QK", "issue V", "softmax", "apply PV", "store"]
+            print("sp_attn forward phases (us, work-group 9): " + ", ".join(f"{nm} {(t[i+1]-t[i])/100:.2f}" for i, nm in enumerate(names)))
+            print("  apply tile ends (us after apply start): " + " ".join(f"{(t[6+i]-t[3])/100:.2f}" for i in range(8)))
+            print("  prod (us after kernel start): loads issued %.2f, block rows staged %.2f, steps done " % ((t[16]-t[0])/100, (t[17]-t[0])/100)
+                  + " ".join(f"{(t[18+i]-t[0])/100:.2f}" for i in range(8)))
     elif a.kind == "vq":
         z = torch.randn(n, 256, 16, 16, device=dev).contiguous(memory_format=torch.channels_last)
         cb = torch.randn(8192, 256, device=dev)
