@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/final; mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -3 > $O/pytest_gpu.txt
+timeout 1800 python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -3 > $O/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 600 python bench.py --workload transformer > $O/bench_transformer.json 2> $O/bench_transformer.err
@@ -27,6 +27,9 @@ KB="timeout 100 python tools/kbench.py"
     $KB conv_fwd --n 32 --c $1 --hw $2 --act 2 | tail -1; $KB wgrad --n 32 --c $1 --hw $2 --act 2 | tail -1
   done
   $KB conv_fwd --n 32 --c 128 --hw 256 --stride 2 | tail -1
+  $KB sp_attn --iters 50 | grep sp_attn
+  $KB gn_bwd --n 32 --c 128 --hw 256 --res 1 | grep "^gn_bwd"
+  $KB gn_fwd --c 512 --hw 16 | grep gn_fwd
   $KB attn --n 8 | tail -2
   $KB attn --n 32 | tail -2
   timeout 60 tools/probes/mfma_peak

@@ -49,14 +49,21 @@ def main():
         fn()
     torch.cuda.synchronize()
     from torch.profiler import profile, ProfilerActivity
-    with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
         fn()
         torch.cuda.synchronize()
     groups = collections.Counter()
     for ev in prof.events():
         if ev.name in want:
             st = [s for s in (ev.stack or []) if "site-packages/torch" not in s and "dist-packages/torch" not in s and "<built-in" not in s][:3]
-            groups[ev.name + "  " + (" <- ".join(s.replace(R + "/", "") for s in st) or "(no python frame)")] += 1
+            where = " <- ".join(s.replace(R + "/", "") for s in st)
+            if not where:                      # backward runs on autograd threads (no Python frame): name the enclosing autograd node instead
+                par, chain = ev.cpu_parent, []
+                while par is not None and len(chain) < 3:
+                    chain.append(par.name)
+                    par = par.cpu_parent
+                where = "(autograd thread) in " + " <- ".join(chain) if chain else "(no python frame, no parent)"
+            groups[f"{ev.name} {list(ev.input_shapes)[:2] if ev.input_shapes else ''}  {where}"] += 1
     print(f"{sum(groups.values())} calls of {sorted(want)} in one {a.mode} pass")
     for k, v in groups.most_common(30):
         print(f"{v:5d}  {k}")
