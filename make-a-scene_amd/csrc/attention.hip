@@ -1014,16 +1014,19 @@ __global__ __launch_bounds__(NT, FA_DKV_WGS) void attn_bwd_dkv_bf16_kernel(AttnB
                 d4[j] = *reinterpret_cast<const f32x4*>(del_s + sub * 32 + 8 * j + 4 * g);
             }
             const bool needs_mask = (qs < kw + 31) || (qs + 32 > p.S) || (kw + 32 > p.S);
+            // (the mask as ONE wave-uniform branch around 16 selects, not a branch per element: with the test inside the element loop the
+            //  compiler cut this block into 33 basic blocks per 32 MFMAs and nothing could be scheduled across them)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -l4[r >> 2][r & 3]));
-                if (needs_mask) {
+            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -l4[r >> 2][r & 3]));      // P[query][key]
+            if (needs_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
                     const int query = qs + acc_row(lane, r);
-                    if (!((key <= query) && (query < p.S) && (key < p.S))) pv = 0.0f;
+                    s[r] = ((key <= query) && (query < p.S) && (key < p.S)) ? s[r] : 0.0f;
                 }
-                s[r] = pv;                                           // P[query][key]
-                dp[r] = pv * (dp[r] - d4[r >> 2][r & 3]) * p.scale;  // dS[query][key]
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[r] = s[r] * (dp[r] - d4[r >> 2][r & 3]) * p.scale;                            // dS[query][key]
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 bf16x8 pf, sf;
@@ -1137,14 +1140,16 @@ __global__ __launch_bounds__(NT, 3) void attn_bwd_dq_bf16_kernel(AttnBwdParams p
             }
             const bool needs_mask = (ks + 31 > qw) || (ks + 32 > p.S);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -my_lse2));
-                if (needs_mask) {
+            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -my_lse2));
+            if (needs_mask) {                                        // (one wave-uniform branch around 16 selects: see attn_bwd_dkv)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
                     const int key = ks + acc_row(lane, r);
-                    if (!((key <= query) && (key < p.S))) pv = 0.0f;
+                    s[r] = ((key <= query) && (key < p.S)) ? s[r] : 0.0f;
                 }
-                dp[r] = pv * (dp[r] - my_delta) * p.scale;           // dS^T[key][query]
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[r] = s[r] * (dp[r] - my_delta) * p.scale;                                     // dS^T[key][query]
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 bf16x8 sf;
