@@ -35,13 +35,20 @@ struct StreamParams {
 };
 
 constexpr int S_PWL = 18;                      // patch pitch in pixels ((16-1)+3)
-constexpr int S_NPIX = 18 * 18;
-constexpr int S_PATCH = 41 * 1024;             // 324 pixels x 128 B = 41472, rounded up to whole 1-KiB DMA pieces
-constexpr int S_NPIECE = 41;
+// Patch geometry by tile height TH (16 rows: 324 pixels x 128 B = 41 DMA pieces of 1 KiB, 6 per wave; 8 rows: 180 pixels = 23 pieces,
+// 3 per wave).  (A traits struct, not constexpr locals in the kernel: locals that appear in the parameter types of the kernel's
+// lambdas make hipcc drop the kernel's host-side handle without a diagnostic -- the launch then fails to link at load time.)
+template <int TH> struct SGeo {
+    static constexpr int NPIX = (TH + 2) * S_PWL;
+    static constexpr int NPIECE = (NPIX * 128 + 1023) / 1024;      // 41 | 23
+    static constexpr int PATCH = NPIECE * 1024;
+    static constexpr int NSLOT = (NPIECE + 7) / 8;                 // 6 | 3 DMA pieces per wave per chunk
+    static constexpr int NJ = TH / 8;                              // 32-pixel fragments per wave: 2 | 1
+    static constexpr int PCNT = NSLOT / 3;                         // patch pieces a wave issues per stage (plain path): 2 | 1
+    static constexpr int NST = 4 * NJ;                             // deferred stores per lane per tile: 8 | 4, one per stage
+};
 constexpr int S_WT = 128 * 128;                // one tap-step weight tile: 128 couts x 128 B
 constexpr int S_WSTAGE = 2 * S_WT;
-constexpr int S_LDS = 2 * S_PATCH + 2 * S_WSTAGE;
-constexpr int S_NSLOT = 6;                     // 16-byte patch slots (DMA pieces) per thread (wave) per chunk
 constexpr int S_OOB = (int)0x80000000;         // voffset beyond any descriptor's num_records
 
 #ifndef S_ABL_NOBARRIER
@@ -77,11 +84,17 @@ __device__ __forceinline__ bf16x8 s_ld_frag(const unsigned char* row, int xs, in
 }
 
 // ACT: GroupNorm(+SiLU) prologue -> register-staged patch; otherwise LDS-DMA patch.  DEFER: deferred-store epilogue.
-template <bool ACT, bool DEFER>
+// TH: tile height, 16 (default) or 8.  Round 4: the 16x16-pixel level of VQ-IMG (512 -> 512 at batch 32) has 128 tiles of 16x16 pixels
+// x 128 couts -- half the chip idle (VERDICT r3 #4i: 0.70 PF).  With TH = 8 a wave owns 64 couts x 32 pixels (one pixel fragment
+// instead of two), the patch is 10 x 18 pixels (23 DMA pieces, 3 per wave, one per stage), the tile has 4 deferred stores per lane
+// instead of 8 -- same stage program, same counted waits with the smaller per-stage allowances, twice the tiles.  Prologue-free only.
+template <bool ACT, bool DEFER, int TH>
 __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) {
+    static_assert(TH == 16 || (TH == 8 && !ACT), "the 8-row tile exists for the prologue-free path only");
+    using G = SGeo<TH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const patch = smem;                    // [2][S_PATCH]
-    unsigned char* const wbuf = smem + 2 * S_PATCH;       // [2][S_WSTAGE]
+    unsigned char* const patch = smem;                    // [2][G::PATCH]
+    unsigned char* const wbuf = smem + 2 * G::PATCH;       // [2][S_WSTAGE]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
         const int ct = t % p.n_ct; t /= p.n_ct;
         const int tw_i = t % p.tiles_w; t /= p.tiles_w;
         const int th_i = t % p.tiles_h; tc.n = t / p.tiles_h;
-        tc.c0 = ct * 128; tc.h0 = th_i * 16; tc.w0 = tw_i * 16;
+        tc.c0 = ct * 128; tc.h0 = th_i * TH; tc.w0 = tw_i * 16;
         return tc;
     };
 
@@ -113,16 +126,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
     // ds_write address, so one thread needs one set of 8 scale/shift pairs).
     const int lrow = lane >> 3;
     auto slot_pix = [&](int i, int& pr, int& pc) -> bool {   // patch pixel of slot i (recomputed where needed: no register arrays)
-        const int piece = (wave + 8 * i < S_NPIECE) ? wave + 8 * i : wave + 32;
+        const int piece = (wave + 8 * i < G::NPIECE) ? wave + 8 * i : wave + 8 * (i - 1);
         const int q = piece * 8 + lrow;
         pr = (q * 3641) >> 16;                  // q / 18 for q < 3641
         pc = q - pr * S_PWL;
-        return q < S_NPIX;                       // false: dead pixels of the last piece -- always out of range
+        return q < G::NPIX;                       // false: dead pixels of the last piece -- always out of range
     };
-    auto make_plan = [&](const Tile& tc, int (&vo)[S_NSLOT], unsigned& inb_mask) {
+    auto make_plan = [&](const Tile& tc, int* vo, unsigned& inb_mask) {
         inb_mask = 0;
 #pragma unroll
-        for (int i = 0; i < S_NSLOT; ++i) {
+        for (int i = 0; i < G::NSLOT; ++i) {
             int pr, pc;
             const bool live = slot_pix(i, pr, pc);
             int ih = tc.h0 + pr - p.pad_top, iw = tc.w0 + pc - p.pad_left;
@@ -158,15 +171,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
 
     // ---- patch operations ---------------------------------------------------------------------------------------
     float sc[8], sh[8];
-    auto p_dma = [&](__amdgpu_buffer_rsrc_t rs, const int (&vo)[S_NSLOT], int soff, int buf, int i0, int cnt) {
+    auto p_dma = [&](__amdgpu_buffer_rsrc_t rs, const int* vo, int soff, int buf, int i0, int cnt) {
 #pragma unroll
-        for (int k = 0; k < S_NSLOT; ++k) {
+        for (int k = 0; k < G::NSLOT; ++k) {
             if (k < i0 || k >= i0 + cnt) continue;
-            const int piece = (wave + 8 * k < S_NPIECE) ? wave + 8 * k : wave + 32;
+            const int piece = (wave + 8 * k < G::NPIECE) ? wave + 8 * k : wave + 8 * (k - 1);
 #ifdef S_ABL_NOPATCH
             if (p.N != -12345) continue;
 #endif
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(patch + buf * S_PATCH + piece * 1024),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(patch + buf * G::PATCH + piece * 1024),
                                                      16, vo[k], soff, 0, 0);
         }
     };
@@ -183,12 +196,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
     // written as zeros by the DMA and must stay zero (the padding is applied AFTER the activation).
     auto p_activate = [&](unsigned inb_mask, int buf, int i0, int cnt) {
 #pragma unroll
-        for (int k = 0; k < S_NSLOT; ++k) {
+        for (int k = 0; k < G::NSLOT; ++k) {
             if (k < i0 || k >= i0 + cnt) continue;
             int pr, pc;
             const bool live = slot_pix(k, pr, pc) && (k < 5 || wave == 0) && ((inb_mask >> k) & 1u);
             if (!live) continue;
-            unsigned char* dst = patch + buf * S_PATCH + (pr * S_PWL + pc) * 128 + (((lane & 7) ^ ((pc >> 1) & 7)) << 4);
+            unsigned char* dst = patch + buf * G::PATCH + (pr * S_PWL + pc) * 128 + (((lane & 7) ^ ((pc >> 1) & 7)) << 4);
             u32x4 v = *reinterpret_cast<const u32x4*>(dst);
             bf16_t* tv = reinterpret_cast<bf16_t*>(&v);
             if (p.act == MAS_ACT_AFFINE_SILU) {
@@ -203,10 +216,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
     };
 
     // ---- per-lane fragment addressing -----------------------------------------------------------------------------
-    int bq[2];                                  // byte offset (inside a patch buffer) of this lane's pixel at tap (0,0)
+    int bq[G::NJ];                                 // byte offset (inside a patch buffer) of this lane's pixel at tap (0,0)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pix = (wave_p * 2 + j) * 32 + l31;
+    for (int j = 0; j < G::NJ; ++j) {
+        const int pix = (wave_p * G::NJ + j) * 32 + l31;
         bq[j] = ((pix >> 4) * S_PWL + (pix & 15)) * 128;
     }
     const int bcol = l31 & 15;
@@ -222,12 +235,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
     }
 
     // ---- deferred output of the previous tile ----------------------------------------------------------------------
-    u32x4 outp[8];
-    int ooff[2] = {S_OOB, S_OOB};
+    u32x4 outp[G::NST];
+    int ooff[G::NJ];
+#pragma unroll
+    for (int j = 0; j < G::NJ; ++j) ooff[j] = S_OOB;
     bool pending_out = false;
     bool imm_stores = false;                    // the previous tile's epilogue issued its 8 stores directly (they may stay in flight)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) outp[k] = u32x4{0u, 0u, 0u, 0u};
+    for (int k = 0; k < G::NST; ++k) outp[k] = u32x4{0u, 0u, 0u, 0u};
     auto store_one = [&](int k) {               // k = (j*2 + i)*2 + qp
         const int j = k >> 2, i = (k >> 1) & 1, qp = k & 1;
         const int off = ooff[j] + (i * 32 + qp * 16) * 2;
@@ -240,18 +255,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
     // ---- prologue -----------------------------------------------------------------------------------------------------
     int tile = blockIdx.x;                      // grid <= total_tiles
     Tile cur = decode(tile);
-    int vo_cur[S_NSLOT], vo_nxt[S_NSLOT];
+    int vo_cur[G::NSLOT], vo_nxt[G::NSLOT];
     unsigned inb_cur, inb_nxt;
     make_plan(cur, vo_cur, inb_cur);
 #pragma unroll
-    for (int i = 0; i < S_NSLOT; ++i) vo_nxt[i] = vo_cur[i];
+    for (int i = 0; i < G::NSLOT; ++i) vo_nxt[i] = vo_cur[i];
     inb_nxt = inb_cur;
     __amdgpu_buffer_rsrc_t rs_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.x) + (size_t)cur.n * img_bytes, 0,
                                                                       (unsigned)img_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_nxt = rs_cur;
     int wsel = 0;
     w_issue(0, cur.c0, 0);
-    p_dma(rs_cur, vo_cur, 0, 0, 0, S_NSLOT);
+    p_dma(rs_cur, vo_cur, 0, 0, 0, G::NSLOT);
     if constexpr (ACT) {
         ss_load(cur.n, 0);
         S_WAIT_BARRIER(0);                       // the raw patch of chunk 0 has landed for every wave
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
     S_WAIT_BARRIER(0);
     if (blockIdx.x == 0) {
         for (int i = tid; i < S_WSTAGE / 16; i += 512) reinterpret_cast<u32x4*>(p.y)[i] = *reinterpret_cast<const u32x4*>(wbuf + i * 16);
-        for (int i = tid; i < S_PATCH / 16; i += 512) reinterpret_cast<u32x4*>(p.y + S_WSTAGE)[i] = *reinterpret_cast<const u32x4*>(patch + i * 16);
+        for (int i = tid; i < G::PATCH / 16; i += 512) reinterpret_cast<u32x4*>(p.y + S_WSTAGE)[i] = *reinterpret_cast<const u32x4*>(patch + i * 16);
     }
     return;
 #endif
@@ -280,11 +295,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
         const Tile nxt = has_next ? decode(next_tile) : cur;
         STS(0);
 
-        f32x16 acc[2][2];
+        f32x16 acc[2][G::NJ];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < G::NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -305,9 +320,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
                 {
                     constexpr int sp = (s + 8) % 9;           // previous stage (of this or the previous pair)
                     constexpr int npatch = ACT ? ((sp == 0 || sp == 5) ? 7 : ((sp == 1 || sp == 6) ? 3 : 0))
-                                               : ((sp <= 2 || (sp >= 5 && sp <= 7)) ? 2 : 0);
-                    if (s > 0 && do_store) s_wait_barrier(npatch + 1);     // s-1 in 0..7 also issued one deferred store
-                    else if (s == 0 && imm_stores) { s_wait_barrier(8); imm_stores = false; }   // younger than stage 0's weight DMA
+                                               : ((sp <= 2 || (sp >= 5 && sp <= 7)) ? G::PCNT : 0);
+                    if (s > 0 && sp < G::NST && do_store) s_wait_barrier(npatch + 1);     // stage s-1 also issued one deferred store
+                    else if (s == 0 && imm_stores) { s_wait_barrier(G::NST); imm_stores = false; }   // younger than stage 0's weight DMA
                     else s_wait_barrier(npatch);
                 }
                 if (pair == 0) STS(2 + 3 * s);
@@ -315,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
                 if (s == S_DEBUG_DUMP_STAGE && blockIdx.x == 0 && tile == 0 && pair == 0) {
                     unsigned char* dd = const_cast<unsigned char*>(p.res);
                     for (int i = tid; i < S_WSTAGE / 16; i += 512) reinterpret_cast<u32x4*>(dd)[i] = *reinterpret_cast<const u32x4*>(wbuf + wsel * S_WSTAGE + i * 16);
-                    for (int i = tid; i < 2 * S_PATCH / 16; i += 512) reinterpret_cast<u32x4*>(dd + S_WSTAGE)[i] = *reinterpret_cast<const u32x4*>(patch + i * 16);
+                    for (int i = tid; i < 2 * G::PATCH / 16; i += 512) reinterpret_cast<u32x4*>(dd + S_WSTAGE)[i] = *reinterpret_cast<const u32x4*>(patch + i * 16);
                 }
 #endif
                 // ---- register path: commit what was loaded two stages ago (guaranteed landed by the wait above)
@@ -342,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
                         if (s == 0) { p_dma(rs_cur, vo_cur, (ciA + 64) * 2, 1, 0, 3); ss_load(cur.n, ciA + 64); }
                         if (s == 1) p_dma(rs_cur, vo_cur, (ciA + 64) * 2, 1, 3, 3);
                     } else {
-                        p_dma(rs_cur, vo_cur, (ciA + 64) * 2, 1, 2 * s, 2);
+                        p_dma(rs_cur, vo_cur, (ciA + 64) * 2, 1, G::PCNT * s, G::PCNT);
                     }
                 } else if (s >= 5 && s <= 7) {                // chunk A of the next pair, or chunk 0 of the next tile -> buffer 0
                     const int soff = last_pair ? 0 : (ciA + 128) * 2;
@@ -353,12 +368,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
                         }
                         if (s == 6) { if (last_pair) p_dma(rs_nxt, vo_nxt, soff, 0, 3, 3); else p_dma(rs_cur, vo_cur, soff, 0, 3, 3); }
                     } else {
-                        if (last_pair) p_dma(rs_nxt, vo_nxt, soff, 0, 2 * (s - 5), 2); else p_dma(rs_cur, vo_cur, soff, 0, 2 * (s - 5), 2);
+                        if (last_pair) p_dma(rs_nxt, vo_nxt, soff, 0, G::PCNT * (s - 5), G::PCNT); else p_dma(rs_cur, vo_cur, soff, 0, G::PCNT * (s - 5), G::PCNT);
                     }
                 }
                 // ---- one deferred store of the previous tile's output
                 if constexpr (DEFER) {
-                    if (s < 8 && do_store) store_one(s);
+                    if (s < G::NST && do_store) store_one(s);
                 }
                 asm volatile("" ::: "memory");
                 };
@@ -369,14 +384,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
                 // ---- 2 tap-steps = 8 k-steps of 4 MFMAs; fragment reads software-pipelined one k-step ahead
                 {
                     const unsigned char* wb = wbuf + wsel * S_WSTAGE;
-                    bf16x8 bfr[2][2], afr[2][2];
+                    bf16x8 bfr[2][G::NJ], afr[2][2];
                     auto ld_k = [&](int n, int b) {           // n = 0..7: step n >> 2, kk = n & 3
                         const int t = 2 * s + (n >> 2);       // step inside the pair
                         const int cb = t / 9, tap = t - cb * 9;
                         const int kh = tap / 3, kw = tap - kh * 3, kk = n & 3;
-                        const unsigned char* pb = patch + cb * S_PATCH + (kh * S_PWL + kw) * 128;
+                        const unsigned char* pb = patch + cb * G::PATCH + (kh * S_PWL + kw) * 128;
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) bfr[b][j] = s_ld_frag(pb + bq[j], bxs[kw], kk);
+                        for (int j = 0; j < G::NJ; ++j) bfr[b][j] = s_ld_frag(pb + bq[j], bxs[kw], kk);
 #pragma unroll
                         for (int i = 0; i < 2; ++i) afr[b][i] = s_ld_frag(wb + (n >> 2) * S_WT + aoff[i], axs[i], kk);
                     };
@@ -387,15 +402,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) mma16(acc[i][j], afr[n & 1][i], bfr[n & 1][j]);
+                            for (int j = 0; j < G::NJ; ++j) mma16(acc[i][j], afr[n & 1][i], bfr[n & 1][j]);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);          // DS reads of k-step 0
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 + G::NJ, 0);     // DS reads of k-step 0
 #pragma unroll
                     for (int n = 0; n + 1 < 8; ++n) {
-                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2 + G::NJ, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2 * G::NJ, 0);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * G::NJ, 0);
                 }
 #ifdef S_LATE_ISSUE   // HBM-facing operations of this stage issued at its END, where the early half of the waves would wait at the barrier anyway
                 asm volatile("" ::: "memory");
@@ -409,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
 #ifdef S_ABL_NOEPIALL   // timing experiment only: no epilogue at all (the accumulators are consumed by an impossible store)
         if (p.N != -12345) {
             float t = 0.0f;
-            for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+            for (int i = 0; i < 2; ++i) for (int j = 0; j < G::NJ; ++j) for (int r = 0; r < 16; ++r) t += acc[i][j][r];
             if (t == 123.456f) reinterpret_cast<float*>(p.y)[0] = t;
         } else
 #endif
@@ -427,8 +442,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
                     bv[i][qp][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, cb + 16, 0, 0));
                 }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int pix = (wave_p * 2 + j) * 32 + l31;
+            for (int j = 0; j < G::NJ; ++j) {
+                const int pix = (wave_p * G::NJ + j) * 32 + l31;
                 const int ho = cur.h0 + (pix >> 4), wo = cur.w0 + (pix & 15);
                 const bool pix_ok = (ho < p.Ho) && (wo < p.Wo);
                 // byte offset of (n, ho, wo, c0 + wave_c*64 + 8*g) -- the stores add (i*32 + qp*16)*2
@@ -472,19 +487,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
         if (!has_next) break;
         tile = next_tile; cur = nxt; rs_cur = rs_nxt; inb_cur = inb_nxt;
 #pragma unroll
-        for (int i = 0; i < S_NSLOT; ++i) vo_cur[i] = vo_nxt[i];
+        for (int i = 0; i < G::NSLOT; ++i) vo_cur[i] = vo_nxt[i];
     }
     if constexpr (DEFER) {
         if (pending_out) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) store_one(k);
+            for (int k = 0; k < G::NST; ++k) store_one(k);
         }
     }
 }
 
-template <bool ACT, bool DEFER>
+template <bool ACT, bool DEFER, int TH>
 int launch_stream(const StreamParams& p, hipStream_t s) {
-    auto kern = conv3x3_stream_kernel<ACT, DEFER>;
+    auto kern = conv3x3_stream_kernel<ACT, DEFER, TH>;
+    constexpr int S_LDS = 2 * SGeo<TH>::PATCH + 2 * S_WSTAGE;
     static mas_devmask_t attr_mask{0};
     unsigned long long attr_bit;
     if (mas_attr_needed(attr_mask, &attr_bit)) {
@@ -527,7 +543,11 @@ int mas_conv3x3_stream_try(const MasConvDesc* d, const void* x, const float* sca
     p.pad_top = d->pad_top; p.pad_left = d->pad_left; p.upsample = d->upsample; p.act = d->act;
     p.n_chunks = d->Cin / 64; p.Cout_pad = mas_roundup(d->Cout, 128);
     p.tiles_h = mas_cdiv(d->Ho, 16); p.tiles_w = mas_cdiv(d->Wo, 16); p.n_ct = d->Cout / 128;
-    const long long tiles = (long long)p.N * p.tiles_h * p.tiles_w * p.n_ct;
+    long long tiles = (long long)p.N * p.tiles_h * p.tiles_w * p.n_ct;
+    // fewer 16-row tiles than CUs (the 16x16 level at batch 32: 128): 8-row tiles, twice as many (prologue-free launches only)
+    static const int th8 = mas_env_int("MAS_CONV_STREAM_TH8", 1);
+    const bool half = th8 && d->act == MAS_ACT_NONE && tiles < mas_num_cus();
+    if (half) { p.tiles_h = mas_cdiv(d->Ho, 8); tiles = (long long)p.N * p.tiles_h * p.tiles_w * p.n_ct; }
     // Small maps (fewer tiles than CUs): round 2 sent them to the 8x16-tile general kernel, which fills the chip; since the 16x16 level's
     // layers are (Cin, Cout) = (512, 512) -- 72 tap-steps per tile -- one stream tile on half the CUs is as fast per launch (52 vs 51 us)
     // and the step is 0.3 ms faster with it (profiles/r03_ab_stream_small.txt).  MAS_CONV_STREAM_MIN_TILES_PER_CU=2 restores the old rule.
@@ -535,7 +555,8 @@ int mas_conv3x3_stream_try(const MasConvDesc* d, const void* x, const float* sca
     if (tiles < (long long)min_per_cu * mas_num_cus() || tiles > 0x7fffffffLL) return 0;
     const bool defer = (mode & 2) != 0;
     int rc;
-    if (d->act != MAS_ACT_NONE) rc = defer ? launch_stream<true, true>(p, s) : launch_stream<true, false>(p, s);
-    else rc = defer ? launch_stream<false, true>(p, s) : launch_stream<false, false>(p, s);
+    if (d->act != MAS_ACT_NONE) rc = defer ? launch_stream<true, true, 16>(p, s) : launch_stream<true, false, 16>(p, s);
+    else if (half) rc = defer ? launch_stream<false, true, 8>(p, s) : launch_stream<false, false, 8>(p, s);
+    else rc = defer ? launch_stream<false, true, 16>(p, s) : launch_stream<false, false, 16>(p, s);
     return rc == MAS_OK ? 1 : rc;
 }
