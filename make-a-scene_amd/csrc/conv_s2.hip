@@ -534,7 +534,9 @@ int mas_conv_s2_fwd_try(const MasConvDesc* d, const void* x, const void* w_packe
     if (!on || residual) return 0;
     if (d->ks != 3 || d->stride != 2 || d->upsample || d->act != MAS_ACT_NONE || d->pad_top != 0 || d->pad_left != 0) return 0;
     if (d->in_dtype != MAS_BF16 || d->out_dtype != MAS_BF16 || d->w_layout != MAS_WLAYOUT_K64) return 0;
-    if (d->Cin % 32 || d->Cout % 128 || d->Wo < 32) return 0;                   // (narrower maps would idle half of every tile)
+    // (16 <= Wo < 32 idles half of every 8 x 32 tile and still beats conv_fwd.hip's stride-2 instance 4x: the 32 -> 16 Downsample of
+    //  VQ-IMG, 256 -> 256 at batch 32, took 103 us there -- round 4)
+    if (d->Cin % 32 || d->Cout % 128 || d->Wo < 16) return 0;
     if ((long long)d->N * d->H * d->W * d->Cin * 2 >= 0x7fffffffLL || (long long)d->N * d->Ho * d->Wo * d->Cout * 2 >= 0x7fffffffLL) return 0;
     S2FwdParams p;
     p.x = (const unsigned char*)x; p.w = (const unsigned char*)w_packed; p.bias = bias; p.y = (unsigned char*)y;
@@ -559,7 +561,8 @@ static bool s2_dgrad_ok(const MasConvDesc* d) {
     if (!on || !d) return false;
     if (d->ks != 3 || d->stride != 2 || d->upsample || d->act != MAS_ACT_NONE || d->pad_top != 0 || d->pad_left != 0) return false;
     if (d->in_dtype != MAS_BF16 || d->out_dtype != MAS_BF16) return false;
-    if (d->Cout % 32 || d->Cin % 128 || d->W < 64) return false;                 // (a, b) blocks of 8 x 32: narrower maps idle half of every tile
+    if (d->Cout % 32 || d->Cin % 128 || d->W < 32) return false;                 // (a, b) blocks of 8 x 32: W < 64 idles half of every tile (still faster
+                                                                                 //  than the zero-stuffed stride-1 path); narrower maps stay there
     if ((long long)d->N * d->H * d->W * d->Cin * 2 >= 0x7fffffffLL || (long long)d->N * d->Ho * d->Wo * d->Cout * 2 >= 0x7fffffffLL) return false;
     return true;
 }

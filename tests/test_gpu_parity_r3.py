@@ -528,7 +528,8 @@ def test_stride2_wgrad_kernel_vs_cpu_fp32(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 128, 128, 20, 80), (3, 64, 256, 33, 65), (2, 96, 128, 70, 66), (32, 128, 128, 64, 64), (1, 256, 256, 64, 64),
-                                   (2, 128, 224, 33, 71), (1, 128, 64, 130, 128)])
+                                   (2, 128, 224, 33, 71), (1, 128, 64, 130, 128),
+                                   (32, 256, 256, 32, 32), (3, 128, 128, 37, 35), (2, 128, 128, 24, 30)])   # round 4: half-wide tiles (16 <= Wo < 32); Wo = 15 stays generic
 def test_stride2_forward_kernel_vs_cpu_fp32(shape):
     """Downsample's forward (reference models/modules.py:76-79: pad right / bottom by one, 3x3, stride 2) on conv_s2_fwd_kernel: even and
     odd map sizes, ragged 8 x 32 output tiles, 32-channel chunk counts 2 / 3 / 4 / 8 (odd: the low half of the last 64-channel weight
