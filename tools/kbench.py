@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--stride", type=int, default=1, help="2 = the Downsample geometry (pad 0/1, conv_fwd only)")
     ap.add_argument("--act", type=int, default=0)
     ap.add_argument("--res", type=int, default=0)
+    ap.add_argument("--stats", type=int, default=0, help="conv_fwd: 1 = request the fused GroupNorm statistics epilogue (the training forward's variant)")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--three", type=int, default=-1, help="gn_bwd: 1 = the three-launch path, 0 = the one-launch queue kernel, 2 = the library default, -1 = all")
     ap.add_argument("--dtype", default="bf16")
@@ -64,7 +65,7 @@ def main():
             if a.stride != 1:
                 flops /= 4.0
                 res = None
-            fn = lambda: ops.conv_fwd_raw(x, ss, wp, b, res, n, h, h, c, ho, ho, co, a.ks, a.stride, pt, pt, a.act, False, dt)
+            fn = lambda: ops.conv_fwd_raw(x, ss, wp, b, res, n, h, h, c, ho, ho, co, a.ks, a.stride, pt, pt, a.act, False, dt, want_stats=bool(a.stats))
             byt = (x.numel() + n * co * ho * ho * (2 if res is not None else 1)) * esz
         ms = timeit(fn, a.iters)
         print(f"{a.kind} n={n} c={c}->{co} hw={h} ks={a.ks} act={a.act} {a.dtype}: {ms:.4f} ms  {flops/ms/1e9:.1f} TFLOP/s  {byt/ms/1e6:.1f} GB/s(alg)")
