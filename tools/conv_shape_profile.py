@@ -36,7 +36,7 @@ def main():
         e0.record()
         launch()
         e1.record()
-        rec["ev"].append((kind, shape, e0, e1))
+        rec["ev"].append((kind, shape, e0, e1, ops.last_kernel()))
 
     ops.set_launch_hook(hook)
 
@@ -57,9 +57,9 @@ def main():
     t1.record()
     torch.cuda.synchronize()
     agg = collections.OrderedDict()
-    for kind, sh, e0, e1 in rec["ev"]:
+    for kind, sh, e0, e1, kern in rec["ev"]:
         n, h, w, cin, ho, wo, cout, ks, stride, act, res = sh
-        key = (kind, cin, cout, h, ho, ks, stride, act, res)
+        key = (kind, cin, cout, h, ho, ks, stride, act, res, kern)
         ent = agg.setdefault(key, [0, 0.0, 0.0])
         ent[0] += 1
         ent[1] += e0.elapsed_time(e1)
@@ -67,10 +67,10 @@ def main():
         ent[2] += 2.0 * ks * ks * cin * cout * px
     tot = sum(v[1] for v in agg.values())
     print(f"step {t0.elapsed_time(t1):.2f} ms; {len(rec['ev'])} conv launches, {tot:.2f} ms inside the hooks")
-    print(f"{'kind':10s} {'cin':>4s} {'cout':>4s} {'h':>4s} {'ho':>4s} ks s act res {'calls':>5s} {'ms':>8s} {'ms/call':>8s} {'TF/s':>7s}")
+    print(f"{'kind':10s} {'cin':>4s} {'cout':>4s} {'h':>4s} {'ho':>4s} ks s act res {'calls':>5s} {'ms':>8s} {'ms/call':>8s} {'TF/s':>7s}  last kernel of the launch")
     for key, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        kind, cin, cout, h, ho, ks, stride, act, res = key
-        print(f"{kind:10s} {cin:4d} {cout:4d} {h:4d} {ho:4d} {ks:2d} {stride:1d} {act:3d} {res:3d} {v[0]:5d} {v[1]:8.3f} {v[1]/v[0]:8.4f} {v[2]/v[1]/1e9:7.0f}")
+        kind, cin, cout, h, ho, ks, stride, act, res, kern = key
+        print(f"{kind:10s} {cin:4d} {cout:4d} {h:4d} {ho:4d} {ks:2d} {stride:1d} {act:3d} {res:3d} {v[0]:5d} {v[1]:8.3f} {v[1]/v[0]:8.4f} {v[2]/v[1]/1e9:7.0f}  {kern}")
 
 
 if __name__ == "__main__":
