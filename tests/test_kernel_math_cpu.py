@@ -125,3 +125,44 @@ def test_batch_slices_keep_every_tensor_below_2_to_the_31():
         assert sl[0][0] == 0 and sl[-1][1] == n and all(p[1] == q[0] for p, q in zip(sl, sl[1:]))
         assert all((n1 - n0) * max(a, b) <= (1 << 31) - 1 or n1 - n0 == 1 for n0, n1 in sl)
         assert max(n1 - n0 for n0, n1 in sl) - min(n1 - n0 for n0, n1 in sl) <= max(1, len(sl))
+
+
+@pytest.mark.parametrize("th", [16, 8])
+def test_stream_kernel_staging_plan_covers_the_halo_patch_once(th):
+    """conv3x3_stream.hip, SGeo<TH> + slot_pix: the (TH + 2) x 18-pixel halo patch is moved by 1-KiB DMA pieces of 8 pixels x 128 B;
+    wave w issues pieces w, w + 8, ... and REPEATS its previous piece where w + 8 i runs past the last one (every wave must issue
+    the same number of VMEM operations: the kernel's waits are counted).  Every live patch pixel must be written (>= once, by one
+    piece), dead pixels of the last piece must be flagged out of range, and the per-stage schedule of the plain path (PCNT pieces in
+    each of three stages) must add up to the slot count.  TH = 8 is round 4's tile for small maps."""
+    npix = (th + 2) * 18
+    npiece = (npix * 128 + 1023) // 1024
+    nslot = (npiece + 7) // 8
+    pcnt = nslot // 3
+    assert (npiece, nslot, pcnt) == ((41, 6, 2) if th == 16 else (23, 3, 1))
+    assert 3 * pcnt == nslot                                   # stages 0..2 (chunk B) and 5..7 (next chunk A) issue all slots
+    written = np.zeros(npiece * 8, dtype=int)
+    for wave in range(8):
+        seen = []
+        for i in range(nslot):
+            piece = wave + 8 * i if wave + 8 * i < npiece else wave + 8 * (i - 1)
+            assert 0 <= piece < npiece
+            seen.append(piece)
+            for lrow in range(8):
+                q = piece * 8 + lrow
+                pr = (q * 3641) >> 16                          # the kernel's q / 18
+                assert pr == q // 18
+                live = q < npix
+                if live:
+                    assert 0 <= pr < th + 2 and 0 <= q - 18 * pr < 18
+                written[q] += 1
+        assert len(set(seen)) >= nslot - 1                     # at most one repeated piece per wave
+    assert (written[:npix] >= 1).all()                         # every live pixel arrives
+    # a repeated piece rewrites the same bytes (same source address): benign; pieces are otherwise disjoint
+    per_piece = written.reshape(npiece, 8)[:, 0]
+    assert per_piece.min() >= 1 and per_piece.max() <= 2
+    # fragment addressing: wave_p in 0..3 owns NJ = TH / 8 fragments of 32 pixels; together they tile TH x 16 output pixels
+    nj = th // 8
+    pix = sorted((wp * nj + j) * 32 + l for wp in range(4) for j in range(nj) for l in range(32))
+    assert pix == list(range(th * 16))
+    # deferred stores: 4 NJ per lane, one per stage, all within the 8 stages that follow the tile
+    assert 4 * nj <= 8
