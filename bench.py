@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dp", default="mas", choices=["mas", "ddp"],
                     help="N>1 gradient averaging: mas_hip.dp.GradReducer (default) or torch DistributedDataParallel")
+    ap.add_argument("--optimizer", default="mas", choices=["mas", "torch"],
+                    help="mas: mas_hip.optim.Adam (the same update as torch.optim.Adam, every parameter in one launch; tests/test_gpu_adam.py); "
+                         "torch: torch.optim.Adam(fused=True), what the reference's train.py constructs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-batch", type=int, default=2)
     ap.add_argument("--cpu-baseline-all-cores", action="store_true",
@@ -171,6 +174,14 @@ def cpu_baseline(batch, budget_s=150, all_cores=False):
 
 
 # --------------------------------------------------------------------------------------------------------------------
+def _adam(args, params, **kw):
+    """reference train.py:99-103: torch.optim.Adam.  --optimizer mas (default) = the same update from one kernel launch"""
+    if getattr(args, "optimizer", "mas") == "mas":
+        from mas_hip.optim import Adam
+        return Adam(params, **kw)
+    return torch.optim.Adam(params, fused=True, **kw)
+
+
 def _pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC summary (a separate profiled run of the
     same kernel and shape, tools/pmc_kernel.sh), not measured by this run."""
@@ -360,7 +371,7 @@ def run_vq(args):
     model = model.to(dev).train()
     model.quantize.q_counter = model.quantize.q_re_end      # steady state: VQ lookup on the path, no warm-up bypass
     net, reducer = _wrap_dp(model, args, ddp, local_rank)
-    opt = torch.optim.Adam(model.parameters(), lr=5e-6, betas=(0.5, 0.9), fused=True)   # conf/img_config.yaml:36-41
+    opt = _adam(args, model.parameters(), lr=5e-6, betas=(0.5, 0.9))                    # conf/img_config.yaml:36-41
 
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)          # distinct data per rank
     x = torch.rand(batch, 3, 256, 256, generator=g).to(dev)
@@ -416,7 +427,8 @@ def run_vq(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "VQ-IMG 256x256, codebook 8192x256, conf/img_config.yaml model block (95.2 M params), "
                                    "fwd+bwd of L1+q_loss + Adam step", "per_gpu_batch": batch, "global_batch": batch * world,
-                       "parallelism": _par(world, args, ddp) + (" + SyncBatchNorm" if ddp else "")},
+                       "parallelism": _par(world, args, ddp) + (" + SyncBatchNorm" if ddp else ""),
+                       "optimizer": "mas_hip.optim.Adam (one launch; = torch.optim.Adam's update)" if args.optimizer == "mas" else "torch.optim.Adam(fused=True)"},
             "final_loss": round(final_loss, 5),
             "replica_weight_checksum_spread": spread,
             "model_tflops_per_gpu": round(value / world * FWD_BWD_GFLOP_PER_IMG / 1e3, 1),
@@ -544,7 +556,7 @@ def run_transformer(args, e2e):
     torch.manual_seed(0)
     model = MakeAScene(**cfg).to(dev).train()
     net, reducer = _wrap_dp(model, args, ddp, local_rank)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+    opt = _adam(args, model.parameters(), lr=1e-4)
     g = torch.Generator(device="cpu").manual_seed(4321 + rank)
     text = torch.randint(1, 49408, (batch, 256), generator=g)
     text[:, 200:] = 0                                                    # zero-padded tail (transformer.py:350-353)

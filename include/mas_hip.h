@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAS_ABI_VERSION 4
+#define MAS_ABI_VERSION 5
 
 enum { MAS_OK = 0, MAS_EINVAL = -1, MAS_EUNSUPPORTED = -2, MAS_ELAUNCH = -3, MAS_EWORKSPACE = -4 };
 enum { MAS_F32 = 0, MAS_BF16 = 1 };
@@ -103,6 +103,20 @@ typedef struct MasPackTileItem {
 } MasPackTileItem;
 int    mas_pack_tile_blocks(int Cout, int Cin, int ks);
 int    mas_pack_conv_weight_tiles(const MasPackTileItem* items_device, int n_items, int total_blocks, int max_ks, void* stream);
+
+/* ---- Adam over many tensors in ONE launch (replaces torch.optim.Adam.step of reference train.py:99-103 for fp32 parameters; same
+ * arithmetic in the same order as torch's fused kernel: g' = g + wd p; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
+ * p -= (lr / bias_correction1) * m / (sqrt(v) / sqrt(bias_correction2) + eps), bias_correction_k = 1 - beta_k^step from the caller).
+ * Item i covers work-groups [first_block, first_block + mas_adam_blocks(n)); items in ascending first_block order, table in DEVICE memory.
+ * No amsgrad, no maximize; p, g, m, v fp32 of n elements each (16-byte aligned tensors take the vector path).                        */
+typedef struct MasAdamItem {
+    float* p; const float* g; float* m; float* v;
+    long long n;
+    int first_block, pad_;
+} MasAdamItem;
+int    mas_adam_blocks(long long numel);
+int    mas_adam_multi(const MasAdamItem* items_device, int n_items, int total_blocks, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, double bias_correction1, double bias_correction2, void* stream);
 
 /* ---- GroupNorm statistics (replaces the reduction half of torch.nn.GroupNorm,
  * modules.py:40-41).  x: [N,HW,C] NHWC.  Outputs:

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MAS_HIP_LIB") or os.path.join(_HERE, "libmas_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_AFFINE, ACT_AFFINE_SILU = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 WLAYOUT_K64, WLAYOUT_K32 = 0, 1
 
 
@@ -40,6 +40,12 @@ class PackTileItem(C.Structure):
                [(n, C.c_int32) for n in ("n_img", "Cout", "Cin", "ks", "first_block", "pad_")]
 
 
+class AdamItem(C.Structure):
+    """Mirror of ``MasAdamItem`` (include/mas_hip.h): one fp32 parameter with its gradient and the two Adam moments."""
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_longlong), ("first_block", C.c_int32),
+                ("pad_", C.c_int32)]
+
+
 _p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _SIGNATURES = {
     "mas_abi_version": (C.c_int, []),
@@ -50,6 +56,8 @@ _SIGNATURES = {
     "mas_conv_weight_layout": (_i, [C.POINTER(ConvDesc)]),
     "mas_pack_conv_weight_layout": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mas_pack_batch_blocks": (_i, [_i, _i, _i, _i, _i, _i]),
+    "mas_adam_blocks": (_i, [C.c_longlong]),
+    "mas_adam_multi": (_i, [_p, _i, _i, _f, _f, _f, _f, _f, C.c_double, C.c_double, _p]),
     "mas_pack_conv_weight_batch": (_i, [_p, _i, _i, _p]),
     "mas_pack_tile_blocks": (_i, [_i, _i, _i]),
     "mas_pack_conv_weight_tiles": (_i, [_p, _i, _i, _i, _p]),

@@ -1,0 +1,96 @@
+"""``mas_hip.optim.Adam``: torch.optim.Adam's update (reference train.py:99-103) for fp32 CUDA parameters as ONE kernel launch per
+step over all parameters of all groups that share hyper-parameters (``mas_adam_multi``).  Same arithmetic, same state layout
+(``state[p] = {"step", "exp_avg", "exp_avg_sq"}``: ``state_dict()`` / ``load_state_dict()`` interchange with torch.optim.Adam), same
+constructor arguments; ``amsgrad`` / ``maximize`` / ``capturable`` / ``differentiable`` are not implemented and raise.
+
+It is a ``torch.optim.Optimizer``: the process-wide post-step hook of ``mas_hip.ops`` sees its steps, so packed weight images and
+bf16 shadows are refreshed exactly as with torch's optimizers.  Parameters that are not fp32 CUDA tensors (none in the reference's
+models) are updated by a plain torch expression with the same formula."""
+import ctypes as C
+import math
+
+import torch
+
+from . import AdamItem, check, lib
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, *, maximize=False,
+                 capturable=False, differentiable=False, fused=None, foreach=None):
+        if amsgrad or maximize or capturable or differentiable:
+            raise NotImplementedError("mas_hip.optim.Adam: amsgrad / maximize / capturable / differentiable are not implemented")
+        if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or not 0.0 <= weight_decay:
+            raise ValueError("mas_hip.optim.Adam: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                                      capturable=False, differentiable=False, fused=None, foreach=None))
+        self._tables = {}            # device index -> (signature, device table, pinned staging, event of the last upload)
+
+    def _table(self, device, items):
+        """the item table on the device; rebuilt and re-uploaded (pinned staging, asynchronous) only when a pointer changed"""
+        arr = (AdamItem * len(items))(*items)
+        raw = bytes(memoryview(arr))
+        ent = self._tables.get(device.index)
+        if ent is not None and ent[0] == raw:
+            return ent[1]
+        nbytes = len(raw)
+        if ent is None or ent[2].numel() < nbytes:
+            pinned = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, pin_memory=True)
+            dev = torch.empty(pinned.numel(), dtype=torch.uint8, device=device)
+            ev = torch.cuda.Event()
+        else:
+            _, dev, pinned, ev = ent
+            ev.synchronize()         # the previous upload has left the staging buffer (it did: a whole step ago)
+        C.memmove(pinned.data_ptr(), raw, nbytes)
+        dev[:nbytes].copy_(pinned[:nbytes], non_blocking=True)
+        ev.record()
+        self._tables[device.index] = (raw, dev, pinned, ev)
+        return dev
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            lr, (b1, b2), eps, wd = float(group["lr"]), group["betas"], float(group["eps"]), float(group["weight_decay"])
+            by_dev, first = {}, {}
+            step_no = None
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError("mas_hip.optim.Adam does not support sparse gradients")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                t = int(st["step"])
+                native = (p.is_cuda and p.dtype == torch.float32 and p.grad.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
+                          and st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous() and p.grad.device == p.device)
+                if not native or (step_no is not None and t != step_no):
+                    self._torch_update(p, st, t, lr, b1, b2, eps, wd)       # (another dtype / device, or a parameter on its own step count)
+                    continue
+                step_no = t
+                it = AdamItem()
+                it.p, it.g, it.m, it.v, it.n = p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+                it.first_block = first.get(p.device, 0)
+                first[p.device] = it.first_block + lib().mas_adam_blocks(p.numel())
+                by_dev.setdefault(p.device, []).append(it)
+            for device, items in by_dev.items():
+                with torch.cuda.device(device):
+                    table = self._table(device, items)
+                    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+                    check(lib().mas_adam_multi(C.c_void_p(table.data_ptr()), len(items), first[device], lr, b1, b2, eps, wd,
+                                               1.0 - b1 ** step_no, 1.0 - b2 ** step_no, stream), "adam_multi")
+        return loss
+
+    @staticmethod
+    def _torch_update(p, st, t, lr, b1, b2, eps, wd):
+        g = p.grad if wd == 0.0 else p.grad.add(p, alpha=wd)
+        st["exp_avg"].lerp_(g.to(st["exp_avg"].dtype), 1.0 - b1)
+        st["exp_avg_sq"].mul_(b2).addcmul_(g, g, value=1.0 - b2)
+        denom = (st["exp_avg_sq"].sqrt() / math.sqrt(1.0 - b2 ** t)).add_(eps)
+        p.addcdiv_(st["exp_avg"], denom, value=-lr / (1.0 - b1 ** t))

@@ -302,7 +302,7 @@ def test_weight_cache_invalidation():
     assert relerr(conv(x), F.conv2d(x.cpu(), new_w.cpu() + 1.0, conv.bias.detach().cpu(), padding=1)) < 2e-4
 
 
-@pytest.mark.parametrize("opt_kw", [dict(fused=True), dict(foreach=True), dict(foreach=False, fused=False)])
+@pytest.mark.parametrize("opt_kw", [dict(fused=True), dict(foreach=True), dict(foreach=False, fused=False), dict(mas=True)])
 def test_packed_weights_follow_every_optimizer_flavour(opt_kw):
     """torch.optim.Adam(fused=True) updates parameters WITHOUT bumping Parameter._version (measured); the packed-weight cache and the
     bf16 Linear shadows must still refresh after its step (global optimizer post-step hook): the convolution and the Linear layer after
@@ -317,7 +317,11 @@ def test_packed_weights_follow_every_optimizer_flavour(opt_kw):
     lin = Linear(64, 64).cuda()
     x = torch.randn(2, 64, 32, 32, device="cuda")
     xl = torch.randn(7, 64, device="cuda")
-    opt = torch.optim.Adam(list(conv.parameters()) + list(lin.parameters()), lr=0.05, **opt_kw)
+    if opt_kw.get("mas"):
+        from mas_hip.optim import Adam as MasAdam                  # round 4: the library's own one-launch Adam
+        opt = MasAdam(list(conv.parameters()) + list(lin.parameters()), lr=0.05)
+    else:
+        opt = torch.optim.Adam(list(conv.parameters()) + list(lin.parameters()), lr=0.05, **opt_kw)
 
     def outs():
         y = conv(x)
