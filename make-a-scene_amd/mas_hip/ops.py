@@ -719,19 +719,21 @@ def norm_act_conv(x, weight, bias, gn_w=None, gn_b=None, residual=None, *, strid
 
 
 class _ResBlock(torch.autograd.Function):
-    """x + conv2(silu(gn2(conv1(silu(gn1(x))))))  for Cin == Cout (reference ResnetBlock.forward, models/modules.py:119-136)
-    as ONE autograd node: same kernels as two ``_NormActConv`` calls, but the backward hands the skip-connection gradient
-    to the GroupNorm-backward kernel of norm1 (``dres``), so the two gradient branches of x are summed inside that
+    """shortcut(x) + conv2(silu(gn2(conv1(silu(gn1(x))))))  (reference ResnetBlock.forward, models/modules.py:119-136) as ONE autograd
+    node; shortcut = identity for Cin == Cout, the block's 1x1 ``nin_shortcut`` otherwise (round 4).  Same kernels as two
+    ``_NormActConv`` calls (+ the 1x1), but the backward hands the skip-connection gradient -- dy itself, or the 1x1's data gradient
+    of dy -- to the GroupNorm-backward kernel of norm1 (``dres``), so the two gradient branches of x are summed inside that
     streaming pass instead of by a separate elementwise add over the full activation."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, groups, eps, cd, xpart=None, xrows=0, grad=True):
+    def forward(ctx, x, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, sw, sb, groups, eps, cd, xpart=None, xrows=0, grad=True):
         _require_cuda(x, "resblock")
         x = nhwc(x, cd)
         n, c, h, w = x.shape
-        f32 = lambda t: t.detach().float()
+        co = c1w.shape[0]
+        f32 = lambda t: t.detach().float() if t is not None else None
         ng = ctx.needs_input_grad
-        mat = _MATERIALIZE and _gn_act_ok(c, x.dtype)
+        mat = _MATERIALIZE and _gn_act_ok(c, x.dtype) and _gn_act_ok(co, x.dtype)
 
         def norm(inp, gw, gb, part, rows):
             """-> (mean_rstd, scale_shift, activated tensor or None): small maps without statistics from the producer take ONE launch"""
@@ -739,65 +741,80 @@ class _ResBlock(torch.autograd.Function):
                 return gn_stats_act(inp, f32(gw), f32(gb), groups, eps, ACT_AFFINE_SILU)
             return gn_stats(inp, f32(gw), f32(gb), groups, eps, part, rows) + (None,)
 
-        def conv(inp, ss_, a_, wgt, bia, resid, need_w):
+        def conv(inp, ss_, a_, wgt, bia, resid, need_w, ci):
             """-> (output, statistics table, rows, activated input if the backward wants it)"""
             if mat:                                  # (with or without a weight gradient to share it with: see _NormActConv.forward)
                 if a_ is None:
                     a_ = gn_act(inp, ss_, ACT_AFFINE_SILU)
-                return conv_fwd_raw(a_, None, ConvWeight(wgt, False), f32(bia), resid, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_NONE, False, cd,
+                return conv_fwd_raw(a_, None, ConvWeight(wgt, False), f32(bia), resid, n, h, w, ci, h, w, co, 3, 1, 1, 1, ACT_NONE, False, cd,
                                     want_stats=True) + (a_ if grad and need_w else None,)
-            return conv_fwd_raw(inp, ss_, ConvWeight(wgt, False), f32(bia), resid, n, h, w, c, h, w, c, 3, 1, 1, 1, ACT_AFFINE_SILU, False,
+            return conv_fwd_raw(inp, ss_, ConvWeight(wgt, False), f32(bia), resid, n, h, w, ci, h, w, co, 3, 1, 1, 1, ACT_AFFINE_SILU, False,
                                 cd, want_stats=True) + (None,)
 
         mr1, ss1, act1 = norm(x, n1w, n1b, xpart, xrows)
-        hh, hpart, hrows, a1 = conv(x, ss1, act1, c1w, c1b, None, ng[3] or ng[4])
+        hh, hpart, hrows, a1 = conv(x, ss1, act1, c1w, c1b, None, ng[3] or ng[4], c)
+        # the skip path: x itself, or nin_shortcut(x) (a plain 1x1 on the block's INPUT, models/modules.py:131-134)
+        skip = x if sw is None else conv_fwd_raw(x, None, ConvWeight(sw, False), f32(sb), None, n, h, w, c, h, w, co, 1, 1, 0, 0, ACT_NONE, False, cd)
         mr2, ss2, act2 = norm(hh, n2w, n2b, hpart, hrows)
-        y, ypart, yrows, a2 = conv(hh, ss2, act2, c2w, c2b, x, ng[7] or ng[8])
+        y, ypart, yrows, a2 = conv(hh, ss2, act2, c2w, c2b, skip, ng[7] or ng[8], co)
         _stats_state["stash"] = (ypart, yrows) if ypart is not None else None
-        ctx.groups, ctx.cd = groups, cd
-        ctx.save_for_backward(x, hh, mr1, ss1, mr2, ss2, n1w, c1w, n2w, c2w, a1, a2)
+        ctx.groups, ctx.cd, ctx.has_sc = groups, cd, sw is not None
+        ctx.save_for_backward(x, hh, mr1, ss1, mr2, ss2, n1w, c1w, n2w, c2w, a1, a2, sw)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, hh, mr1, ss1, mr2, ss2, n1w, c1w, n2w, c2w, a1, a2 = ctx.saved_tensors
+        x, hh, mr1, ss1, mr2, ss2, n1w, c1w, n2w, c2w, a1, a2, sw = ctx.saved_tensors
         cd, groups = ctx.cd, ctx.groups
         n, c, h, w = x.shape
+        co = c1w.shape[0]
         dy = nhwc(dy, cd)
         ng = ctx.needs_input_grad
-        geo = (n, h, w, c, h, w, c, 3, 1, 1, 1)
-        dw2 = db2 = dw1 = db1 = None
+        geo1 = (n, h, w, c, h, w, co, 3, 1, 1, 1)
+        geo2 = (n, h, w, co, h, w, co, 3, 1, 1, 1)
+        geo1t = (n, h, w, co, h, w, c, 3, 1, 1, 1)           # conv1's data gradient: a convolution from Cout back to Cin
+        dw2 = db2 = dw1 = db1 = dsw = dsb = None
         dx = dg1w = dg1b = None
 
         def wgrad2():
-            return conv_wgrad_raw(a2, None, dy, *geo, ACT_NONE, False, True) if a2 is not None else \
-                conv_wgrad_raw(hh, ss2, dy, *geo, ACT_AFFINE_SILU, False, True)
+            return conv_wgrad_raw(a2, None, dy, *geo2, ACT_NONE, False, True) if a2 is not None else \
+                conv_wgrad_raw(hh, ss2, dy, *geo2, ACT_AFFINE_SILU, False, True)
 
         def wgrad1(dh_):
-            return conv_wgrad_raw(a1, None, dh_, *geo, ACT_NONE, False, True) if a1 is not None else \
-                conv_wgrad_raw(x, ss1, dh_, *geo, ACT_AFFINE_SILU, False, True)
+            return conv_wgrad_raw(a1, None, dh_, *geo1, ACT_NONE, False, True) if a1 is not None else \
+                conv_wgrad_raw(x, ss1, dh_, *geo1, ACT_AFFINE_SILU, False, True)
 
         need_x = ng[0] or ng[1] or ng[2]
         # conv2 / norm2
         if ng[7] or ng[8]:       # (a2 / a1: the activated inputs the forward left behind -> prologue-free weight gradients)
             dw2, db2 = wgrad2()
-        da2 = conv_fwd_raw(dy, None, ConvWeight(c2w, True), None, None, *geo, ACT_NONE, False, cd)
+        da2 = conv_fwd_raw(dy, None, ConvWeight(c2w, True), None, None, *geo2, ACT_NONE, False, cd)
         dh, dg2w, dg2b = gn_bwd(hh, da2, None, groups, ACT_AFFINE_SILU, n2w.detach().float(), mr2, ss2)
+        # the skip path's parameter gradients and its gradient with respect to x
+        dskip = dy
+        if ctx.has_sc:
+            if ng[9] or ng[10]:
+                dsw, dsb = conv_wgrad_raw(x, None, dy, n, h, w, c, h, w, co, 1, 1, 0, 0, ACT_NONE, False, True)
+            if need_x:
+                dskip = conv_fwd_raw(dy, None, ConvWeight(sw, True), None, None, n, h, w, co, h, w, c, 1, 1, 0, 0, ACT_NONE, False, cd)
         # conv1 / norm1 (+ the skip connection's gradient, fused into the GroupNorm-backward apply pass)
         if ng[3] or ng[4]:
             dw1, db1 = wgrad1(dh)
         if need_x:
-            da1 = conv_fwd_raw(dh, None, ConvWeight(c1w, True), None, None, *geo, ACT_NONE, False, cd)
-            dx, dg1w, dg1b = gn_bwd(x, da1, dy, groups, ACT_AFFINE_SILU, n1w.detach().float(), mr1, ss1)
+            da1 = conv_fwd_raw(dh, None, ConvWeight(c1w, True), None, None, *geo1t, ACT_NONE, False, cd)
+            dx, dg1w, dg1b = gn_bwd(x, da1, dskip, groups, ACT_AFFINE_SILU, n1w.detach().float(), mr1, ss1)
         cast = lambda g, ref: g.to(ref.dtype) if g is not None else None
         return (dx, cast(dg1w, n1w), cast(dg1b, n1w), cast(dw1, c1w), cast(db1, c1w), cast(dg2w, n2w), cast(dg2b, n2w),
-                cast(dw2, c2w), cast(db2, c2w), None, None, None, None, None, None)
+                cast(dw2, c2w), cast(db2, c2w), cast(dsw, sw) if sw is not None else None, cast(dsb, sw) if sw is not None else None,
+                None, None, None, None, None, None)
 
 
-def resblock(x, norm1, conv1, norm2, conv2):
+def resblock(x, norm1, conv1, norm2, conv2, shortcut=None):
+    """``shortcut``: the block's ``nin_shortcut`` module (1x1, stride 1, no padding) when Cin != Cout, else None"""
     xpart, xrows = _take_stats(x)
+    sw, sb = (shortcut.weight, shortcut.bias) if shortcut is not None else (None, None)
     return _attach_stats(_ResBlock.apply(x, norm1.weight, norm1.bias, conv1.weight, conv1.bias, norm2.weight, norm2.bias, conv2.weight,
-                                         conv2.bias, norm1.num_groups, norm1.eps, compute_dtype(), xpart, xrows, torch.is_grad_enabled()))
+                                         conv2.bias, sw, sb, norm1.num_groups, norm1.eps, compute_dtype(), xpart, xrows, torch.is_grad_enabled()))
 
 
 # --------------------------------------------------------------------------- #
