@@ -23,27 +23,35 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("mas_hip.optim.Adam: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
                                       capturable=False, differentiable=False, fused=None, foreach=None))
-        self._tables = {}            # device index -> (signature, device table, pinned staging, event of the last upload)
+        self._tables = {}            # device index -> ring of (pinned staging, device table, event) slots + the bytes of the current table
+
+    _RING = 4
 
     def _table(self, device, items):
-        """the item table on the device; rebuilt and re-uploaded (pinned staging, asynchronous) only when a pointer changed"""
+        """The item table on the device.  Gradient tensors are usually fresh allocations every step (``zero_grad(set_to_none=True)``),
+        so the table changes every step: it goes through a ring of pinned staging buffers with an asynchronous copy each, and the
+        host only waits for the copy issued ``_RING`` steps ago -- never for the step in flight (a wait on the previous step's copy
+        would serialise the host behind the whole backward: measured, +9 ms of wall time per step)."""
         arr = (AdamItem * len(items))(*items)
         raw = bytes(memoryview(arr))
         ent = self._tables.get(device.index)
-        if ent is not None and ent[0] == raw:
-            return ent[1]
+        if ent is not None and ent["raw"] == raw:
+            return ent["slots"][ent["cur"]][1]
         nbytes = len(raw)
-        if ent is None or ent[2].numel() < nbytes:
-            pinned = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, pin_memory=True)
-            dev = torch.empty(pinned.numel(), dtype=torch.uint8, device=device)
-            ev = torch.cuda.Event()
-        else:
-            _, dev, pinned, ev = ent
-            ev.synchronize()         # the previous upload has left the staging buffer (it did: a whole step ago)
+        if ent is None or ent["cap"] < nbytes:
+            cap = max(nbytes, 1 << 16)
+            ent = self._tables[device.index] = dict(cap=cap, cur=0, raw=None, slots=[
+                (torch.empty(cap, dtype=torch.uint8, pin_memory=True), torch.empty(cap, dtype=torch.uint8, device=device), torch.cuda.Event())
+                for _ in range(self._RING)], used=[False] * self._RING)
+        ent["cur"] = (ent["cur"] + 1) % self._RING
+        pinned, dev, ev = ent["slots"][ent["cur"]]
+        if ent["used"][ent["cur"]]:
+            ev.synchronize()         # the copy issued _RING table changes ago has left this staging buffer
         C.memmove(pinned.data_ptr(), raw, nbytes)
         dev[:nbytes].copy_(pinned[:nbytes], non_blocking=True)
         ev.record()
-        self._tables[device.index] = (raw, dev, pinned, ev)
+        ent["used"][ent["cur"]] = True
+        ent["raw"] = raw
         return dev
 
     @torch.no_grad()

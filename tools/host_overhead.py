@@ -16,7 +16,11 @@ with torch.no_grad():
     model.quantize.embedding.weight.normal_(0.0, 1.0)
 model = model.to(dev).train()
 model.quantize.q_counter = model.quantize.q_re_end
-opt = torch.optim.Adam(model.parameters(), lr=5e-6, betas=(0.5, 0.9), fused=True)
+if os.environ.get("OPT", "mas") == "mas":
+    from mas_hip.optim import Adam
+    opt = Adam(model.parameters(), lr=5e-6, betas=(0.5, 0.9))
+else:
+    opt = torch.optim.Adam(model.parameters(), lr=5e-6, betas=(0.5, 0.9), fused=True)
 B = int(os.environ.get("B", "32"))
 x = torch.rand(B, 3, 256, 256).to(dev)
 
