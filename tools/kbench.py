@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--stride", type=int, default=1, help="2 = the Downsample geometry (pad 0/1, conv_fwd only)")
     ap.add_argument("--act", type=int, default=0)
     ap.add_argument("--res", type=int, default=0)
+    ap.add_argument("--ups", type=int, default=0, help="conv_fwd: 1 = Upsample's convolution (nearest x2 folded in: --hw is the INPUT map, the output is 2x)")
     ap.add_argument("--stats", type=int, default=0, help="conv_fwd: 1 = request the fused GroupNorm statistics epilogue (the training forward's variant)")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--three", type=int, default=-1, help="gn_bwd: 1 = the three-launch path, 0 = the one-launch queue kernel, 2 = the library default, -1 = all")
@@ -60,12 +61,15 @@ def main():
         else:
             wp = ops.ConvWeight(torch.nn.Parameter(w), a.kind == "dgrad")   # packed (once: the Parameter is cached) in the layout the library prefers
             res = torch.randn(n, co, h, h, device=dev).to(dt).contiguous(memory_format=torch.channels_last) if a.res else None
-            ho = h if a.stride == 1 else h // 2
+            ho = (2 * h if a.ups else h) if a.stride == 1 else h // 2
             pt = p if a.stride == 1 else 0
+            if a.ups:
+                flops *= 4.0                         # counted as the reference runs it: 9 taps at the output resolution
+                res = None
             if a.stride != 1:
                 flops /= 4.0
                 res = None
-            fn = lambda: ops.conv_fwd_raw(x, ss, wp, b, res, n, h, h, c, ho, ho, co, a.ks, a.stride, pt, pt, a.act, False, dt, want_stats=bool(a.stats))
+            fn = lambda: ops.conv_fwd_raw(x, ss, wp, b, res, n, h, h, c, ho, ho, co, a.ks, a.stride, pt, pt, a.act, bool(a.ups), dt, want_stats=bool(a.stats))
             byt = (x.numel() + n * co * ho * ho * (2 if res is not None else 1)) * esz
         ms = timeit(fn, a.iters)
         print(f"{a.kind} n={n} c={c}->{co} hw={h} ks={a.ks} act={a.act} {a.dtype}: {ms:.4f} ms  {flops/ms/1e9:.1f} TFLOP/s  {byt/ms/1e6:.1f} GB/s(alg)")
