@@ -20,7 +20,7 @@
 // With 256 work-groups of 4 waves the kernels are bound by exposed memory round trips (1.2 us each, measured with -DSP_TRACE), not
 // by MFMA (2 us per work-group) or bandwidth: round 4 keeps 16-32 KiB per wave in flight (prod: next 256-channel step prefetched,
 // apply: M tiles four ahead and issued before the softmax) and does the softmax / dS arithmetic on the accumulators instead of
-// bouncing fp32 scores through LDS row by row (forward 57 -> measured in profiles/r04_spatial_attn.txt).
+// bouncing fp32 scores through LDS row by row: forward 58 -> 23 us, backward 72 + 95 -> 31 + 43 us (profiles/r04_spatial_attn.txt).
 // No atomics: every output element is written exactly once (deterministic).
 #include "mas_common.h"
 #include <math.h>
@@ -206,7 +206,7 @@ __device__ __forceinline__ float sp_row_reduce(float v, float* pad, int wave, in
 // The 32-token tiles of M go global -> registers -> LDS, FOUR tiles ahead: sp_apply_issue puts tiles 0..3 in flight (the callers do
 // that before their softmax / dS arithmetic, M does not depend on it), sp_apply_run commits tile t+1 into the LDS buffer tile t-1 just
 // left, re-arms its registers with tile t+4 and runs tile t's MFMAs -- one barrier per tile, and a tile's round trip (1.2 us measured)
-// is spread over four tiles of work instead of being exposed 8 times (11.3 us -> measured below).
+// is spread over four tiles of work instead of being exposed 8 times (P.V phase of the forward: 11.3 -> 6.8 us).
 __device__ __forceinline__ int sp_rot_tile(int t, int rot, int nt) { const int tt = t + rot; return tt >= nt ? tt - nt : tt; }   // rot < nt
 
 __device__ __forceinline__ void sp_apply_issue(u32x4 (&pf)[4][8], const bf16_t* M, int ld, int S, int C, int rot, int tid) {
