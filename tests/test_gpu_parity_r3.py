@@ -387,7 +387,8 @@ def test_gn_act_equals_the_fused_prologue(shape, dtype):
 # --------------------------------------------------------------------------------------------------------------
 # 6b. 1x1 convolutions on the GEMM kernel (conv1x1.hip)
 # --------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(2, 64, 128, 16, 16), (3, 192, 384, 9, 7), (32, 512, 1536, 16, 16), (1, 128, 256, 40, 24), (4, 256, 128, 5, 5)])
+@pytest.mark.parametrize("shape", [(2, 64, 128, 16, 16), (3, 192, 384, 9, 7), (32, 512, 1536, 16, 16), (1, 128, 256, 40, 24), (4, 256, 128, 5, 5),
+                                   (2, 320, 128, 13, 11), (1, 448, 256, 33, 9)])      # (5 / 7 chunks)
 def test_conv1x1_gemm_kernel_vs_cpu_fp32(shape):
     """nin_shortcut / AttnBlock q,k,v,proj_out (reference models/modules.py:106-108,145-160) as plain GEMMs: forward with bias and
     residual, the data gradient (transposed weight image) and the weight gradient, against F.conv2d / autograd in fp32 on the CPU.
