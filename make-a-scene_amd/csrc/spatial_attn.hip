@@ -5,10 +5,10 @@
 // blocks are 16x16x512 for VQ-IMG, 8x8x512 for VQ-SEG), so one 32-token block's whole score row fits LDS and no online softmax is
 // needed.  q, k, v are read in place from the fused [N, S, 3C] projection (q | k | v on the channel axis).
 //
-// Every kernel is built from two tile products (4 waves = one per SIMD; MFMA 32x32x16 bf16):
+// Every kernel is built from two tile products (8 waves = two per SIMD since the end of round 4, NW below; MFMA 32x32x16 bf16):
 //   prod : T[32 rows][S]   = X_blk[32][C] . Y_all[S][C]^T     (contraction over channels: both operands channel-contiguous, so
 //                             Y rows stream straight from global memory as MFMA A fragments, X_blk rows come from LDS; T STAYS IN
-//                             THE ACCUMULATORS: wave w holds column tiles w and w+4, a lane 32 columns of one row)
+//                             THE ACCUMULATORS: wave w holds column tile w (tiles w and w+4 with 4 waves), a lane 16 (32) columns of one row)
 //   apply: O[32 rows][C]   = P[32][S] . M_all[S][C]           (contraction over tokens: M tiles are staged in their natural
 //                             [token][channel] layout and read with the LDS transpose read ds_read_b64_tr_b16 -- per-lane
 //                             addressing as in conv_wgrad.hip -- P rows (bf16) come from LDS)
@@ -27,8 +27,15 @@
 
 namespace {
 
-constexpr int SNT = 256;
+#ifndef SP_NW
+#define SP_NW 8                                 // waves per work-group: 8 (two per SIMD; shipped) or 4 (-DSP_NW=4: the A/B of profiles/r04_spatial_attn.txt, section 8)
+#endif
+constexpr int NW = SP_NW, SNT = 64 * NW;
 constexpr int S_MAX = 256, C_MAX = 512;
+constexpr int TPW = S_MAX / 32 / NW;            // 32-column score tiles per wave: 2 | 1
+constexpr int CPW = C_MAX / 32 / NW;            // 32-channel output tiles per wave: 4 | 2
+constexpr int UPT = 32 * (C_MAX / 8) / SNT;     // 16-byte units of a 32-row tile per thread: 8 | 4
+static_assert(NW == 4 || NW == 8, "4 or 8 waves");
 
 // -DSP_TRACE (tools/build_file_variant.sh, never the shipped build): wave 0 of one work-group stamps the 100 MHz wall clock at the phase
 // boundaries of the forward kernel; tools/kbench.py sp_attn prints the differences.
@@ -64,7 +71,7 @@ struct SpLds {
         const int Sp = (S + 31) & ~31;           // the products write whole 32-column tiles
         RX = ((C + 127) & ~127) * 2 + 16; SP = Sp * 2 + 16; RM = C * 2 + 64;
         o_x = 0; o_p = o_x + 32 * RX; o_p2 = o_p + 32 * SP; o_m0 = o_p2 + 32 * SP; o_m1 = o_m0 + 32 * RM; o_r = o_m1 + 32 * RM;
-        total = o_r + 2 * 4 * 32 * 4;            // two [4 waves][32 rows] fp32 reduction pads
+        total = o_r + 2 * NW * 32 * 4;           // two [waves][32 rows] fp32 reduction pads
     }
 };
 
@@ -79,10 +86,10 @@ struct SpMap {
     int r, cu, dr, dc, upr;
     __device__ __forceinline__ SpMap(int C, int tid) { upr = C / 8; r = tid / upr; cu = tid - r * upr; dr = SNT / upr; dc = SNT - dr * upr; }
 };
-__device__ __forceinline__ void sp_rows_fetch(u32x4 (&pf)[8], const bf16_t* src, int ld, int r0, int S, const SpMap& mp) {
+__device__ __forceinline__ void sp_rows_fetch(u32x4 (&pf)[UPT], const bf16_t* src, int ld, int r0, int S, const SpMap& mp) {
     int r = mp.r, cu = mp.cu;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < UPT; ++k) {
         const int rr = min(r, 31), cc = r > 31 ? mp.upr - 1 : cu;          // units past the tile re-read its last unit
         pf[k] = *reinterpret_cast<const u32x4*>(src + (size_t)min(r0 + rr, S - 1) * ld + cc * 8);
         cu += mp.dc; r += mp.dr;
@@ -90,10 +97,10 @@ __device__ __forceinline__ void sp_rows_fetch(u32x4 (&pf)[8], const bf16_t* src,
     }
 }
 // ... -> LDS with row stride RS (rows >= S are zero)
-__device__ __forceinline__ void sp_rows_commit(const u32x4 (&pf)[8], unsigned char* dst, int RS, int r0, int S, const SpMap& mp) {
+__device__ __forceinline__ void sp_rows_commit(const u32x4 (&pf)[UPT], unsigned char* dst, int RS, int r0, int S, const SpMap& mp) {
     int r = mp.r, cu = mp.cu;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < UPT; ++k) {
         const int rr = min(r, 31), cc = r > 31 ? mp.upr - 1 : cu;
         const bool ok = r0 + rr < S;
         const u32x4 v = {ok ? pf[k][0] : 0u, ok ? pf[k][1] : 0u, ok ? pf[k][2] : 0u, ok ? pf[k][3] : 0u};
@@ -110,12 +117,16 @@ __device__ __forceinline__ void sp_rows_commit(const u32x4 (&pf)[8], unsigned ch
 // (27 GB/s per CU measured = the L1 miss queue x 128 B / that latency, with 8 CUs spending it on the SAME lines).  `rot` (the block's
 // index within its image) de-phases them: odd blocks start with their upper column tile, bit 1 flips the order of the two channel
 // halves (here), and the apply walks its token tiles starting at tile `rot` -- the lines one block waits for are hits for the rest.
-__device__ __forceinline__ void sp_tiles(int (&mt)[2], int wave, int S, int rot) {
-    const bool swap = (wave + 4 < (S + 31) / 32) && (rot & 1);
-    mt[0] = swap ? wave + 4 : wave;
-    mt[1] = swap ? wave : wave + 4;
+__device__ __forceinline__ void sp_tiles(int (&mt)[TPW], int wave, int S, int rot) {
+    if constexpr (TPW == 2) {
+        const bool swap = (wave + 4 < (S + 31) / 32) && (rot & 1);
+        mt[0] = swap ? wave + 4 : wave;
+        mt[TPW - 1] = swap ? wave : wave + 4;
+    } else {
+        mt[0] = wave;                            // 8 waves: one column tile each
+    }
 }
-__device__ __forceinline__ int sp_col(const int (&mt)[2], int ti, int r, int g) { return mt[ti] * 32 + (r & 3) + 8 * (r >> 2) + 4 * g; }
+__device__ __forceinline__ int sp_col(const int (&mt)[TPW], int ti, int r, int g) { return mt[ti] * 32 + (r & 3) + 8 * (r >> 2) + 4 * g; }
 
 // sc[ti][r] = sum_c X[r0 + n][c] * Y[m][c]: the 32 block rows are staged into xs (LDS) by this call, the rows of Y stream straight
 // from global memory as MFMA A fragments (lane = m), B operand (lane = n) from LDS; the result stays in the accumulators.
@@ -127,14 +138,14 @@ __device__ __forceinline__ int sp_col(const int (&mt)[2], int ti, int r, int g) 
 //   that a step has no per-fragment branch, and a step that does not exist for this wave / this C still loads (one clamped line) and
 //   only skips its MFMAs under a wave-uniform branch.  The first version, with two 16-fragment buffers selected by `k & 1 ? a0 : a1`
 //   and per-fragment bounds branches, compiled to 2700 v_accvgpr moves per product.
-__device__ __forceinline__ void sp_prod(f32x16 (&sc)[2], const int (&mt)[2], int rot, unsigned char* xs, int RX, const bf16_t* X, int ldx,
+__device__ __forceinline__ void sp_prod(f32x16 (&sc)[TPW], const int (&mt)[TPW], int rot, unsigned char* xs, int RX, const bf16_t* X, int ldx,
                                         int r0, const bf16_t* Y, int ld, int S, int C, int tid) {
     const int lane = tid & 63, g = lane >> 5, l31 = lane & 31;
     const int n_mt = (S + 31) / 32, n_grp = (C + 127) / 128;            // 1..4 channel groups
-    const int my_tiles = (mt[0] < n_mt) + (mt[1] < n_mt);               // 0, 1 or 2 (S <= 256); slot 0 is the valid one when 1
+    const int my_tiles = (mt[0] < n_mt) + (TPW == 2 ? (mt[TPW - 1] < n_mt) : 0);      // 0, 1 or 2 (S <= 256); slot 0 is the valid one when 1
     const int gr = (rot >> 1) & 3;                                      // (the blocks of an image start on different groups)
     const SpMap mp(C, tid);
-    u32x4 xr_[8];
+    u32x4 xr_[UPT];
     sp_rows_fetch(xr_, X, ldx, r0, S, mp);
     bf16x8 a[4][8];
     auto fetch = [&](bf16x8 (&f)[8], int k) {
@@ -155,13 +166,13 @@ __device__ __forceinline__ void sp_prod(f32x16 (&sc)[2], const int (&mt)[2], int
     __syncthreads();
     SP_T(17);
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < TPW; ++ti)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[ti][r] = 0.0f;
     const unsigned char* xr = xs + l31 * RX + 16 * g;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        if (k + 3 < 8) fetch(a[(k + 3) & 3], k + 3);
+    for (int k = 0; k < 4 * TPW; ++k) {
+        if (k + 3 < 4 * TPW) fetch(a[(k + 3) & 3], k + 3);
         const int grp = ((k & 3) + gr) & 3;
         if ((k >> 2) < my_tiles && grp < n_grp) {
             bf16x8 b[8];
@@ -175,10 +186,10 @@ __device__ __forceinline__ void sp_prod(f32x16 (&sc)[2], const int (&mt)[2], int
 }
 
 // bf16 rows of P / dS for the second product: lane (g, l31) owns 4 consecutive columns per accumulator quad -> one 8-byte LDS write
-__device__ __forceinline__ void sp_put_rows(unsigned char* ps, int SP, const f32x16 (&v)[2], int S, const int (&mts)[2], int g, int l31) {
+__device__ __forceinline__ void sp_put_rows(unsigned char* ps, int SP, const f32x16 (&v)[TPW], int S, const int (&mts)[TPW], int g, int l31) {
     const int n_mt = (S + 31) / 32;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
+    for (int ti = 0; ti < TPW; ++ti) {
         const int mt = mts[ti];
         if (mt < n_mt) {
 #pragma unroll
@@ -197,8 +208,10 @@ __device__ __forceinline__ float sp_row_reduce(float v, float* pad, int wave, in
     v = MAX ? fmaxf(v, o) : v + o;
     if (g == 0) pad[wave * 32 + l31] = v;
     __syncthreads();
-    const float a = pad[l31], b = pad[32 + l31], c = pad[64 + l31], d = pad[96 + l31];
-    return MAX ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : (a + b) + (c + d);
+    float acc = pad[l31];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) acc = MAX ? fmaxf(acc, pad[w * 32 + l31]) : acc + pad[w * 32 + l31];
+    return acc;
 }
 
 // O[n][c] = sum_s P[n][s] * M[s][c]: P (bf16 [32][S], LDS), M global [S][ld]; result acc tiles: wave w owns channel tiles
@@ -209,7 +222,7 @@ __device__ __forceinline__ float sp_row_reduce(float v, float* pad, int wave, in
 // is spread over four tiles of work instead of being exposed 8 times (P.V phase of the forward: 11.3 -> 6.8 us).
 __device__ __forceinline__ int sp_rot_tile(int t, int rot, int nt) { const int tt = t + rot; return tt >= nt ? tt - nt : tt; }   // rot < nt
 
-__device__ __forceinline__ void sp_apply_issue(u32x4 (&pf)[4][8], const bf16_t* M, int ld, int S, int C, int rot, int tid) {
+__device__ __forceinline__ void sp_apply_issue(u32x4 (&pf)[4][UPT], const bf16_t* M, int ld, int S, int C, int rot, int tid) {
     const int nt = (S + 31) / 32;
     const SpMap mp(C, tid);
 #pragma unroll
@@ -217,14 +230,14 @@ __device__ __forceinline__ void sp_apply_issue(u32x4 (&pf)[4][8], const bf16_t* 
         if (t < nt) sp_rows_fetch(pf[t], M, ld, sp_rot_tile(t, rot, nt) * 32, S, mp);
 }
 
-__device__ __forceinline__ void sp_apply_run(f32x16 (&acc)[4], u32x4 (&pf)[4][8], const unsigned char* ps, int SP, unsigned char* ms0,
+__device__ __forceinline__ void sp_apply_run(f32x16 (&acc)[CPW], u32x4 (&pf)[4][UPT], const unsigned char* ps, int SP, unsigned char* ms0,
                                              unsigned char* ms1, int RM, const bf16_t* M, int ld, int S, int C, int rot, int tid) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, l31 = lane & 31, G16 = (lane >> 4) & 1, sl = lane & 15;
     const int n_ct = C / 32, nt = (S + 31) / 32;
     const SpMap mp(C, tid);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < CPW; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     __syncthreads();                              // the callers' P / dS rows are written; earlier readers of ms0 / ms1 are done
@@ -237,15 +250,15 @@ __device__ __forceinline__ void sp_apply_run(f32x16 (&acc)[4], u32x4 (&pf)[4][8]
             __syncthreads();                      // tile t is visible; every wave has left tile t-1's buffer
             // (operands first, all of them, then the commit / re-arm traffic, then the 8 MFMAs: with the reads inside the per-channel-
             //  tile bounds branch each MFMA waited out its own LDS round trip -- 1.1 us per tile for 0.12 us of MFMA)
-            bf16x8 bq[2], aq[2][4];
+            bf16x8 bq[2], aq[2][CPW];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bq[ks] = *reinterpret_cast<const bf16x8*>(ps + l31 * SP + (s0 + ks * 16 + 8 * g) * 2);     // P[n][s0 + 16 ks + 8 g ..+7]
                 // transpose-read lane addressing: token (16 ks + 8 g + (sl >> 2)) (+4 for the second read), channels ct*32 + 16*G16 + 4*(sl&3) ..+3
                 const unsigned char* a_lane = cur + (ks * 16 + 8 * g + (sl >> 2)) * RM + (16 * G16 + 4 * (sl & 3)) * 2;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int ct = min(wave + 4 * i, n_ct - 1);          // a channel tile past C recomputes the last real one; sp_store drops it
+                for (int i = 0; i < CPW; ++i) {
+                    const int ct = min(wave + NW * i, n_ct - 1);         // a channel tile past C recomputes the last real one; sp_store drops it
                     aq[ks][i] = sp_tr_frag(a_lane + ct * 64, a_lane + ct * 64 + 4 * RM);
                 }
             }
@@ -254,7 +267,7 @@ __device__ __forceinline__ void sp_apply_run(f32x16 (&acc)[4], u32x4 (&pf)[4][8]
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) mma16(acc[i], aq[ks][i], bq[ks]);
+                for (int i = 0; i < CPW; ++i) mma16(acc[i], aq[ks][i], bq[ks]);
             SP_T(6 + t);
         }
     }
@@ -262,12 +275,12 @@ __device__ __forceinline__ void sp_apply_run(f32x16 (&acc)[4], u32x4 (&pf)[4][8]
 }
 
 // writes acc tiles to out[n][c] (rows r0 + l31 < S), 4 consecutive channels (8 bytes) per accumulator quad
-__device__ __forceinline__ void sp_store(const f32x16 (&acc)[4], bf16_t* out, int ld, int r0, int S, int C, int tid) {
+__device__ __forceinline__ void sp_store(const f32x16 (&acc)[CPW], bf16_t* out, int ld, int r0, int S, int C, int tid) {
     const int lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
     if (r0 + l31 >= S) return;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ct = wave + 4 * i;
+    for (int i = 0; i < CPW; ++i) {
+        const int ct = wave + NW * i;
         if (ct >= C / 32) continue;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -302,42 +315,42 @@ __global__ __launch_bounds__(SNT) void spatial_attn_fwd_kernel(SpParams p) {
     float* pad = reinterpret_cast<float*>(smem + L.o_r);
 
     const int rot = blk % nqb;
-    int mt[2];
+    int mt[TPW];
     sp_tiles(mt, wave, p.S, rot);
     SP_T(0);
-    f32x16 sc[2];
+    f32x16 sc[TPW];
     sp_prod(sc, mt, rot, smem + L.o_x, L.RX, Q, ld, q0, K, ld, p.S, p.C, tid);
     SP_T(1);
-    u32x4 pf[4][8];
+    u32x4 pf[4][UPT];
     sp_apply_issue(pf, V, ld, p.S, p.C, rot, tid);                 // four V tiles travel while the softmax runs
     SP_T(2);
     // softmax over keys, in the accumulators: lane (g, l31) holds 32 of query l31's scores
     float mx = -1e30f;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < TPW; ++ti)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             if (sp_col(mt, ti, r, g) < p.S) mx = fmaxf(mx, sc[ti][r] * p.scale);
     mx = sp_row_reduce<true>(mx, pad, wave, g, l31);
     float sum = 0.0f;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < TPW; ++ti)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float e = sp_col(mt, ti, r, g) < p.S ? __expf(sc[ti][r] * p.scale - mx) : 0.0f;
             sc[ti][r] = e;
             sum += e;
         }
-    sum = sp_row_reduce<false>(sum, pad + 128, wave, g, l31);
+    sum = sp_row_reduce<false>(sum, pad + NW * 32, wave, g, l31);
     const float inv = 1.0f / sum;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < TPW; ++ti)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[ti][r] *= inv;
     sp_put_rows(smem + L.o_p, L.SP, sc, p.S, mt, g, l31);
     if (wave == 0 && g == 0 && q0 + l31 < p.S && p.lse) p.lse[(size_t)n * p.S + q0 + l31] = mx + __logf(sum);
     SP_T(3);
-    f32x16 acc[4];
+    f32x16 acc[CPW];
     sp_apply_run(acc, pf, smem + L.o_p, L.SP, smem + L.o_m0, smem + L.o_m1, L.RM, V, ld, p.S, p.C, rot, tid);
     SP_T(4);
     sp_store(acc, p.out + (size_t)n * p.S * p.C, p.C, q0, p.S, p.C, tid);
@@ -365,13 +378,13 @@ __global__ __launch_bounds__(SNT) void spatial_attn_bwd_kernel(SpParams p) {
 
     // ---- P (block rows x all columns): rows = queries (KEYS = false) or keys (KEYS = true); lse belongs to the QUERY
     const int rot = blk % nb;
-    int mt[2];
+    int mt[TPW];
     sp_tiles(mt, wave, p.S, rot);
-    f32x16 pv[2], dp[2];
+    f32x16 pv[TPW], dp[TPW];
     sp_prod(pv, mt, rot, smem + L.o_x, L.RX, KEYS ? K : Q, ld, r0, KEYS ? Q : K, ld, p.S, p.C, tid);
     const float lrow = (!KEYS && row_ok) ? lse[r0 + l31] : 0.0f;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < TPW; ++ti)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = sp_col(mt, ti, r, g);
@@ -381,20 +394,20 @@ __global__ __launch_bounds__(SNT) void spatial_attn_bwd_kernel(SpParams p) {
     if constexpr (KEYS) sp_put_rows(smem + L.o_p, L.SP, pv, p.S, mt, g, l31);         // dV = P^T dO wants P itself
     // ---- dP: prod(dO_blk, V) (queries) or prod(V_blk, dO) (keys)
     sp_prod(dp, mt, rot + 2, smem + L.o_x, L.RX, KEYS ? V : dO, KEYS ? ld : p.C, r0, KEYS ? dO : V, KEYS ? p.C : ld, p.S, p.C, tid);
-    u32x4 pf[4][8];
+    u32x4 pf[4][UPT];
     if constexpr (!KEYS) sp_apply_issue(pf, K, ld, p.S, p.C, rot, tid);               // K tiles travel under the delta / dS arithmetic
     float drow = 0.0f;
     if constexpr (!KEYS) {                        // delta_q = sum_keys P dP  (= sum_c dO O), published for the dK/dV kernel
         float part = 0.0f;
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
+        for (int ti = 0; ti < TPW; ++ti)
 #pragma unroll
             for (int r = 0; r < 16; ++r) part += pv[ti][r] * dp[ti][r];
         drow = sp_row_reduce<false>(part, pad, wave, g, l31);
         if (wave == 0 && g == 0 && row_ok) delta[r0 + l31] = drow;
     }
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < TPW; ++ti)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = sp_col(mt, ti, r, g);
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(SNT) void spatial_attn_bwd_kernel(SpParams p) {
         }
     if constexpr (KEYS) sp_apply_issue(pf, dO, p.C, p.S, p.C, rot, tid);              // (after the delta loads: nothing waits behind them)
     sp_put_rows(smem + L.o_p2, L.SP, dp, p.S, mt, g, l31);
-    f32x16 acc[4];
+    f32x16 acc[CPW];
     if constexpr (!KEYS) {
         sp_apply_run(acc, pf, smem + L.o_p2, L.SP, smem + L.o_m0, smem + L.o_m1, L.RM, K, ld, p.S, p.C, rot, tid); // dQ = dS K
         sp_store(acc, p.dqkv + (size_t)n * p.S * ld, ld, r0, p.S, p.C, tid);
