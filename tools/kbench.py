@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--three", type=int, default=-1, help="gn_bwd: 1 = the three-launch path, 0 = the one-launch queue kernel, 2 = the library default, -1 = all")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--zero", type=int, default=0, help="1 = all-zero activations and weights (no operand toggling: the power-bound clock give-back)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = torch.device("cuda:0")
@@ -48,8 +49,12 @@ def main():
     n, c, h = a.n, a.c, a.hw
     x = torch.randn(n, c, h, h, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
     esz = x.element_size()
+    if a.zero:
+        x.zero_()
     if a.kind in ("conv_fwd", "dgrad", "wgrad"):
         w = (torch.randn(co, c, a.ks, a.ks, device=dev) / (c * a.ks * a.ks) ** 0.5)
+        if a.zero:
+            w.zero_()
         b = torch.randn(co, device=dev) * 0.1
         ss = torch.randn(n, c, 2, device=dev) if a.act else None
         p = a.ks // 2
