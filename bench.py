@@ -21,8 +21,9 @@ Rank 0 prints ONE JSON line; besides the driver's contract it carries
                   MFMA peak (vq: the 3x3 128->128 conv at 256^2, fwd + dgrad launches, per loader population and launch-weighted
                   -- in training every launch is prologue-free since round 3; transformer / e2e: the causal-attention forward
                   kernel); "mfma_only_floor_ms": the same kernel with everything but MFMAs and LDS reads compiled out (committed);
-  "cpu_baseline": the CPU oracle (oracle/vq_oracle.py, a port of the reference's arithmetic -- /root/reference does not exist
-                  on the GPU box) timed on this host's cores on a bounded sample (rank 0, N=1, vq workload only);
+  "cpu_baseline": the reference itself where a checkout exists (MAS_REFERENCE_ROOT or /root/reference: kind "reference"), else the CPU
+                  oracle (oracle/vq_oracle.py, a port of the reference's arithmetic: kind "port" -- the GPU box has no checkout), timed
+                  on this host's cores on a bounded sample (rank 0, N=1, vq workload only);
   "also":         (vq workload, N=1) compact results of short `--workload transformer` and `--workload e2e` runs (BASELINE configs
                   4 and 5) made right after the headline measurement, so that they carry the same driver clock; --no-also skips them.
 """
@@ -68,9 +69,10 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dp", default="mas", choices=["mas", "ddp"],
                     help="N>1 gradient averaging: mas_hip.dp.GradReducer (default) or torch DistributedDataParallel")
-    ap.add_argument("--optimizer", default="mas", choices=["mas", "torch"],
+    ap.add_argument("--optimizer", default="mas", choices=["mas", "torch", "torch-default"],
                     help="mas: mas_hip.optim.Adam (the same update as torch.optim.Adam, every parameter in one launch; tests/test_gpu_adam.py); "
-                         "torch: torch.optim.Adam(fused=True), what the reference's train.py constructs")
+                         "torch: torch.optim.Adam(fused=True); torch-default: torch.optim.Adam(params, lr, betas) exactly as the reference's "
+                         "train.py:61 constructs it (torch's default foreach implementation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-batch", type=int, default=2)
     ap.add_argument("--cpu-baseline-all-cores", action="store_true",
@@ -84,6 +86,46 @@ def parse():
 # --------------------------------------------------------------------------------------------------------------------
 # CPU baseline (vq workload)
 # --------------------------------------------------------------------------------------------------------------------
+def _reference_root():
+    """the reference checkout, if this machine has one (MAS_REFERENCE_ROOT, else /root/reference): the GPU box has none"""
+    for r in (os.environ.get("MAS_REFERENCE_ROOT"), "/root/reference"):
+        if r and os.path.isfile(os.path.join(r, "models", "vqvae.py")):
+            return r
+    return None
+
+
+def _cpu_baseline_worker_reference(batch, threads, timed, ref_root):
+    """child process: the REFERENCE ITSELF (imported unmodified from `ref_root`, SURVEY 8(c)'s recipe: the one absent third-party
+    import, fast_pytorch_kmeans, is stubbed -- the k-means branch is not entered) on this host's cores: BASELINE.md section 3"""
+    import types
+    for p_ in [p_ for p_ in sys.path if os.path.isdir(os.path.join(p_ or ".", "models")) and os.path.abspath(p_ or ".") != os.path.abspath(ref_root)]:
+        sys.path.remove(p_)                         # `models` must resolve to the reference's package, not to ours
+    sys.path.insert(0, ref_root)
+    stub = types.ModuleType("fast_pytorch_kmeans")
+    stub.KMeans = object
+    sys.modules["fast_pytorch_kmeans"] = stub
+    from models import VQBASE
+    assert os.path.abspath(sys.modules["models"].__file__).startswith(os.path.abspath(ref_root))
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    model = VQBASE(**IMG_CFG).train()
+    with torch.no_grad():
+        model.quantize.embedding.weight.normal_(0.0, 1.0)
+    model.quantize.q_counter = model.quantize.q_re_end
+    x = torch.rand(batch, 3, 256, 256, generator=torch.Generator().manual_seed(0))
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        rec, q = model(x)
+        ((x - rec).abs().mean() + q).backward()
+
+    step()
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        step()
+        print("CPU_BASELINE_SECONDS", time.perf_counter() - t0, flush=True)
+
+
 def _cpu_baseline_worker(batch, threads, timed):
     """child process: prints the seconds of each timed CPU-oracle fwd+bwd step"""
     from oracle import vq_oracle as O
@@ -126,12 +168,12 @@ def _physical_cores():
         return None
 
 
-def _run_cpu_worker(batch, threads, timed, budget_s):
+def _run_cpu_worker(batch, threads, timed, budget_s, ref_root=None):
     import subprocess
     secs, note = [], ""
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(batch), str(threads), str(timed)],
-                           capture_output=True, text=True, timeout=budget_s)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(batch), str(threads), str(timed)]
+                           + ([ref_root] if ref_root else []), capture_output=True, text=True, timeout=budget_s)
         txt, err = r.stdout, r.stderr
     except subprocess.TimeoutExpired as e:
         txt = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
@@ -154,16 +196,25 @@ def cpu_baseline(batch, budget_s=150, all_cores=False):
     host = os.cpu_count() or 1
     threads = min(host, 32)
     timed = 3
-    out = {"value": None, "unit": "images/s", "cores": threads, "host_cpus": host, "host_physical_cores": _physical_cores(), "kind": "port",
-           "sample": f"oracle/vq_oracle.py fp32 fwd+bwd, B={batch} x 256x256, 1 warm-up + {timed} timed steps, {threads} threads of "
+    # the reference itself whenever this machine has a checkout of it (kind "reference"); the GPU box has none: the oracle then
+    # (kind "port": the same arithmetic restated, oracle/vq_oracle.py)
+    ref_root = _reference_root()
+    what = f"the reference's VQBASE imported from {ref_root}" if ref_root else "oracle/vq_oracle.py"
+    out = {"value": None, "unit": "images/s", "cores": threads, "host_cpus": host, "host_physical_cores": _physical_cores(),
+           "kind": "reference" if ref_root else "port",
+           "sample": f"{what}, fp32 fwd+bwd, B={batch} x 256x256, 1 warm-up + {timed} timed steps, {threads} threads of "
                      f"{host} host CPUs, torch CPU {torch.__version__}"}
-    secs, note = _run_cpu_worker(batch, threads, timed, budget_s)
+    secs, note = _run_cpu_worker(batch, threads, timed, budget_s, ref_root)
+    if ref_root and not secs:                   # the checkout is there but does not run here: fall back to the port and say so
+        out["kind"] = "port"
+        out["sample"] = out["sample"].replace(what, "oracle/vq_oracle.py") + f" (the reference at {ref_root} did not finish a step{note})"
+        secs, note = _run_cpu_worker(batch, threads, timed, budget_s)
     out["sample"] += note
     if secs:
         out["value"] = round(batch * len(secs) / sum(secs), 4)
         out["timed_steps"] = len(secs)
     if all_cores and host > threads:        # BASELINE.md section 3 as written: every host thread (slower than 32 on these hosts: round 1)
-        secs2, note2 = _run_cpu_worker(batch, host, 1, budget_s)
+        secs2, note2 = _run_cpu_worker(batch, host, 1, budget_s, ref_root if out["kind"] == "reference" else None)
         out["all_cores"] = {"cores": host, "value": round(batch * len(secs2) / sum(secs2), 4) if secs2 else None,
                             "sample": f"same, {host} threads, 1 warm-up + 1 timed step" + note2}
     else:
@@ -179,6 +230,8 @@ def _adam(args, params, **kw):
     if getattr(args, "optimizer", "mas") == "mas":
         from mas_hip.optim import Adam
         return Adam(params, **kw)
+    if args.optimizer == "torch-default":       # exactly what reference train.py:61 constructs: torch.optim.Adam(params, **cfg) -- the foreach path
+        return torch.optim.Adam(params, **kw)
     return torch.optim.Adam(params, fused=True, **kw)
 
 
@@ -428,7 +481,8 @@ def run_vq(args):
             "config": {"workload": "VQ-IMG 256x256, codebook 8192x256, conf/img_config.yaml model block (95.2 M params), "
                                    "fwd+bwd of L1+q_loss + Adam step", "per_gpu_batch": batch, "global_batch": batch * world,
                        "parallelism": _par(world, args, ddp) + (" + SyncBatchNorm" if ddp else ""),
-                       "optimizer": "mas_hip.optim.Adam (one launch; = torch.optim.Adam's update)" if args.optimizer == "mas" else "torch.optim.Adam(fused=True)"},
+                       "optimizer": {"mas": "mas_hip.optim.Adam (one launch; = torch.optim.Adam's update)", "torch": "torch.optim.Adam(fused=True)",
+                                     "torch-default": "torch.optim.Adam(params, lr, betas) as reference train.py:61 (foreach)"}[args.optimizer]},
             "final_loss": round(final_loss, 5),
             "replica_weight_checksum_spread": spread,
             "model_tflops_per_gpu": round(value / world * FWD_BWD_GFLOP_PER_IMG / 1e3, 1),
@@ -659,6 +713,9 @@ def main():
 
 if __name__ == "__main__":
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
-        _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 1)
+        if len(sys.argv) > 5:
+            _cpu_baseline_worker_reference(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
+        else:
+            _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 1)
     else:
         main()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAS_ABI_VERSION 5
+#define MAS_ABI_VERSION 6
 
 enum { MAS_OK = 0, MAS_EINVAL = -1, MAS_EUNSUPPORTED = -2, MAS_ELAUNCH = -3, MAS_EWORKSPACE = -4 };
 enum { MAS_F32 = 0, MAS_BF16 = 1 };
@@ -75,8 +75,14 @@ int    mas_pack_conv_weight(const float* w_oihw, void* packed, int Cout, int Cin
  * [Cin/64 chunks][tap][Cout_pad][128 B], 16-byte slots XOR-swizzled with (row>>1)&7.  MAS_WLAYOUT_K32 (bf16 only; the
  * wide 3x3 kernel, conv3x3_wide.hip): [Cin/32 chunks][tap][Cout_pad][64 B], slots XOR-swizzled with (row>>2)&3.
  * mas_conv_weight_layout(d) tells which image mas_conv_fwd prefers for a convolution; a K64 image is always accepted
- * (the call then takes the kernels that read it).  Same buffer size for both (mas_packed_weight_elems).            */
-enum { MAS_WLAYOUT_K64 = 0, MAS_WLAYOUT_K32 = 1 };
+ * (the call then takes the kernels that read it).  Same buffer size for both (mas_packed_weight_elems).
+ * MAS_WLAYOUT_UP2 (bf16, 3x3 only; conv_up2.hip): the sub-pixel form of `Upsample` + conv (reference models/modules.py:44-59) --
+ * output pixel (2i + a, 2j + b) of the convolution over the nearest-x2 image sees the 2x2 window x[i + a - 1 + r][j + b - 1 + s] with
+ * Wp[a][b][r][s] = sum of W[kh][kw] over kh in R(a, r), kw in R(b, s), R(0,0) = {0}, R(0,1) = {1,2}, R(1,0) = {0,1}, R(1,1) = {2}
+ * (summed in fp32, then rounded).  Image: [phase 2a+b][Cin/32 chunks][tap 2r+s][Cout_pad][64 B], rows and slots as K32;
+ * transpose = 1 (data-gradient operand): in/out swapped and tap (1-r, 1-s) stored at (r, s).  mas_packed_weight_elems_up2 elements. */
+enum { MAS_WLAYOUT_K64 = 0, MAS_WLAYOUT_K32 = 1, MAS_WLAYOUT_UP2 = 2 };
+size_t mas_packed_weight_elems_up2(int Cout, int Cin);
 int    mas_conv_weight_layout(const MasConvDesc* d);
 int    mas_pack_conv_weight_layout(const float* w_oihw, void* packed, int Cout, int Cin, int ks,
                                    int transpose, int dtype, int layout, void* stream);
@@ -135,24 +141,13 @@ size_t mas_gn_bwd_workspace(int N, int C);
 int    mas_gn_bwd(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G,
                   int act, const float* gamma, const float* mean_rstd, const float* scale_shift,
                   void* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, void* stream);
-/* Two implementations behind mas_gn_bwd, both callable directly (same arguments, same workspace, both bitwise reproducible run to
- * run; their sums are partitioned differently, so they agree with each other to fp32 rounding, not bit for bit):
- *   mas_gn_bwd_3pass  reduce / finalize / apply as three launches; x and da are read twice.  Every dtype and shape.
- *   mas_gn_bwd_1pass  bf16: ONE persistent launch, reduce -> finalize -> apply per image group with the groups pipelined through
- *                     in-launch counters; the apply phase re-reads x / da from the Infinity Cache, HBM sees them once.
- *                     MAS_EUNSUPPORTED when the tensor has no plan (mas_gn_bwd_plan) or the grid would not be co-resident.
- * mas_gn_bwd picks the one measured faster on MI355X: the three launches (profiles/r04_gn_coop_v1.txt); MAS_GN_BWD_ONE_LAUNCH=1
- * makes it try mas_gn_bwd_1pass first.                                                                                              */
+/* mas_gn_bwd takes the small-map kernel (bf16, h*w <= 512 pixels, see mas_gn_small_supported) where it applies and otherwise
+ * mas_gn_bwd_3pass: reduce / finalize / apply as three launches (x and da are read twice; every dtype and shape), also callable
+ * directly.  Same arguments, same workspace; bitwise reproducible run to run.  (Round 4's one-launch kernels lost to it on MI355X and
+ * are shelved: docs/history/experiments/r4_gn_queue.patch, profiles/r04_gn_queue_v2.txt.)                                            */
 int    mas_gn_bwd_3pass(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G,
                         int act, const float* gamma, const float* mean_rstd, const float* scale_shift,
                         void* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, void* stream);
-int    mas_gn_bwd_1pass(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G,
-                        int act, const float* gamma, const float* mean_rstd, const float* scale_shift,
-                        void* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, void* stream);
-/* How mas_gn_bwd_1pass would run a bf16 tensor on a device with num_cus compute units (host arithmetic only, no device call):
- * returns 1 and fills plan[10] = {threads per work-group, work-groups, row ranges per image, images per group, groups, channel slices per image,
- * channels per slice, pipeline depth, ring slots, task-owner multiplier}; 0 when the tensor has no one-launch plan.                  */
-int    mas_gn_bwd_plan(int N, int HW, int C, int G, int num_cus, int* plan);
 
 /* ---- materialised GroupNorm(+SiLU) output: a [N,HW,C] = act(x * scale + shift), scale_shift [N][C][2] from mas_gn_stats, act
  * MAS_ACT_AFFINE or MAS_ACT_AFFINE_SILU, rounded to `dtype` exactly as the fused loaders of mas_conv_fwd / mas_conv_wgrad round it
@@ -204,19 +199,29 @@ int mas_conv_wgrad(const MasConvDesc* d, const void* x, const float* scale_shift
  * dbias [Cout]; acc is zeroed again while it is read, so ONE scratch per stream serves every convolution of a step without fill
  * launches (the caller still owns it).                                                                                              */
 int mas_wgrad_commit(float* acc, float* dw_oihw, float* dbias, int Cout, int Cin, int ks, void* stream);
-/* Deterministic split-K (ABI v3): for the convolutions that carry the FLOPs (mas_conv_wgrad_splits(d) = nsplit > 0: bf16, stride 1, no
- * prologue; 3x3 with Cin % 64 == 0, Cout % 128 == 0, or 1x1 with Cin % 128 == 0, Cout % 128 == 0: part is then [nsplit][Cout][ks][ks][Cin]) mas_conv_wgrad_partial writes the nsplit partial sums -- part [nsplit][Cout][3][3][Cin] fp32,
- * part_bias [nsplit][Cout] or NULL, every element exactly once, plain stores, no initialisation required -- and mas_wgrad_reduce adds
- * the slabs in a fixed order into dw_oihw [Cout][Cin][ks][ks] / dbias [Cout]: no atomics, bitwise reproducible run to run.          */
 /* Downsample's data gradient without the zero-stuffed tensor (reference models/modules.py:62-81 under autograd): d describes the
  * FORWARD convolution (3x3, stride 2, pads 0); w_packed_t = mas_pack_conv_weight_layout(transpose = 1, MAS_WLAYOUT_K64).           */
 int mas_conv_s2_dgrad_supported(const MasConvDesc* d);
 int mas_conv_s2_dgrad(const MasConvDesc* d, const void* dy, const void* w_packed_t, void* dx, void* stream);
+/* Deterministic split-K (ABI v3): for the convolutions that carry the FLOPs (mas_conv_wgrad_splits(d) = nsplit > 0: bf16, stride 1, no
+ * prologue; 3x3 with Cin % 64 == 0, Cout % 128 == 0, or 1x1 with Cin % 128 == 0, Cout % 128 == 0: part is then [nsplit][Cout][ks][ks][Cin]) mas_conv_wgrad_partial writes the nsplit partial sums -- part [nsplit][Cout][3][3][Cin] fp32,
+ * part_bias [nsplit][Cout] or NULL, every element exactly once, plain stores, no initialisation required -- and mas_wgrad_reduce adds
+ * the slabs in a fixed order into dw_oihw [Cout][Cin][ks][ks] / dbias [Cout]: no atomics, bitwise reproducible run to run.          */
 int mas_conv_wgrad_splits(const MasConvDesc* d);
 int mas_conv_wgrad_partial(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy,
                            float* part, float* part_bias, void* stream);
 int mas_wgrad_reduce(const float* part, const float* part_bias, int nsplit, float* dw_oihw, float* dbias, int Cout, int Cin, int ks,
                      void* stream);
+
+/* `Upsample` + convolution in its sub-pixel form (conv_up2.hip; MAS_WLAYOUT_UP2 above): 2.25x fewer FLOPs than the 3x3 convolution over
+ * the x2 image.  d describes the FORWARD convolution as for mas_conv_fwd (upsample = 1, H x W the input map, Ho x Wo = 2H x 2W, 3x3,
+ * stride 1, pads 1, bf16, no prologue).  Forward: mas_conv_up2_supported(d) != 0 -> pack the weight with MAS_WLAYOUT_UP2, set
+ * d->w_layout to it and call mas_conv_fwd / mas_conv_fwd_stats (no residual).  Data gradient with respect to the LOW-resolution input:
+ * dx [N,H,W,Cin] from dy [N,Ho,Wo,Cout] and w_packed_t = the MAS_WLAYOUT_UP2 image with transpose = 1 -- replaces the stride-1
+ * data-gradient convolution at the high resolution plus the x2 sum-pooling pass.                                                   */
+int mas_conv_up2_supported(const MasConvDesc* d);
+int mas_conv_up2_dgrad_supported(const MasConvDesc* d);
+int mas_conv_up2_dgrad(const MasConvDesc* d, const void* dy, const void* w_packed_t, void* dx, void* stream);
 
 /* ---- vector quantiser  (replaces Codebook.forward's distance / argmin / gather / loss,
  * modules.py:501-509; never materialises d[M,K]).

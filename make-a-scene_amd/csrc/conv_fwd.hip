@@ -609,12 +609,20 @@ int mas_conv3x3_wide_stat_rows(const MasConvDesc* d);
 int mas_conv1x1_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s);
 int mas_conv_thin_fwd_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s);
 int mas_conv_s2_fwd_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s);
+bool mas_conv_up2_fwd_eligible(const MasConvDesc* d);                        // conv_up2.hip
+int mas_conv_up2_stat_rows(const MasConvDesc* d);
+int mas_conv_up2_fwd_launch(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, void* y, float* stats, hipStream_t s);
 
 // Can mas_conv_fwd_stats fill the consumer's GroupNorm statistics for this convolution, and with how many table rows per image?
 extern "C" int mas_conv_stat_rows(const MasConvDesc* d) {
+    if (d && d->w_layout == MAS_WLAYOUT_UP2) return mas_conv_up2_fwd_eligible(d) ? mas_conv_up2_stat_rows(d) : 0;
     if (!d || d->w_layout != MAS_WLAYOUT_K32 || !mas_conv3x3_wide_eligible(d)) return 0;
     return mas_conv3x3_wide_stat_rows(d);
 }
+
+// Upsample + 3x3 in its sub-pixel form (conv_up2.hip): a separate question from mas_conv_weight_layout, because the caller must also
+// know that the call carries no residual and no prologue
+extern "C" int mas_conv_up2_supported(const MasConvDesc* d) { return (d && mas_conv_up2_fwd_eligible(d)) ? 1 : 0; }
 
 extern "C" int mas_conv_weight_layout(const MasConvDesc* d) {
     if (!d) return MAS_WLAYOUT_K64;
@@ -647,6 +655,11 @@ static int conv_fwd_impl(const MasConvDesc* d, const void* x, const float* scale
         MAS_FAIL(MAS_EINVAL, "conv_fwd: non-positive dimension");
     if (d->upsample && d->stride != 1) MAS_FAIL(MAS_EUNSUPPORTED, "conv_fwd: upsample fold needs stride 1");
     if ((long long)d->H * d->W * d->Cin > 0x7fffffffLL) MAS_FAIL(MAS_EUNSUPPORTED, "conv_fwd: one image exceeds 2^31 elements");
+    if (d->w_layout == MAS_WLAYOUT_UP2) {   // Upsample + conv, sub-pixel form: the caller asked mas_conv_up2_supported and packed for it
+        if (!mas_conv_up2_fwd_eligible(d)) MAS_FAIL(MAS_EINVAL, "conv_fwd: w_layout UP2 but this convolution does not take the sub-pixel kernel");
+        if (residual || d->act != MAS_ACT_NONE) MAS_FAIL(MAS_EUNSUPPORTED, "conv_fwd: the sub-pixel kernel takes no residual and no prologue");
+        return mas_conv_up2_fwd_launch(d, x, w_packed, bias, y, stats, reinterpret_cast<hipStream_t>(stream));
+    }
     if (d->w_layout == MAS_WLAYOUT_K32) {   // the caller packed for the wide 3x3 kernel (mas_conv_weight_layout said so)
         if (!mas_conv3x3_wide_eligible(d)) MAS_FAIL(MAS_EINVAL, "conv_fwd: w_layout K32 but this convolution does not take the wide kernel");
         return mas_conv3x3_wide_launch(d, x, scale_shift, w_packed, bias, residual, y, stats, reinterpret_cast<hipStream_t>(stream));

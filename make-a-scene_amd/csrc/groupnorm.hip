@@ -789,292 +789,6 @@ inline bool gn_small_bwd_ok(int dtype, int HW, int C, int G) { return HW <= 512 
 inline int gn_small_units(int HW, int cb) { const int t = gn_small_threads(HW); return (HW * (cb / 8) + t - 1) / t; }
 inline size_t gn_small_lds(int HW, int cb) { return ((size_t)gn_small_threads(HW) / (cb / 8) * 2 * cb + 2 * cb + 4 * cb) * sizeof(float); }
 
-// ---------------------------------------------------------------------------------------
-// GroupNorm(+SiLU) backward as ONE persistent launch (bf16): reduce -> finalize -> apply per IMAGE GROUP, the groups pipelined through
-// the launch, so that the apply phase re-reads x / da while the group still sits in the 256 MiB Infinity Cache instead of from HBM: HBM
-// sees x and da once.  The three-launch scheme above reads both twice (2.7 GB instead of 1.6 GB at 128 ch @256^2 x 32), and walking
-// the batch in groups with separate launches lost to the launch ramps (profiles/r03_gn_streaming.txt section 4).
-//
-// Work is a QUEUE of tasks handed out by one ticket counter, in an order that makes every wait a wait for SMALLER tickets:
-//     round t :  F(t-1) finalize tasks | S(t) reduce tasks | P(t-L) apply tasks            (L = lead, in groups)
-//     S(t)    : partial sums of one (image, row range) pair of group t -> one table row (write-through stores), then cntA[t] += 1
-//     F(t)    : one (image, channel slice) of group t: waits for cntA[t] == pairs, folds the rows (fp64, row order) into the coefficient
-//               table, then cntB[t] += 1
-//     P(t)    : waits for cntB[t] == finalize tasks, then dx = c1 du + k2 x + k3 (+ dres) for one pair of group t
-// A task that waits has a smaller ticket to wait for, and the smallest unfinished ticket never waits: the schedule cannot deadlock
-// whatever the number of resident work-groups, their placement or their timing (one work-group alone would drain the queue) -- unlike
-// round 4's first version, a static stage program that needed every work-group co-resident and ran the whole chip in lock-step
-// through its hand-offs (0.61 ms against the three launches' 0.48 at 128 ch @256^2, profiles/r04_gn_coop_v1.txt).  Work-groups drift
-// apart, so one's hand-off latency (write-through drain, counter round trip, coefficient fetch: a few us) overlaps the others'
-// streaming.  The lead L and the task size bound what lies between a pair's S and its P: ~4 images (134 MB at the benched shape).
-// Visibility (MI355X guide, hand-off recipe R1): producers store write-through (sc1), drain (s_waitcnt vmcnt(0)), barrier, ONE lane
-// adds to the counter (relaxed, agent scope); consumers poll the counter from one lane (relaxed agent loads + s_sleep, bounded) and
-// read what other work-groups wrote with agent-scope (sc1) loads -- no fences.  Counters are zeroed by a memset node in front of every
-// launch.  All sums keep a fixed order (thread registers -> LDS slots in row-group order -> table rows in row order, fp64): bitwise
-// reproducible run to run.  A spin that gives up (~2 s) poisons dgamma / dbeta with NaN instead of hanging the GPU.
-typedef __attribute__((address_space(1))) unsigned int gu32;
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-#define GN_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-
-struct GnQueueParams {
-    const bf16_t* x; const bf16_t* da; const bf16_t* dres; bf16_t* dx;
-    const float* mean_rstd; const float* ss; const float* gamma;
-    unsigned long long* rows;   // ring of [R][Gi * nsplit][C] {S1, S2} pairs (8 bytes each)
-    float* coef;                // [N][C][4] {c1, k2, k3, 0}
-    float* nsum;                // [N][C][2] {S2, S1} -> dgamma, dbeta
-    unsigned* cnt;              // head, status, cntA[NG], cntB[NG]
-    float* dgamma; float* dbeta;
-    int N, HW, C, G, nsplit, Gi, NG, NS, CS, L, R, rev;
-};
-
-__device__ __forceinline__ void gn_st_pair(unsigned long long* p, float a, float b) {   // one 8-byte write-through store
-    const unsigned long long v = ((unsigned long long)__float_as_uint(b) << 32) | (unsigned long long)__float_as_uint(a);
-    __hip_atomic_store((gu64*)p, v, GN_RLX);
-}
-__device__ __forceinline__ void gn_ld_pair(const unsigned long long* p, float& a, float& b) {   // agent-scope (L1-bypassing) load
-    const unsigned long long v = __hip_atomic_load((gu64*)p, GN_RLX);
-    a = __uint_as_float((unsigned)v); b = __uint_as_float((unsigned)(v >> 32));
-}
-// one lane: poll `*c >= target`; false when the wait was given up (status word set)
-__device__ __forceinline__ bool gn_wait(unsigned* c, unsigned target, unsigned* status) {
-    for (unsigned spins = 0;; ++spins) {
-        if (__hip_atomic_load((gu32*)c, GN_RLX) >= target) return true;
-        if ((spins & 255u) == 255u && __hip_atomic_load((gu32*)status, GN_RLX) != 0u) return false;
-        if (spins > (1u << 22)) { __hip_atomic_store((gu32*)status, 1u, GN_RLX); return false; }
-        __builtin_amdgcn_s_sleep(16);
-    }
-}
-
-template <bool SILU, bool RES>
-__global__ __launch_bounds__(512, 4) void gn_bwd_queue_kernel(GnQueueParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
-    unsigned* bc = reinterpret_cast<unsigned*>(gsm);                // [4] broadcast slots of lane 0
-    float* lds = reinterpret_cast<float*>(gsm + 16);
-    const int tid = threadIdx.x, T = blockDim.x;
-    const int C = p.C, HW = p.HW, upp = C / 8, cpg = C / p.G;
-    const int cu = tid % upp, rg = tid / upp, rstep = T / upp;
-    unsigned* head = p.cnt;
-    unsigned* status = p.cnt + 1;
-    unsigned* cntA = p.cnt + 2;
-    unsigned* cntB = cntA + p.NG;
-    const int rows_per = (HW + p.nsplit - 1) / p.nsplit;
-    const int rpg = p.Gi * p.nsplit;                                // pairs (= table rows) per group
-    const int nF = p.Gi * p.NS, nS = rpg, tpr = nF + 2 * nS;        // tickets per round: F | S | P
-    const unsigned n_main = (unsigned)(p.NG + p.L) * (unsigned)tpr;
-    const unsigned n_tail = (unsigned)((C + T - 1) / T);            // dgamma / dbeta tasks
-    auto group_of = [&](int t) { return p.rev ? p.NG - 1 - t : t; };
-    auto images_of = [&](int t) { const int n0 = group_of(t) * p.Gi; return min(p.Gi, p.N - n0); };
-    // lane 0 polls, everybody learns the outcome
-    auto wait_for = [&](unsigned* c, unsigned target) {
-        if (tid == 0) bc[1] = gn_wait(c, target, status) ? 1u : 0u;
-        __syncthreads();
-        const bool ok = bc[1] != 0u;
-        __syncthreads();
-        return ok;
-    };
-    auto arrive = [&](unsigned* c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add((gu32*)c, 1u, GN_RLX);
-    };
-    bool alive = true;                                             // uniform: false once a wait was given up
-
-    for (;;) {
-        if (tid == 0) bc[0] = __hip_atomic_fetch_add((gu32*)head, 1u, GN_RLX);
-        __syncthreads();
-        const unsigned tk = bc[0];
-        __syncthreads();
-        if (tk >= n_main + n_tail) break;
-        if (tk >= n_main) {
-            // ---------------- dgamma / dbeta: sums over the batch of nsum, once every group is finalized ----------------
-            for (int t = 0; alive && t < p.NG; ++t) alive = wait_for(cntB + t, (unsigned)(images_of(t) * p.NS));
-            const int c = (int)(tk - n_main) * T + tid;
-            if (c < C && (p.dgamma || p.dbeta)) {
-                double a = 0.0, b = 0.0;
-                for (int m = 0; m < p.N; ++m) {
-                    float sa, sb;
-                    gn_ld_pair(reinterpret_cast<const unsigned long long*>(p.nsum + ((size_t)m * C + c) * 2), sa, sb);
-                    a += (double)sa; b += (double)sb;
-                }
-                if (!alive || __hip_atomic_load((gu32*)status, GN_RLX) != 0u) { a = __builtin_nan(""); b = a; }   // make a give-up visible
-                if (p.dgamma) p.dgamma[c] = (float)a;
-                if (p.dbeta) p.dbeta[c] = (float)b;
-            }
-            continue;
-        }
-        const int round = (int)(tk / (unsigned)tpr), idx = (int)(tk % (unsigned)tpr);
-        if (idx < nF) {
-            // ---------------- F(round - 1): one (image, channel slice) ----------------
-            const int t = round - 1;
-            if (t < 0 || t >= p.NG) continue;
-            const int cn = images_of(t), n0 = group_of(t) * p.Gi;
-            const int i = idx / p.NS, c0 = (idx % p.NS) * p.CS;
-            if (i >= cn) continue;
-            alive = alive && wait_for(cntA + t, (unsigned)(cn * p.nsplit));
-            if (!alive) continue;
-            const int n = n0 + i, CS = p.CS, RL = T / CS;          // thread = (row lane, channel of the slice)
-            const unsigned long long* ring = p.rows + (size_t)(t % p.R) * rpg * C;
-            double* dsl = reinterpret_cast<double*>(lds);          // [RL][CS][2], then cs [CS][2] behind it
-            double* cs = dsl + (size_t)RL * CS * 2;
-            const int cl = tid % CS, rl = tid / CS;
-            if (rl < RL) {
-                double a = 0.0, b = 0.0;
-                const unsigned long long* col = ring + (size_t)i * p.nsplit * C + c0 + cl;
-                int r = rl;
-                for (; r + 7 * RL < p.nsplit; r += 8 * RL) {      // eight rows in flight, added in row order
-                    float va[8], vb[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) gn_ld_pair(col + (size_t)(r + k * RL) * C, va[k], vb[k]);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) { a += (double)va[k]; b += (double)vb[k]; }
-                }
-                for (; r < p.nsplit; r += RL) { float a0, b0; gn_ld_pair(col + (size_t)r * C, a0, b0); a += (double)a0; b += (double)b0; }
-                dsl[((size_t)rl * CS + cl) * 2 + 0] = a; dsl[((size_t)rl * CS + cl) * 2 + 1] = b;
-            }
-            __syncthreads();
-            if (tid < CS) {
-                double sa = 0.0, sb = 0.0;
-                for (int q = 0; q < RL; ++q) { sa += dsl[((size_t)q * CS + tid) * 2 + 0]; sb += dsl[((size_t)q * CS + tid) * 2 + 1]; }
-                cs[2 * tid] = sa; cs[2 * tid + 1] = sb;
-                gn_st_pair(reinterpret_cast<unsigned long long*>(p.nsum + ((size_t)n * C + c0 + tid) * 2), (float)sb, (float)sa);   // {-> dgamma, -> dbeta}
-            }
-            __syncthreads();
-            if (tid < CS) {
-                const int c = c0 + tid, gq = c / cpg, j0 = gq * cpg - c0;      // the group's channels lie inside the slice (CS % cpg == 0)
-                double A = 0.0, B = 0.0;
-                for (int j = 0; j < cpg; ++j) {
-                    const double ga = p.gamma ? (double)p.gamma[gq * cpg + j] : 1.0;
-                    A += ga * cs[2 * (j0 + j)]; B += ga * cs[2 * (j0 + j) + 1];
-                }
-                const double mean = p.mean_rstd[((size_t)n * p.G + gq) * 2 + 0], rstd = p.mean_rstd[((size_t)n * p.G + gq) * 2 + 1];
-                const double m = (double)cpg * (double)HW;
-                unsigned long long* o = reinterpret_cast<unsigned long long*>(p.coef + ((size_t)n * C + c) * 4);
-                gn_st_pair(o, (float)(rstd * (p.gamma ? (double)p.gamma[c] : 1.0)), (float)(-rstd * rstd * B / m));
-                gn_st_pair(o + 1, (float)(rstd * (mean * rstd * B - A) / m), 0.0f);
-            }
-            arrive(cntB + t);
-            __syncthreads();                                       // (the LDS block is reused by the next task)
-        } else if (idx < nF + nS) {
-            // ---------------- S(round): partial sums of one pair ----------------
-            const int t = round;
-            if (t >= p.NG) continue;
-            const int cn = images_of(t), n0 = group_of(t) * p.Gi, pr = idx - nF;
-            if (pr >= cn * p.nsplit) continue;
-            const int i = pr / p.nsplit, sp = pr % p.nsplit, n = n0 + i;
-            const int r0 = min(HW, sp * rows_per), r1 = min(HW, r0 + rows_per);
-            const long long total = (long long)(r1 - r0) * upp;
-            f32x2 sc[4], sh[4], xr[4], xb[4], s1[4], s2[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int c = cu * 8 + 2 * q + h;
-                    sc[q][h] = p.ss[((size_t)n * C + c) * 2 + 0]; sh[q][h] = p.ss[((size_t)n * C + c) * 2 + 1];
-                    const float mu = p.mean_rstd[((size_t)n * p.G + c / cpg) * 2 + 0], rs = p.mean_rstd[((size_t)n * p.G + c / cpg) * 2 + 1];
-                    xr[q][h] = rs; xb[q][h] = -mu * rs;
-                    s1[q][h] = 0.0f; s2[q][h] = 0.0f;
-                }
-            auto acc = [&](const u32x4& rx, const u32x4& rd) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x2 xe = bf16pair_f32(rx[q]);
-                    f32x2 du = bf16pair_f32(rd[q]);
-                    if constexpr (SILU) du = du * dsilu2_f(xe * sc[q] + sh[q]);
-                    s1[q] += du; s2[q] += du * (xe * xr[q] + xb[q]);
-                }
-            };
-            const bf16_t* xb_ = p.x + ((size_t)n * HW + r0) * C;
-            const bf16_t* db_ = p.da + ((size_t)n * HW + r0) * C;
-            long long u = tid;
-            for (; u + T < total; u += 2LL * T) {                  // two units of each tensor in flight per thread
-                const size_t o0 = (size_t)u * 8, o1 = o0 + (size_t)T * 8;
-                const u32x4 x0 = GN_LD(xb_ + o0), x1 = GN_LD(xb_ + o1);
-                const u32x4 d0 = GN_LD(db_ + o0), d1 = GN_LD(db_ + o1);
-                acc(x0, d0); acc(x1, d1);
-            }
-            for (; u < total; u += T) {
-                const u32x4 x0 = GN_LD(xb_ + (size_t)u * 8), d0 = GN_LD(db_ + (size_t)u * 8);
-                acc(x0, d0);
-            }
-            // fixed-order combine of the row groups: slots [rstep][C][2]
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    lds[((size_t)rg * C + cu * 8 + 2 * q + h) * 2 + 0] = s1[q][h];
-                    lds[((size_t)rg * C + cu * 8 + 2 * q + h) * 2 + 1] = s2[q][h];
-                }
-            // the ring slot of group t was last used by group t - R: its finalize tasks must have read it (they have smaller tickets)
-            if (t >= p.R) alive = alive && wait_for(cntB + (t - p.R), (unsigned)(images_of(t - p.R) * p.NS));
-            else __syncthreads();
-            if (alive) {
-                unsigned long long* row = p.rows + ((size_t)(t % p.R) * rpg + (size_t)i * p.nsplit + sp) * C;
-                for (int c = tid; c < C; c += T) {
-                    float a = 0.0f, b = 0.0f;
-                    for (int k = 0; k < rstep; ++k) { a += lds[((size_t)k * C + c) * 2 + 0]; b += lds[((size_t)k * C + c) * 2 + 1]; }
-                    gn_st_pair(row + c, a, b);
-                }
-            }
-            arrive(cntA + t);                                      // (also when given up: nobody else hangs on this pair)
-            __syncthreads();
-        } else {
-            // ---------------- P(round - L): apply one pair ----------------
-            const int t = round - p.L;
-            if (t < 0 || t >= p.NG) continue;
-            const int cn = images_of(t), n0 = group_of(t) * p.Gi, pr = idx - nF - nS;
-            if (pr >= cn * p.nsplit) continue;
-            alive = alive && wait_for(cntB + t, (unsigned)(cn * p.NS));
-            if (!alive) continue;
-            const int i = pr / p.nsplit, sp = pr % p.nsplit, n = n0 + i;
-            const int r0 = min(HW, sp * rows_per), r1 = min(HW, r0 + rows_per);
-            const long long total = (long long)(r1 - r0) * upp;
-            f32x2 sc[4], sh[4], k0[4], k1[4], k2[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int c = cu * 8 + 2 * q + h;
-                    sc[q][h] = p.ss[((size_t)n * C + c) * 2]; sh[q][h] = p.ss[((size_t)n * C + c) * 2 + 1];
-                    const unsigned long long* o = reinterpret_cast<const unsigned long long*>(p.coef + ((size_t)n * C + c) * 4);
-                    float u0, u1, u2, u3;
-                    gn_ld_pair(o, u0, u1); gn_ld_pair(o + 1, u2, u3);
-                    k0[q][h] = u0; k1[q][h] = u1; k2[q][h] = u2;
-                }
-            const size_t base = ((size_t)n * HW + r0) * C;
-            auto body = [&](const u32x4& rx, const u32x4& rd, const u32x4& rr, size_t off) {
-                u32x4 ov;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x2 xe = bf16pair_f32(rx[q]);
-                    f32x2 du = bf16pair_f32(rd[q]);
-                    if constexpr (SILU) du = du * dsilu2_f(xe * sc[q] + sh[q]);
-                    f32x2 v = k0[q] * du + (k1[q] * xe + k2[q]);
-                    if constexpr (RES) v = v + bf16pair_f32(rr[q]);
-                    ov[q] = f32pair_bf16(v);
-                }
-                GN_ST(p.dx + off, ov);
-            };
-            long long u = tid;
-            for (; u + T < total; u += 2LL * T) {
-                const size_t o0 = base + (size_t)u * 8, o1 = o0 + (size_t)T * 8;
-                const u32x4 rx0 = GN_LD(p.x + o0), rx1 = GN_LD(p.x + o1);
-                const u32x4 rd0 = GN_LD(p.da + o0), rd1 = GN_LD(p.da + o1);
-                u32x4 rr0 = {0u, 0u, 0u, 0u}, rr1 = rr0;
-                if constexpr (RES) { rr0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.dres + o0));
-                                     rr1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.dres + o1)); }
-                body(rx0, rd0, rr0, o0); body(rx1, rd1, rr1, o1);
-            }
-            for (; u < total; u += T) {
-                const size_t off = base + (size_t)u * 8;
-                const u32x4 rx = GN_LD(p.x + off), rd = GN_LD(p.da + off);
-                u32x4 rr = {0u, 0u, 0u, 0u};
-                if constexpr (RES) rr = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.dres + off));
-                body(rx, rd, rr, off);
-            }
-        }
-    }
-}
-
 // Pass ordering against the Infinity Cache (256 MiB, memory side): the tensors of the 256x256 / 128x128 levels are 134-537 MB, so a
 // pass that re-walks a tensor in the SAME direction as the pass before it finds everything it needs already evicted, while the
 // opposite direction starts on the most recently touched ~quarter.  Convolutions and the backward apply pass walk images front
@@ -1199,73 +913,9 @@ extern "C" int mas_gn_stats_act(const void* x, void* a, int dtype, int N, int HW
     return MAS_OK;
 }
 
-// ---- host side of the one-launch backward (gn_bwd_queue_kernel) ----
-namespace {
-constexpr int Q_MAX_LEAD = 4;                                        // ring of L + 2 group slots
-constexpr int Q_MAX_PAIRS = 1024;                                    // table rows per group (bounds the workspace)
-
-struct GnQueuePlan { int T, W, nsplit, Gi, NG, NS, CS, L, R; size_t lds; };
-
-// false: this tensor has no one-launch plan (mas_gn_bwd_1pass refuses it)
-bool gn_queue_plan(int N, int HW, int C, int G, int ncu, GnQueuePlan* pl) {
-    static const int threads = mas_env_int("MAS_GN_Q_THREADS", 512);
-    static const int per_cu_env = mas_env_int("MAS_GN_Q_WGS_PER_CU", 2);
-    static const int lead = mas_env_int("MAS_GN_Q_LEAD", 2);
-    static const int units_per_thread = mas_env_int("MAS_GN_Q_UNITS", 4);
-    if (C % 8 || C % G) return false;
-    const int upp = C / 8, cpg = C / G;
-    const int T = threads == 256 ? 256 : 512;
-    if (T % upp || C > 8 * T) return false;
-    const int per_cu = per_cu_env < 1 ? 1 : (per_cu_env * T > 2048 ? 2048 / T : per_cu_env);
-    const int upt = units_per_thread < 1 ? 1 : units_per_thread;
-    pl->T = T;
-    // a pair = the rows one work-group reduces / applies as one task: `upt` 16-byte units of each tensor per thread
-    const int px_min = (T * upt) / upp > 0 ? (T * upt) / upp : 1;
-    int nsplit = HW / px_min;
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > Q_MAX_PAIRS / 2) nsplit = Q_MAX_PAIRS / 2;
-    // a group = enough images for ~one task per work-group and round (the lead L is counted in groups)
-    int W = per_cu * ncu;
-    const long long pairs_total = (long long)N * nsplit;
-    if (pairs_total < W) W = (int)pairs_total;
-    const int target = W < Q_MAX_PAIRS / 2 ? W : Q_MAX_PAIRS / 2;
-    int Gi = (target + nsplit - 1) / nsplit;
-    if (Gi < 1) Gi = 1;
-    if (Gi > N) Gi = N;
-    pl->W = W; pl->nsplit = nsplit; pl->Gi = Gi; pl->NG = (N + Gi - 1) / Gi;
-    int L = lead < 1 ? 1 : lead;
-    if (L > Q_MAX_LEAD) L = Q_MAX_LEAD;
-    pl->L = L; pl->R = L + 2;
-    // finalize tasks: (image, slice of CS channels); a task folds nsplit rows x CS x 8 bytes -- aim at <= 64 KiB, whole groups only
-    int CS = C;
-    const int tgt = 65536 / (nsplit * 8) > 0 ? 65536 / (nsplit * 8) : 1;
-    while ((CS > tgt || CS > T) && CS % 2 == 0 && (CS / 2) % cpg == 0 && C % (CS / 2) == 0) CS /= 2;
-    if (CS > T) return false;
-    pl->CS = CS; pl->NS = C / CS;
-    const size_t lds_s = (size_t)64 * T, lds_f = (size_t)16 * T + (size_t)16 * CS;
-    pl->lds = 16 + (lds_s > lds_f ? lds_s : lds_f);
-    return true;
-}
-
-size_t gn_queue_ws_bytes(int N, int C) {                             // upper bound over every plan for (N, C)
-    return (size_t)(Q_MAX_LEAD + 2) * Q_MAX_PAIRS * C * 8 + (size_t)N * C * 16 + (size_t)N * C * 8 + ((size_t)2 * N + 8) * 4 + 64;
-}
-
-template <bool SILU, bool RES>
-int gn_queue_launch(const GnQueuePlan& pl, GnQueueParams& prm, hipStream_t s) {
-    if (hipMemsetAsync(prm.cnt, 0, ((size_t)2 * pl.NG + 2) * sizeof(unsigned), s) != hipSuccess) { (void)hipGetLastError(); return 1; }
-    hipLaunchKernelGGL((gn_bwd_queue_kernel<SILU, RES>), dim3(pl.W), dim3(pl.T), pl.lds, s, prm);
-    return 0;
-}
-
-}  // namespace
-
-// workspace: the larger of  partial [N][MAX_SPLIT][C][2] + coef [N][C][4] + nsum [N][C][2]  (three launches)  and the one-launch
-// kernel's row ring + coef + nsum + counters
+// workspace: partial [N][MAX_SPLIT][C][2] + coef [N][C][4] + nsum [N][C][2]
 extern "C" size_t mas_gn_bwd_workspace(int N, int C) {
-    const size_t legacy = ((size_t)N * MAX_SPLIT * C * 2 + (size_t)N * C * 4 + (size_t)N * C * 2) * sizeof(float);
-    const size_t queue = gn_queue_ws_bytes(N, C);
-    return legacy > queue ? legacy : queue;
+    return ((size_t)N * MAX_SPLIT * C * 2 + (size_t)N * C * 4 + (size_t)N * C * 2) * sizeof(float);
 }
 
 static int gn_bwd_check(const void* x, const void* da, const void* dx, int dtype, int N, int HW, int C, int G, int act, const float* mean_rstd,
@@ -1279,44 +929,9 @@ static int gn_bwd_check(const void* x, const void* da, const void* dx, int dtype
     return MAS_OK;
 }
 
-// One persistent launch (gn_bwd_queue_kernel).  MAS_EUNSUPPORTED when the tensor has no one-launch plan (fp32, channel counts whose
-// 16-byte units do not divide the work-group).
-extern "C" int mas_gn_bwd_1pass(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G, int act,
-                                const float* gamma, const float* mean_rstd, const float* scale_shift, void* dx, float* dgamma,
-                                float* dbeta, void* workspace, size_t ws_bytes, void* stream) {
-    MAS_ENTER();
-    const int rc0 = gn_bwd_check(x, da, dx, dtype, N, HW, C, G, act, mean_rstd, scale_shift, workspace, ws_bytes);
-    if (rc0 != MAS_OK) return rc0;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const bool silu = act == MAS_ACT_AFFINE_SILU;
-    GnQueuePlan pl;
-    if (dtype != MAS_BF16 || !gn_queue_plan(N, HW, C, G, mas_num_cus(), &pl)) MAS_FAIL(MAS_EUNSUPPORTED, "gn_bwd_1pass: no one-launch plan for this tensor");
-    GnQueueParams prm;
-    prm.x = (const bf16_t*)x; prm.da = (const bf16_t*)da; prm.dres = (const bf16_t*)dres; prm.dx = (bf16_t*)dx;
-    prm.mean_rstd = mean_rstd; prm.ss = scale_shift; prm.gamma = gamma;
-    unsigned char* wsp = reinterpret_cast<unsigned char*>(workspace);
-    prm.rows = reinterpret_cast<unsigned long long*>(wsp);
-    wsp += (size_t)pl.R * pl.Gi * pl.nsplit * C * 8;
-    prm.coef = reinterpret_cast<float*>(wsp); wsp += (size_t)N * C * 16;
-    prm.nsum = reinterpret_cast<float*>(wsp); wsp += (size_t)N * C * 8;
-    prm.cnt = reinterpret_cast<unsigned*>(wsp);
-    prm.dgamma = dgamma; prm.dbeta = dbeta;
-    prm.N = N; prm.HW = HW; prm.C = C; prm.G = G; prm.nsplit = pl.nsplit; prm.Gi = pl.Gi; prm.NG = pl.NG; prm.NS = pl.NS; prm.CS = pl.CS;
-    prm.L = pl.L; prm.R = pl.R; prm.rev = gn_reverse();
-    int rc;
-    if (silu && dres) rc = gn_queue_launch<true, true>(pl, prm, s);
-    else if (silu) rc = gn_queue_launch<true, false>(pl, prm, s);
-    else if (dres) rc = gn_queue_launch<false, true>(pl, prm, s);
-    else rc = gn_queue_launch<false, false>(pl, prm, s);
-    if (rc != 0) MAS_FAIL(MAS_ELAUNCH, "gn_bwd_1pass: cannot zero the counters");
-    MAS_CHECK_LAUNCH("gn_bwd_queue");
-    return MAS_OK;
-}
-
-// The entry point the autograd nodes call: whichever path is faster for the tensor.  Measured on MI355X (profiles/r04_gn_coop_v1.txt):
-// the one-launch kernel reads x / da from HBM once but its per-group hand-offs cost more than the second read saves -- 0.61 vs 0.48 ms
-// at 128 ch @256^2 x 32, slower at every shape of VQ-IMG -- so the three-launch path is the default and MAS_GN_BWD_ONE_LAUNCH=1 selects
-// the persistent kernel where it has a plan.
+// The entry point the autograd nodes call: the small-map kernel up to 512 pixels (bf16), else the three launches.  (Two persistent
+// one-launch kernels that read x / da from HBM once were built in round 4, both correct, both slower -- 0.61 / 0.86 vs 0.48 ms at
+// 128 ch @256^2 x 32: profiles/r04_gn_coop_v1.txt, r04_gn_queue_v2.txt; the second is kept as docs/history/experiments/r4_gn_queue.patch.)
 extern "C" int mas_gn_bwd(const void* x, const void* da, const void* dres, int dtype, int N, int HW, int C, int G, int act,
                           const float* gamma, const float* mean_rstd, const float* scale_shift, void* dx, float* dgamma,
                           float* dbeta, void* workspace, size_t ws_bytes, void* stream) {
@@ -1342,24 +957,7 @@ extern "C" int mas_gn_bwd(const void* x, const void* da, const void* dres, int d
         }
         return MAS_OK;
     }
-    static const int one = mas_env_int("MAS_GN_BWD_ONE_LAUNCH", 0);
-    if (one && dtype == MAS_BF16) {
-        const int rc = mas_gn_bwd_1pass(x, da, dres, dtype, N, HW, C, G, act, gamma, mean_rstd, scale_shift, dx, dgamma, dbeta, workspace, ws_bytes, stream);
-        if (rc != MAS_EUNSUPPORTED) return rc;
-    }
     return mas_gn_bwd_3pass(x, da, dres, dtype, N, HW, C, G, act, gamma, mean_rstd, scale_shift, dx, dgamma, dbeta, workspace, ws_bytes, stream);
-}
-
-// The one-launch plan for a shape on a device with `num_cus` compute units, without touching a device (tests model the queue from
-// it): plan[10] = {threads, work-groups, row ranges per image, images per group, groups, slices per image, channels per slice, lead,
-// ring slots, tickets per round}; returns 1 when the tensor has a plan (mas_gn_bwd_1pass takes it), else 0.
-extern "C" int mas_gn_bwd_plan(int N, int HW, int C, int G, int num_cus, int* plan) {
-    GnQueuePlan pl;
-    if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G || num_cus <= 0 || !plan) return 0;
-    if (!gn_queue_plan(N, HW, C, G, num_cus, &pl)) return 0;
-    const int v[10] = {pl.T, pl.W, pl.nsplit, pl.Gi, pl.NG, pl.NS, pl.CS, pl.L, pl.R, pl.Gi * pl.NS + 2 * pl.Gi * pl.nsplit};
-    for (int i = 0; i < 10; ++i) plan[i] = v[i];
-    return 1;
 }
 
 // three launches: reduce -> finalize -> apply (fp32, bf16 shapes the one-launch kernel does not take; x and da are read twice)

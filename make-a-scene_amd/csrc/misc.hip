@@ -111,6 +111,48 @@ __global__ __launch_bounds__(NT) void pack_weight_k32_kernel(const float* __rest
     pack_weight_k32_body(w, out, Cout, Cin, ks, transpose, rows_pad, n_chunks, (long long)blockIdx.x * NT + threadIdx.x, (long long)gridDim.x * NT);
 }
 
+// MAS_WLAYOUT_UP2 (bf16, 3x3): the sub-pixel form of Upsample + conv (conv_up2.hip) -- [phase 2a+b][chunk32][tap 2r+s][row][64 B], rows
+// and slots as K32; element = sum of the 3x3 taps (kh in R(a, r), kw in R(b, s)) in fp32, rounded once.  transpose = 1 (data
+// gradient): in/out swapped and tap (1 - r, 1 - s) stored at (r, s).  R as a bit mask over {0,1,2}: index 2a + r.
+__device__ __forceinline__ void pack_weight_up2_body(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int transpose,
+                                                     int rows_pad, int n_chunks, long long first, long long stride) {
+    const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
+    const unsigned total = 16u * (unsigned)n_chunks * (unsigned)rows_pad * 4u;      // 16-byte slots
+    for (unsigned u = (unsigned)first; u < total; u += (unsigned)stride) {
+        const unsigned sp = u & 3u, r_ = u >> 2;
+        const unsigned q = r_ / (unsigned)rows_pad, row = r_ - q * (unsigned)rows_pad;
+        const unsigned t = q & 3u, qq = q >> 2;
+        const unsigned ph = qq / (unsigned)n_chunks, ch = qq - ph * (unsigned)n_chunks;
+        int tr = (int)(t >> 1), ts = (int)(t & 1u);
+        if (transpose) { tr = 1 - tr; ts = 1 - ts; }
+        const unsigned masks = 0x4361u;                                 // R(0,0) = 001b, R(0,1) = 110b, R(1,0) = 011b, R(1,1) = 100b (nibbles, index 2a + r)
+        const unsigned mh = (masks >> (4 * (2 * (ph >> 1) + tr))) & 7u, mw = (masks >> (4 * (2 * (ph & 1u) + ts))) & 7u;
+        const int col0 = (int)ch * 32 + (int)((sp ^ ((row >> 2) & 3u)) * 8);
+        const int frow = (int)((row & ~127u) + 4u * (row & 31u) + ((row & 127u) >> 5));
+        u32x4 o;
+        bf16_t* ov = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int col = col0 + e;
+            float v = 0.0f;
+            if (frow < rows && col < cols) {
+                const float* src = transpose ? w + ((size_t)col * Cin + frow) * 9 : w + ((size_t)frow * Cin + col) * 9;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        if (((mh >> kh) & 1u) && ((mw >> kw) & 1u)) v += src[kh * 3 + kw];
+            }
+            ov[e] = (bf16_t)v;
+        }
+        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(out) + (size_t)u * 16) = o;
+    }
+}
+__global__ __launch_bounds__(NT) void pack_weight_up2_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin,
+                                                             int transpose, int rows_pad, int n_chunks) {
+    pack_weight_up2_body(w, out, Cout, Cin, transpose, rows_pad, n_chunks, (long long)blockIdx.x * NT + threadIdx.x, (long long)gridDim.x * NT);
+}
+
 // Every stale packed weight of a step in ONE launch (the per-weight launches are ~8 us each of dependent-launch latency, ~160 per
 // VQ-IMG step): work-group b looks its item up in the block-offset table (items sorted by first_block) and packs its share.
 __global__ __launch_bounds__(NT) void pack_weight_batch_kernel(const MasPackItem* __restrict__ items, int n_items) {
@@ -125,7 +167,9 @@ __global__ __launch_bounds__(NT) void pack_weight_batch_kernel(const MasPackItem
     const int rows = it.transpose ? it.Cin : it.Cout, cols = it.transpose ? it.Cout : it.Cin;
     const int rows_pad = (rows + 127) / 128 * 128;
     auto cdiv = [](int a, int d) { return (a + d - 1) / d; };
-    if (it.layout == MAS_WLAYOUT_K32)
+    if (it.layout == MAS_WLAYOUT_UP2)
+        pack_weight_up2_body(it.w_oihw, (bf16_t*)it.packed, it.Cout, it.Cin, it.transpose, rows_pad, cdiv(cols, 32), first, stride);
+    else if (it.layout == MAS_WLAYOUT_K32)
         pack_weight_k32_body(it.w_oihw, (bf16_t*)it.packed, it.Cout, it.Cin, it.ks, it.transpose, rows_pad, cdiv(cols, 32), first, stride);
     else if (it.dtype == MAS_BF16)
         pack_weight_body<bf16_t>(it.w_oihw, (bf16_t*)it.packed, it.Cout, it.Cin, it.ks, it.transpose, rows_pad, cdiv(cols, 64), first, stride);
@@ -329,6 +373,12 @@ extern "C" size_t mas_packed_weight_elems(int Cout, int Cin, int ks) {
     return (size_t)ks * ks * (a > b ? a : b);
 }
 
+extern "C" size_t mas_packed_weight_elems_up2(int Cout, int Cin) {   // 4 phases x 4 taps of the MAS_WLAYOUT_UP2 image, either operand
+    const size_t a = (size_t)mas_roundup(Cout, 128) * mas_roundup(Cin, 32);
+    const size_t b = (size_t)mas_roundup(Cin, 128) * mas_roundup(Cout, 32);
+    return 16 * (a > b ? a : b);
+}
+
 extern "C" int mas_pack_conv_weight(const float* w_oihw, void* packed, int Cout, int Cin, int ks, int transpose, int dtype,
                                     void* stream) {
     MAS_ENTER();
@@ -354,6 +404,16 @@ extern "C" int mas_pack_conv_weight_layout(const float* w_oihw, void* packed, in
     if (layout == MAS_WLAYOUT_K64) return mas_pack_conv_weight(w_oihw, packed, Cout, Cin, ks, transpose, dtype, stream);
     MAS_ENTER();
     if (!w_oihw || !packed) MAS_FAIL(MAS_EINVAL, "pack_conv_weight: null argument");
+    if (layout == MAS_WLAYOUT_UP2) {
+        if (dtype != MAS_BF16 || ks != 3 || Cout <= 0 || Cin <= 0) MAS_FAIL(MAS_EUNSUPPORTED, "pack_conv_weight: the UP2 image is bf16 / 3x3 only");
+        const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
+        const int rows_pad = mas_roundup(rows, 128), n_chunks = mas_cdiv(cols, 32);
+        const long long total = 16LL * n_chunks * rows_pad * 4;
+        hipLaunchKernelGGL(pack_weight_up2_kernel, dim3(grid_for(total)), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), w_oihw,
+                           (bf16_t*)packed, Cout, Cin, transpose, rows_pad, n_chunks);
+        MAS_CHECK_LAUNCH("pack_conv_weight_up2");
+        return MAS_OK;
+    }
     if (layout != MAS_WLAYOUT_K32) MAS_FAIL(MAS_EINVAL, "pack_conv_weight: bad layout %d", layout);
     if (dtype != MAS_BF16 || ks != 3 || Cout <= 0 || Cin <= 0) MAS_FAIL(MAS_EUNSUPPORTED, "pack_conv_weight: the K32 image is bf16 / 3x3 only");
     const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
@@ -368,8 +428,9 @@ extern "C" int mas_pack_conv_weight_layout(const float* w_oihw, void* packed, in
 extern "C" int mas_pack_batch_blocks(int Cout, int Cin, int ks, int transpose, int dtype, int layout) {
     if (Cout <= 0 || Cin <= 0 || ks < 1 || ks > 4) return 0;
     const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
-    const int ck = layout == MAS_WLAYOUT_K32 ? 32 : (dtype == MAS_BF16 ? 64 : 32);
-    const long long total = (long long)ks * ks * mas_cdiv(cols, ck) * mas_roundup(rows, 128) * (layout == MAS_WLAYOUT_K32 ? 4 : 8);
+    const int ck = layout == MAS_WLAYOUT_K64 ? (dtype == MAS_BF16 ? 64 : 32) : 32;
+    if (layout == MAS_WLAYOUT_UP2 && (ks != 3 || dtype != MAS_BF16)) return 0;
+    const long long total = (long long)(layout == MAS_WLAYOUT_UP2 ? 16 : ks * ks) * mas_cdiv(cols, ck) * mas_roundup(rows, 128) * (layout == MAS_WLAYOUT_K64 ? 8 : 4);
     long long b = (total + NT - 1) / NT;                               // one 16-byte slot per thread
     if (b > 512) b = 512;
     return b < 1 ? 1 : (int)b;

@@ -17,8 +17,8 @@ LIB_PATH = os.environ.get("MAS_HIP_LIB") or os.path.join(_HERE, "libmas_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_AFFINE, ACT_AFFINE_SILU = 0, 1, 2
-ABI_VERSION = 5
-WLAYOUT_K64, WLAYOUT_K32 = 0, 1
+ABI_VERSION = 6
+WLAYOUT_K64, WLAYOUT_K32, WLAYOUT_UP2 = 0, 1, 2
 
 
 class ConvDesc(C.Structure):
@@ -52,6 +52,7 @@ _SIGNATURES = {
     "mas_last_error": (C.c_char_p, []),
     "mas_last_kernel": (C.c_char_p, []),
     "mas_packed_weight_elems": (_sz, [_i, _i, _i]),
+    "mas_packed_weight_elems_up2": (_sz, [_i, _i]),
     "mas_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "mas_conv_weight_layout": (_i, [C.POINTER(ConvDesc)]),
     "mas_pack_conv_weight_layout": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
@@ -66,8 +67,6 @@ _SIGNATURES = {
     "mas_gn_bwd_workspace": (_sz, [_i, _i]),
     "mas_gn_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "mas_gn_bwd_3pass": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
-    "mas_gn_bwd_1pass": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
-    "mas_gn_bwd_plan": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int)]),
     "mas_gn_act": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "mas_gn_small_supported": (_i, [_i, _i, _i, _i]),
     "mas_gn_stats_act": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _i, _p, _p, _p]),
@@ -79,6 +78,9 @@ _SIGNATURES = {
     "mas_wgrad_commit": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "mas_conv_s2_dgrad_supported": (_i, [C.POINTER(ConvDesc)]),
     "mas_conv_s2_dgrad": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p]),
+    "mas_conv_up2_supported": (_i, [C.POINTER(ConvDesc)]),
+    "mas_conv_up2_dgrad_supported": (_i, [C.POINTER(ConvDesc)]),
+    "mas_conv_up2_dgrad": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p]),
     "mas_conv_wgrad_splits": (_i, [C.POINTER(ConvDesc)]),
     "mas_conv_wgrad_partial": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
     "mas_wgrad_reduce": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _p]),

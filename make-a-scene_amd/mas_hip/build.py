@@ -14,7 +14,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # VALU beside MFMAs is slower on gfx950 -- measured -2 ... -5 % on the forward kernel, profiles/r03_attn_v2.txt)
 # conv3x3_wide.hip: the same for the epilogue's bias / residual adds (-2 % on the launch, gpu_r3_17.sh; the stream kernel measured 5 % SLOWER
 # without packing and keeps it)
-PER_FILE_FLAGS = {"attention.hip": ["-DFA_SCALAR_SOFTMAX", "-fno-slp-vectorize"], "conv3x3_wide.hip": ["-fno-slp-vectorize"]}
+PER_FILE_FLAGS = {"attention.hip": ["-DFA_SCALAR_SOFTMAX", "-fno-slp-vectorize"], "conv3x3_wide.hip": ["-fno-slp-vectorize"],
+                  "conv_up2.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():

@@ -14,7 +14,7 @@ from typing import Optional
 
 import torch
 
-from . import ACT_AFFINE, ACT_AFFINE_SILU, ACT_NONE, BF16, F32, WLAYOUT_K64, ConvDesc, PackItem, PackTileItem, check, lib
+from . import ACT_AFFINE, ACT_AFFINE_SILU, ACT_NONE, BF16, F32, WLAYOUT_K64, WLAYOUT_UP2, ConvDesc, PackItem, PackTileItem, check, lib
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 _state = {"compute_dtype": torch.bfloat16 if os.environ.get("MAS_COMPUTE_DTYPE", "bf16") == "bf16" else torch.float32}
@@ -169,7 +169,7 @@ class _PackCache:
                                    "through .data?) -- call mas_hip.ops.invalidate_weight_cache() after such writes" % (tuple(w.shape),))
             return hit[2]
         if hit is None or hit[0]() is not w or hit[2].device != w.device:
-            n = lib().mas_packed_weight_elems(w.shape[0], w.shape[1], w.shape[2])
+            n = _packed_elems(w.shape[0], w.shape[1], w.shape[2], layout)
             self.store[key] = [weakref.ref(w, lambda _r, k=key: self.store.pop(k, None)), None, torch.empty(n, dtype=dtype, device=w.device)]
         self._refresh_stale(w.device)
         return self.store[key][2]
@@ -196,7 +196,7 @@ class _PackCache:
             if _CACHE_CHECK:
                 self.sums[key] = _checksum(w)
             g = groups.get(wid)
-            if dtype == torch.bfloat16 and ks <= 4 and (g is None or len(g[2]) < 4):
+            if dtype == torch.bfloat16 and ks <= 4 and layout != WLAYOUT_UP2 and (g is None or len(g[2]) < 4):
                 if g is None:
                     g = groups[wid] = (wf, (cout, cin, ks), [])
                 g[2].append((ent[2].data_ptr(), int(transpose), int(layout)))
@@ -256,13 +256,20 @@ def invalidate_weight_cache() -> None:
     _bf16_shadows.clear()
 
 
+def _packed_elems(cout: int, cin: int, ks: int, layout: int) -> int:
+    """elements of a packed image: the sub-pixel image of Upsample + conv (UP2) holds 4 phases x 4 taps instead of 9 taps"""
+    if layout == WLAYOUT_UP2:
+        return int(lib().mas_packed_weight_elems_up2(cout, cin))
+    return int(lib().mas_packed_weight_elems(cout, cin, ks))
+
+
 def pack_conv_weight(w: torch.Tensor, transpose: bool, dtype: torch.dtype, layout: int = WLAYOUT_K64) -> torch.Tensor:
     """OIHW fp32 -> the LDS image of ``layout`` (include/mas_hip.h: K64 = every kernel but the wide 3x3 one, K32 = that one)."""
     _require_cuda(w, "pack_conv_weight")
     cout, cin, ks, ks2 = w.shape
     assert ks == ks2
     w = w.contiguous().float()
-    n = lib().mas_packed_weight_elems(cout, cin, ks)
+    n = _packed_elems(cout, cin, ks, layout)
     out = torch.empty(n, dtype=dtype, device=w.device)
     check(lib().mas_pack_conv_weight_layout(_ptr(w), _ptr(out), cout, cin, ks, int(transpose), _DT[dtype], int(layout), _stream()),
           "pack_conv_weight")
@@ -374,17 +381,15 @@ def gn_stats_act(x: torch.Tensor, gamma, beta, groups: int, eps: float, act: int
 
 
 def gn_bwd(x, da, dres, groups, act, gamma, mr, ss, path=None):
-    """GroupNorm(+SiLU) backward: (dx [+ dres], dgamma, dbeta).  ``path`` None: ``mas_gn_bwd`` (the library's choice: the small-map
-    kernel up to 32x32 pixels, else the faster of the two below on MI355X); "three": reduce / finalize / apply launches
-    (``mas_gn_bwd_3pass``); "one": the persistent kernel that reads x / da from HBM once (``mas_gn_bwd_1pass``, bf16; raises where the
-    tensor has no plan)."""
+    """GroupNorm(+SiLU) backward: (dx [+ dres], dgamma, dbeta).  ``path`` None: ``mas_gn_bwd`` (the small-map kernel up to 512 pixels,
+    bf16; else the three launches); "three": reduce / finalize / apply launches on any shape (``mas_gn_bwd_3pass``)."""
     n, c, h, w = x.shape
     dx = torch.empty_like(x, memory_format=torch.channels_last)
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
     wsb = lib().mas_gn_bwd_workspace(n, c)
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
-    fn = {None: lib().mas_gn_bwd, "three": lib().mas_gn_bwd_3pass, "one": lib().mas_gn_bwd_1pass}[path]
+    fn = {None: lib().mas_gn_bwd, "three": lib().mas_gn_bwd_3pass}[path]
     check(fn(_ptr(x), _ptr(da), _ptr(dres), _DT[x.dtype], n, h * w, c, groups, act, _ptr(gamma), _ptr(mr), _ptr(ss),
              _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), wsb, _stream()), "gn_bwd")
     return dx, dgamma, dbeta
@@ -406,6 +411,16 @@ def _preferred_layout(d: ConvDesc) -> int:
 
 
 _stat_rows_memo = {}
+_up2_memo = {}
+
+
+def _up2_supported(d: ConvDesc, dgrad: bool = False) -> bool:
+    key = (dgrad,) + tuple(getattr(d, f) for f, _ in ConvDesc._fields_[:-1])
+    ok = _up2_memo.get(key)
+    if ok is None:
+        fn = lib().mas_conv_up2_dgrad_supported if dgrad else lib().mas_conv_up2_supported
+        ok = _up2_memo[key] = bool(fn(C.byref(d)))
+    return ok
 
 
 # The fast kernels (wide / stream / stride-2 / thin / 1x1 convolutions, LDS-DMA weight gradients) address a whole tensor through ONE
@@ -441,6 +456,8 @@ def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stri
     d = _desc(ns, h, w, cin, ho, wo, cout, ks, stride, pt, pl, x.dtype, out_dtype, act, upsample)
     if isinstance(wp, ConvWeight):
         d.w_layout = _preferred_layout(d)
+        if upsample and residual is None and act == ACT_NONE and _up2_supported(d):
+            d.w_layout = WLAYOUT_UP2                   # Upsample + conv in its sub-pixel form (conv_up2.hip): 2.25x fewer FLOPs
         wp = _pack_cache.get(wp.w, wp.transpose, x.dtype, d.w_layout, wp.sources)
     partial, rows = None, 0
     if want_stats and _stats_state["on"] and act == ACT_NONE:
@@ -678,10 +695,28 @@ class _NormActConv(torch.autograd.Function):
                 else:  # adjoint of the strided read: zero-stuff dy, then a stride-1 conv
                     hd, wd = (ho - 1) * stride + 1, (wo - 1) * stride + 1
                     d_in = zero_stuff2x(dy, hd, wd)
+            if da is None and ups and stride == 1:
+                # Upsample + conv: the data gradient with respect to the LOW-resolution input straight from dy (conv_up2.hip: the four phase
+                # images of dy through the transposed 2x2 phase weights) -- no high-resolution da, no sum-pooling pass
+                esz = dy.element_size()
+                slices = _batch_slices(n, h * w * cin * esz, ho * wo * cout * esz)
+                dfws = [_desc(n1 - n0, h, w, cin, ho, wo, cout, ks, 1, pt, pl, cd, cd, ACT_NONE, True) for n0, n1 in slices]
+                if ks == 3 and all(_up2_supported(dfw, True) for dfw in dfws):
+                    wpk = _pack_cache.get(weight, True, cd, WLAYOUT_UP2, ctx.w_sources)
+                    da = torch.empty((n, cin, h, w), dtype=cd, device=dy.device, memory_format=torch.channels_last)
+
+                    def launch_up2():
+                        for (n0, n1), dfw in zip(slices, dfws):
+                            check(lib().mas_conv_up2_dgrad(C.byref(dfw), _ptr(dy[n0:n1]), _ptr(wpk), _ptr(da[n0:n1]), _stream()), "conv_up2_dgrad")
+
+                    if _launch_hook is not None:
+                        _launch_hook("conv_up2_dgrad", (n, h, w, cin, ho, wo, cout, ks, 1, ACT_NONE, 0), launch_up2)
+                    else:
+                        launch_up2()
             if da is None:
                 da = conv_fwd_raw(d_in, None, wt, None, None, n, hd, wd, cout, hl, wl, cin, ks, 1, ks - 1 - pt, ks - 1 - pl, ACT_NONE, False, cd)
-            if ups:
-                da = sumpool2x(da)
+                if ups:
+                    da = sumpool2x(da)
             if act != ACT_NONE:
                 dx, dgw, dgb = gn_bwd(x, da, None, cfg["groups"], act, gn_w.detach().float(), mr, ss)
                 dgw, dgb = dgw.to(gn_w.dtype), dgb.to(gn_w.dtype)

@@ -47,7 +47,7 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     """the ABI v2 additions follow the same convention: negative code + message, nothing computed"""
     import mas_hip
     L = mas_hip.lib()
-    assert L.mas_abi_version() == mas_hip.ABI_VERSION == 5
+    assert L.mas_abi_version() == mas_hip.ABI_VERSION == 6
     assert L.mas_conv_weight_layout(None) == mas_hip.WLAYOUT_K64
     d = mas_hip.ConvDesc(32, 256, 256, 128, 256, 256, 128, 3, 1, 1, 1, mas_hip.BF16, mas_hip.BF16, 0, 0, 0)
     assert L.mas_conv_weight_layout(ctypes.byref(d)) in (mas_hip.WLAYOUT_K64, mas_hip.WLAYOUT_K32)
@@ -59,6 +59,14 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     assert L.mas_spatial_attn_fwd(1, 1, None, mas_hip.BF16, 1, 300, 64, None) == -2    # more than 256 tokens
     assert L.mas_pack_conv_weight_layout(1, 1, 128, 128, 3, 0, mas_hip.F32, mas_hip.WLAYOUT_K32, None) == -2   # K32 is bf16 only
     assert L.mas_space_to_depth2x(None, None, 1, 1, 2, 2, 8, 2, 2, 1, None) == -1
+    # ABI v6: Upsample + conv in its sub-pixel form (conv_up2.hip)
+    assert L.mas_packed_weight_elems_up2(128, 128) == 16 * 128 * 128 and L.mas_packed_weight_elems_up2(128, 512) == 16 * 128 * 512
+    assert L.mas_conv_up2_supported(None) == 0 and L.mas_conv_up2_dgrad_supported(None) == 0
+    assert L.mas_conv_up2_dgrad(None, None, None, None, None) == -1
+    assert L.mas_pack_conv_weight_layout(1, 1, 128, 128, 3, 0, mas_hip.F32, mas_hip.WLAYOUT_UP2, None) == -2   # UP2 is bf16 / 3x3 only
+    assert L.mas_pack_batch_blocks(128, 128, 3, 0, mas_hip.BF16, mas_hip.WLAYOUT_UP2) == 128      # 16 tap tiles x 4 chunks x 128 rows x 4 slots / 256
+    plain = mas_hip.ConvDesc(32, 128, 128, 128, 128, 128, 128, 3, 1, 1, 1, mas_hip.BF16, mas_hip.BF16, 0, 0, 0)
+    assert L.mas_conv_up2_supported(ctypes.byref(plain)) == 0               # not an Upsample convolution
 
 
 def test_surface_matches_reference_contract():

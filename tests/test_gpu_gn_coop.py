@@ -1,9 +1,11 @@
-"""GroupNorm(+SiLU) backward as ONE persistent launch (``mas_gn_bwd_1pass`` -> ``gn_bwd_coop_kernel``, groupnorm.hip): autograd of the
-reference's ``Normalize`` + ``nonlinearity`` (models/modules.py:35-41,121-128) with the skip-connection gradient added in the same pass.
+"""GroupNorm(+SiLU) backward (``mas_gn_bwd`` / ``mas_gn_bwd_3pass``, groupnorm.hip): autograd of the reference's ``Normalize`` +
+``nonlinearity`` (models/modules.py:35-41,121-128) with the skip-connection gradient added in the same pass.
 
-Checked against (i) torch's fp32 autograd of group_norm (+ SiLU) on the CPU, on the bf16-rounded operands the kernel sees; (ii) the
-three-launch path ``mas_gn_bwd_3pass`` (same arithmetic, other partition of the sums); (iii) itself: bitwise run to run, also while
-another stream keeps the chip busy (the in-launch hand-offs must not depend on timing or placement)."""
+Checked against (i) torch's fp32 autograd of group_norm (+ SiLU) on the CPU, on the bf16-rounded operands the kernel sees; (ii) itself:
+bitwise run to run, also while another stream keeps the chip busy; (iii) at the benched size through a size-independent property.
+Then the small-map kernels (one launch forward, one launch + the batch sums backward) against the streaming passes.
+(Round 4's one-launch persistent backward was tested here too; it lost to the three launches and is shelved with its tests:
+docs/history/experiments/r4_gn_queue.patch.)"""
 import numpy as np
 import pytest
 import torch
@@ -44,7 +46,7 @@ def _reference(x, da, dres, gamma, beta, act):
     return dx, gr.grad, br.grad
 
 
-def _run(dev, x, da, dres, gamma, beta, act, path="one"):
+def _run(dev, x, da, dres, gamma, beta, act, path="three"):
     from mas_hip import ops
     cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last) if t is not None else None
     xd, dad, drd = cl(x), cl(da), cl(dres)
@@ -53,8 +55,7 @@ def _run(dev, x, da, dres, gamma, beta, act, path="one"):
     return ops.gn_bwd(xd, dad, drd, 32, act, gd, mr, ss, path=path)
 
 
-# n, c, h, w: one work-group ... several groups through the ring (8 x 128 x 128^2 -> 2 images per group at the default plan;
-# 24 images -> the ring of D + 2 slots wraps), ragged maps, every channel-unit width (C / 8 = 4 ... 64)
+# n, c, h, w: ragged maps, every channel-unit width (C / 8 = 4 ... 64), several row splits per image
 SHAPES = [(2, 32, 32, 32), (3, 64, 12, 20), (1, 128, 9, 13), (4, 128, 64, 64), (2, 512, 16, 16), (5, 256, 24, 24), (2, 512, 32, 32),
           (24, 128, 128, 128), (7, 256, 64, 64)]
 
@@ -62,45 +63,39 @@ SHAPES = [(2, 32, 32, 32), (3, 64, 12, 20), (1, 128, 9, 13), (4, 128, 64, 64), (
 @pytest.mark.parametrize("res", [False, True])
 @pytest.mark.parametrize("act", [1, 2])
 @pytest.mark.parametrize("shape", SHAPES)
-def test_one_launch_backward_vs_cpu_fp32_and_three_pass(shape, act, res):
+def test_three_launch_backward_vs_cpu_fp32(shape, act, res):
     dev = _dev()
     n, c, h, w = shape
     x, da, dres, gamma, beta = _case(n, c, h, w, act, res, seed=n * 1000 + c + h)
     dx_ref, dg_ref, db_ref = _reference(x, da, dres, gamma, beta, act)
-    dx, dg, db = _run(dev, x, da, dres, gamma, beta, act)
-    dx3, dg3, db3 = _run(dev, x, da, dres, gamma, beta, act, path="three")
+    dx, dg, db = _run(dev, x, da, dres, gamma, beta, act, path="three")
     torch.cuda.synchronize()
-    assert torch.isfinite(dg).all() and torch.isfinite(db).all()          # (NaN = a work-group gave up waiting: see the kernel's header)
+    assert torch.isfinite(dg).all() and torch.isfinite(db).all()
     # dx is stored in bf16: 2^-8 relative per element; the fp32 parameter gradients are sums of <= 4e5 rounded terms
     assert _rel(dx, dx_ref) < 1.2e-2, _rel(dx, dx_ref)
     assert _rel(dg, dg_ref) < 2e-3 and _rel(db, db_ref) < 2e-3, (_rel(dg, dg_ref), _rel(db, db_ref))
-    # the two paths differ by the partition of fp32 sums only
-    assert _rel(dg, dg3) < 1e-4 and _rel(db, db3) < 1e-4
-    assert _rel(dx, dx3) < 8e-3                                            # (a last-bit change of a coefficient moves a bf16 rounding here and there)
-    assert float((dx.float() != dx3.float()).float().mean()) < 2e-2
 
 
-def test_one_launch_backward_is_bitwise_reproducible_also_under_concurrent_load():
-    """Two quiet runs and one run beside a stream of large GEMMs (which displaces and delays work-groups of the persistent launch):
-    bit-identical dx / dgamma / dbeta -- the hand-offs are counter-based, the sums keep a fixed order."""
+def test_backward_is_bitwise_reproducible_also_under_concurrent_load():
+    """Two quiet runs and one run beside a stream of large GEMMs: bit-identical dx / dgamma / dbeta -- the sums keep a fixed order."""
     dev = _dev()
     x, da, dres, gamma, beta = _case(16, 128, 128, 128, 2, True, seed=5)
-    a = _run(dev, x, da, dres, gamma, beta, 2)
-    b = _run(dev, x, da, dres, gamma, beta, 2)
+    a = _run(dev, x, da, dres, gamma, beta, 2, path=None)
+    b = _run(dev, x, da, dres, gamma, beta, 2, path=None)
     side = torch.cuda.Stream()
     m = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
     with torch.cuda.stream(side):
         for _ in range(12):
             m2 = m @ m
-    c = _run(dev, x, da, dres, gamma, beta, 2)
+    c = _run(dev, x, da, dres, gamma, beta, 2, path=None)
     torch.cuda.synchronize()
     del m2
     for u, v, t in zip(a, b, c):
         assert torch.equal(u, v) and torch.equal(u, t)
 
 
-def test_one_launch_backward_full_size_matches_three_pass():
-    """the benched shape (32 x 128 ch x 256^2: 32 groups through the pipeline) against the three-launch kernels"""
+def test_backward_full_size_dbeta_property():
+    """the benched shape (32 x 128 ch x 256^2): dbeta = sum over pixels of du, recomputed in fp32 with torch on the GPU"""
     dev = _dev()
     from mas_hip import ops
     g = torch.Generator(device=dev).manual_seed(1)
@@ -111,21 +106,15 @@ def test_one_launch_backward_full_size_matches_three_pass():
     gamma = 1.0 + 0.1 * torch.randn(c, device=dev, generator=g)
     beta = 0.1 * torch.randn(c, device=dev, generator=g)
     mr, ss = ops.gn_stats(x, gamma, beta, 32, 1e-6)
+    u = x.float() * ss[:, :, 0].view(n, c, 1, 1) + ss[:, :, 1].view(n, c, 1, 1)
+    s = torch.sigmoid(u)
+    du = (da.float() * (s * (1 + u * (1 - s)))).sum(dim=(0, 2, 3))
+    del u, s
     for res in (None, dres):
-        dx, dg, db = ops.gn_bwd(x, da, res, 32, 2, gamma, mr, ss, path="one")
-        dx3, dg3, db3 = ops.gn_bwd(x, da, res, 32, 2, gamma, mr, ss, path="three")
+        dx, dg, db = ops.gn_bwd(x, da, res, 32, 2, gamma, mr, ss)
         torch.cuda.synchronize()
         assert torch.isfinite(dg).all()
-        assert _rel(dg, dg3) < 1e-4 and _rel(db, db3) < 1e-4
-        assert float((dx.float() - dx3.float()).abs().max() / dx3.float().abs().max()) < 8e-3
-        assert float((dx != dx3).float().mean()) < 2e-2
-        # size-independent property: with gamma = 1 (beta free) dx - dres sums to zero over every (image, group)
-        # -- checked on the real gamma through dbeta instead: dbeta = sum over pixels of du, recomputed here in fp32
-        u = x.float() * ss[:, :, 0].view(n, c, 1, 1) + ss[:, :, 1].view(n, c, 1, 1)
-        s = torch.sigmoid(u)
-        du = da.float() * (s * (1 + u * (1 - s)))
-        assert _rel(db, du.sum(dim=(0, 2, 3))) < 1e-4
-        del u, s, du
+        assert _rel(db, du) < 1e-4
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

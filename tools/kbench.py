@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--ups", type=int, default=0, help="conv_fwd: 1 = Upsample's convolution (nearest x2 folded in: --hw is the INPUT map, the output is 2x)")
     ap.add_argument("--stats", type=int, default=0, help="conv_fwd: 1 = request the fused GroupNorm statistics epilogue (the training forward's variant)")
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--three", type=int, default=-1, help="gn_bwd: 1 = the three-launch path, 0 = the one-launch queue kernel, 2 = the library default, -1 = all")
+    ap.add_argument("--three", type=int, default=-1, help="gn_bwd: 1 = the three-launch path, 2 = the library default (small-map kernel where it applies), -1 = both")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--zero", type=int, default=0, help="1 = all-zero activations and weights (no operand toggling: the power-bound clock give-back)")
     a = ap.parse_args()
@@ -88,9 +88,9 @@ def main():
         da = torch.randn_like(x)
         dres = torch.randn_like(x) if a.res else None
         alg = (3 + (1 if a.res else 0)) * x.numel() * esz         # x, da (, dres) read once, dx written once
-        for path in ((None, "three", "one") if a.three < 0 else (("three",) if a.three == 1 else (("one",) if a.three == 0 else (None,)))):
+        for path in ((None, "three") if a.three < 0 else (("three",) if a.three == 1 else (None,))):
             ms = timeit(lambda: ops.gn_bwd(x, da, dres, 32, a.act or 2, g, mr, ss, path=path), a.iters)
-            name = {None: "default: " + ops.last_kernel(), "three": "three launches", "one": "one launch (queue)"}[path]
+            name = {None: "default: " + ops.last_kernel(), "three": "three launches"}[path]
             print(f"gn_bwd[{name}] n={n} c={c} hw={h} res={a.res}: {ms:.4f} ms  "
                   f"{alg/ms/1e6:.1f} GB/s algorithmic (x + da{' + dres' if a.res else ''} + dx once)")
     elif a.kind == "gn_fwd":
