@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--cpu-baseline-all-cores", action="store_true",
                     help="also time the CPU oracle on ALL host hardware threads (BASELINE.md section 3's literal recipe; off by default: "
                          "277 s per step was measured with 256 threads in round 1, i.e. nothing finishes inside a bench run)")
+    ap.add_argument("--no-encoder-stack", action="store_true", help="skip the Encoder.forward line (kernel traces of the step alone)")
     ap.add_argument("--no-also", action="store_true",
                     help="vq workload at N=1: skip the short runs of the transformer / e2e workloads whose results the line carries under 'also'")
     return ap.parse_args()
@@ -520,7 +521,8 @@ def run_vq(args):
                                "algorithmic_gflop_per_launch": round(flops / 1e9, 1),
                                "algorithmic_hbm_gbs": round(bytes_ / (avg_ms * 1e-3) / 1e9, 1),
                                "hbm_frac": round(bytes_ / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-        out["encoder_stack"] = _encoder_stack(model, x, batch, args.dtype)
+        if not args.no_encoder_stack:
+            out["encoder_stack"] = _encoder_stack(model, x, batch, args.dtype)
         if "roofline" in out:
             # what this tile design can reach on this silicon: the shipped kernel with everything but its MFMAs and LDS fragment reads
             # compiled out (profiles/r02_wide_store_ablation.txt / DESIGN R2.2: 0.466 ms at the ~1.6 GHz the chip sustains under this

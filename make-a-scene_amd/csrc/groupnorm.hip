@@ -522,12 +522,15 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_pk(const bf16_t* __restrict__
 // the fused loader prologue (ops.py MAS_GN_MATERIALIZE): the forward convolution AND the weight gradient of a GroupNorm(+SiLU)-fed
 // layer then run prologue-free on `a`.  A thread owns a fixed 16-byte channel unit (scale / shift pairs in registers) and walks
 // pixels, four 16-byte loads in flight.
-template <typename T>
+// rev (MAS_GN_ACT_REV, default on): the images are walked LAST TO FIRST.  The producer of x (a convolution) and the consumer of a (the
+// next convolution) both walk first to last: this pass then starts on the part of x the producer wrote last (still in the 256 MiB
+// Infinity Cache) and ends on the part of a the consumer reads first.  NTS = non-temporal stores of a (MAS_GN_ACT_NT).
+template <typename T, bool NTS>
 __global__ __launch_bounds__(NT) void gn_act_kernel(const T* __restrict__ x, T* __restrict__ a, int C, int act, const float* __restrict__ ss,
-                                                    long long units_per_n) {
+                                                    long long units_per_n, int rev) {
     constexpr int EPU = 16 / (int)sizeof(T);
     const int upp = C / EPU;
-    const int n = blockIdx.y;
+    const int n = rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
     const size_t base = (size_t)n * (size_t)units_per_n * EPU;
     const long long u0 = (long long)blockIdx.x * NT + threadIdx.x;
     const int cu = (int)(u0 % upp);
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(NT) void gn_act_kernel(const T* __restrict__ x, T* 
                 f[e] = act == MAS_ACT_AFFINE_SILU ? silu_f(u) : u;
             }
         }
-        GN_ST(a + off, v);
+        if constexpr (NTS) GN_ST(a + off, v); else *reinterpret_cast<u32x4*>(a + off) = v;
     };
     const long long stride = (long long)gridDim.x * NT;
     long long u = u0;
@@ -862,10 +865,13 @@ extern "C" int mas_gn_act(const void* x, void* a, int dtype, int N, int HW, int 
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MAS_BF16)
-        hipLaunchKernelGGL(gn_act_kernel<bf16_t>, dim3(gx, N), dim3(NT), 0, s, (const bf16_t*)x, (bf16_t*)a, C, act, scale_shift, units_per_n);
+    static const int rev = mas_env_int("MAS_GN_ACT_REV", 1), nts = mas_env_int("MAS_GN_ACT_NT", 1);
+    if (dtype == MAS_BF16 && nts)
+        hipLaunchKernelGGL((gn_act_kernel<bf16_t, true>), dim3(gx, N), dim3(NT), 0, s, (const bf16_t*)x, (bf16_t*)a, C, act, scale_shift, units_per_n, rev);
+    else if (dtype == MAS_BF16)
+        hipLaunchKernelGGL((gn_act_kernel<bf16_t, false>), dim3(gx, N), dim3(NT), 0, s, (const bf16_t*)x, (bf16_t*)a, C, act, scale_shift, units_per_n, rev);
     else
-        hipLaunchKernelGGL(gn_act_kernel<float>, dim3(gx, N), dim3(NT), 0, s, (const float*)x, (float*)a, C, act, scale_shift, units_per_n);
+        hipLaunchKernelGGL((gn_act_kernel<float, true>), dim3(gx, N), dim3(NT), 0, s, (const float*)x, (float*)a, C, act, scale_shift, units_per_n, rev);
     MAS_CHECK_LAUNCH("gn_act");
     return MAS_OK;
 }

@@ -5,7 +5,9 @@
 elementwise torch off the hot path.  This package shadows the reference's ``losses`` package, so it falls
 through to the reference's own file instead: ``__path__`` is extended with the ``losses/`` directory of the reference checkout --
 ``$MAS_REFERENCE_ROOT/losses`` or any later ``sys.path`` entry that holds a ``losses/loss_seg.py`` -- and ``losses.loss_seg``,
-``losses.BCELossWithQuant`` and ``losses.VQVAEWithBCELoss`` resolve to it, unmodified."""
+``losses.BCELossWithQuant`` and ``losses.VQVAEWithBCELoss`` resolve to it, unmodified.  The extension happens when this package is
+imported (so ``import losses.loss_seg`` / ``from losses.loss_seg import X`` work: submodule imports consult ``__path__``, never the
+module ``__getattr__``) and again, lazily, on attribute access (``sys.path`` is often completed after the first import)."""
 import os
 import sys
 
@@ -30,11 +32,18 @@ def _reference_dirs():
     return out
 
 
+def _extend_path():
+    for d in _reference_dirs():
+        if d not in __path__:
+            __path__.append(d)                          # behind this package's own directory: its modules keep winning
+
+
+_extend_path()                                          # eager: the plain ``import losses.loss_seg`` form sees the reference's file
+
+
 def __getattr__(name):
     if name in ("BCELossWithQuant", "VQVAEWithBCELoss", "loss_seg"):
-        for d in _reference_dirs():                     # (evaluated on use: sys.path is usually completed after this package is imported)
-            if d not in __path__:
-                __path__.append(d)                      # behind this package's own directory: its modules keep winning
+        _extend_path()                                  # lazy retry: sys.path / MAS_REFERENCE_ROOT may have been set after the import
         try:
             import importlib
             mod = importlib.import_module(__name__ + ".loss_seg")

@@ -340,6 +340,15 @@ def gn_stats(x: torch.Tensor, gamma, beta, groups: int, eps: float, partial: Opt
 # shape).  Under torch.no_grad() (inference, the encoder-stack line of bench.py) there is no second consumer and the fused loader
 # stays.  MAS_GN_MATERIALIZE=0: fused loaders everywhere (round 2's scheme).  A/B: profiles/r03_ab_v3.txt.
 _MATERIALIZE = os.environ.get("MAS_GN_MATERIALIZE", "1") == "1"
+# MAS_SAVE_ACT=0 (``set_save_activations(False)``): the materialised activation is still written and read by the forward convolution
+# but NOT kept for the backward -- the weight gradient then recomputes it in its loader from x and the scale / shift table (the fused
+# prologue of mas_conv_wgrad: +0.145 ms per 128-channel 256^2 launch), and the allocator's high-water mark drops by the activations'
+# 12 GiB at batch 32 (one bf16 tensor per GroupNorm-fed convolution).  Default: keep them (288 GB of HBM; the step is 1 ms faster).
+_save_act = {"on": os.environ.get("MAS_SAVE_ACT", "1") == "1"}
+
+
+def set_save_activations(on: bool) -> None:
+    _save_act["on"] = bool(on)
 
 
 def _gn_act_ok(c: int, dtype: torch.dtype) -> bool:
@@ -646,8 +655,8 @@ class _NormActConv(torch.autograd.Function):
                 a = gn_act(x, ss, act)
             y, ypart, yrows = conv_fwd_raw(a, None, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ACT_NONE, ups,
                                            cfg["out_dtype"], want_stats=True)
-            if not need_wgrad:
-                a = None                            # nothing in the backward reads it: not saved
+            if not need_wgrad or not _save_act["on"]:
+                a = None                            # nothing in the backward reads it (or MAS_SAVE_ACT=0: recomputed there): not saved
         else:
             y, ypart, yrows = conv_fwd_raw(x, ss, wp, b32, res, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups,
                                            cfg["out_dtype"], want_stats=True)
@@ -782,7 +791,7 @@ class _ResBlock(torch.autograd.Function):
                 if a_ is None:
                     a_ = gn_act(inp, ss_, ACT_AFFINE_SILU)
                 return conv_fwd_raw(a_, None, ConvWeight(wgt, False), f32(bia), resid, n, h, w, ci, h, w, co, 3, 1, 1, 1, ACT_NONE, False, cd,
-                                    want_stats=True) + (a_ if grad and need_w else None,)
+                                    want_stats=True) + (a_ if grad and need_w and _save_act["on"] else None,)
             return conv_fwd_raw(inp, ss_, ConvWeight(wgt, False), f32(bia), resid, n, h, w, ci, h, w, co, 3, 1, 1, 1, ACT_AFFINE_SILU, False,
                                 cd, want_stats=True) + (None,)
 

@@ -27,20 +27,20 @@ class Adam(torch.optim.Optimizer):
 
     _RING = 4
 
-    def _table(self, device, items):
-        """The item table on the device.  Gradient tensors are usually fresh allocations every step (``zero_grad(set_to_none=True)``),
-        so the table changes every step: it goes through a ring of pinned staging buffers with an asynchronous copy each, and the
+    def _table(self, tkey, device, items):
+        """The item table on the device (``tkey``: one ring of staging buffers per device, plus one per extra step count).  Gradient
+        tensors are usually fresh allocations every step (``zero_grad(set_to_none=True)``), so the table changes every step: it goes through a ring of pinned staging buffers with an asynchronous copy each, and the
         host only waits for the copy issued ``_RING`` steps ago -- never for the step in flight (a wait on the previous step's copy
         would serialise the host behind the whole backward: measured, +9 ms of wall time per step)."""
         arr = (AdamItem * len(items))(*items)
         raw = bytes(memoryview(arr))
-        ent = self._tables.get(device.index)
+        ent = self._tables.get(tkey)
         if ent is not None and ent["raw"] == raw:
             return ent["slots"][ent["cur"]][1]
         nbytes = len(raw)
         if ent is None or ent["cap"] < nbytes:
             cap = max(nbytes, 1 << 16)
-            ent = self._tables[device.index] = dict(cap=cap, cur=0, raw=None, slots=[
+            ent = self._tables[tkey] = dict(cap=cap, cur=0, raw=None, slots=[
                 (torch.empty(cap, dtype=torch.uint8, pin_memory=True), torch.empty(cap, dtype=torch.uint8, device=device), torch.cuda.Event())
                 for _ in range(self._RING)], used=[False] * self._RING)
         ent["cur"] = (ent["cur"] + 1) % self._RING
@@ -62,8 +62,7 @@ class Adam(torch.optim.Optimizer):
                 loss = closure()
         for group in self.param_groups:
             lr, (b1, b2), eps, wd = float(group["lr"]), group["betas"], float(group["eps"]), float(group["weight_decay"])
-            by_dev, first = {}, {}
-            step_no = None
+            by_key, first = {}, {}          # (device, step number) -> items: parameters on different step counts take separate launches
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -74,25 +73,30 @@ class Adam(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if st["step"].device.type != "cpu":          # a state loaded from torch.optim.Adam(fused=True / capturable=True) keeps `step` on
+                    st["step"] = st["step"].detach().to("cpu", torch.float32)   # the device: one sync here instead of one per step and parameter
                 st["step"] += 1
                 t = int(st["step"])
+                if p.numel() == 0:
+                    continue                                 # (torch.optim.Adam accepts empty parameters: nothing to update)
                 native = (p.is_cuda and p.dtype == torch.float32 and p.grad.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
                           and st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous() and p.grad.device == p.device)
-                if not native or (step_no is not None and t != step_no):
-                    self._torch_update(p, st, t, lr, b1, b2, eps, wd)       # (another dtype / device, or a parameter on its own step count)
+                if not native:
+                    self._torch_update(p, st, t, lr, b1, b2, eps, wd)       # (another dtype / device)
                     continue
-                step_no = t
+                key = (p.device, t)
                 it = AdamItem()
                 it.p, it.g, it.m, it.v, it.n = p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
-                it.first_block = first.get(p.device, 0)
-                first[p.device] = it.first_block + lib().mas_adam_blocks(p.numel())
-                by_dev.setdefault(p.device, []).append(it)
-            for device, items in by_dev.items():
+                it.first_block = first.get(key, 0)
+                first[key] = it.first_block + lib().mas_adam_blocks(p.numel())
+                by_key.setdefault(key, []).append(it)
+            for (device, t), items in by_key.items():
                 with torch.cuda.device(device):
-                    table = self._table(device, items)
+                    ordinal = [k for k in by_key if k[0] == device].index((device, t))      # 0 unless parameters of the group sit on different step counts
+                    table = self._table((device.index, ordinal), device, items)
                     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-                    check(lib().mas_adam_multi(C.c_void_p(table.data_ptr()), len(items), first[device], lr, b1, b2, eps, wd,
-                                               1.0 - b1 ** step_no, 1.0 - b2 ** step_no, stream), "adam_multi")
+                    check(lib().mas_adam_multi(C.c_void_p(table.data_ptr()), len(items), first[(device, t)], lr, b1, b2, eps, wd,
+                                               1.0 - b1 ** t, 1.0 - b2 ** t, stream), "adam_multi")
         return loss
 
     @staticmethod

@@ -6,10 +6,12 @@ AttnBlock :139, Swish :194, Encoder :199, Decoder :337, Codebook :451) so ``conf
 ``train.py`` instantiate these classes unchanged.  The arithmetic runs in hand-written HIP
 kernels (libmas_hip.so) on NHWC bf16 (or fp32) activations:
 
-* GroupNorm + SiLU never materialise: a statistics kernel feeds per-(sample,channel)
-  scale/shift into the following conv's loader (``mas_hip.ops.norm_act_conv``);
-* the residual add rides the conv epilogue; the nearest-x2 upsample and the one-sided
-  Downsample padding are address arithmetic inside the conv kernel;
+* GroupNorm: the statistics come out of the PRODUCING convolution's epilogue (or one launch on small maps), one
+  streaming pass writes silu(gn(x)) as a tensor and the 3x3 convolution AND its weight gradient run prologue-free on
+  it (measured faster on MI355X than the fused loader, which is kept: ``MAS_GN_MATERIALIZE=0``; DESIGN section 3);
+* the residual add rides the conv epilogue; ``Upsample`` + conv runs in its sub-pixel form (four 2x2 phase
+  convolutions on the low-resolution map, conv_up2.hip) and the one-sided Downsample padding is address
+  arithmetic inside the conv kernel;
 * the codebook lookup never materialises the [B*h*w, n_embed] distance matrix.
 
 Parameters stay plain fp32 OIHW ``nn.Parameter``s (``change_requires_grad`` in the reference's
@@ -84,8 +86,9 @@ class Conv2d(nn.Conv2d):
 
 
 class Upsample(nn.Module):
-    """reference modules.py:44-59: nearest x2, then 3x3 conv -- the x2 is folded into the conv's
-    address arithmetic (input pixel (h>>1, w>>1)); the 4x tensor is never written."""
+    """reference modules.py:44-59: nearest x2, then 3x3 conv.  The 4x tensor is never written: maps at least 32
+    pixels wide take the sub-pixel form (four 2x2 phase convolutions on the low-resolution map, 2.25x fewer
+    FLOPs: conv_up2.hip), narrower ones fold the x2 into the 3x3 kernel's address arithmetic."""
 
     def __init__(self, in_channels, with_conv):
         super().__init__()
@@ -118,8 +121,9 @@ class Downsample(nn.Module):
 
 class ResnetBlock(nn.Module):
     """reference modules.py:84-136:  x + conv2(silu(gn2(conv1(silu(gn1(x))))))  (1x1 shortcut when
-    the channel count changes).  Two fused kernels (+ one 1x1): GN+SiLU in each conv's loader,
-    the residual add in conv2's epilogue."""
+    the channel count changes) as ONE autograd node (``ops.resblock``): GroupNorm statistics from the
+    producer's epilogue, silu(gn(.)) written once per convolution, the residual add in conv2's epilogue,
+    the skip gradient added inside norm1's backward pass."""
 
     def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout):
         super().__init__()

@@ -50,7 +50,8 @@ def run_case(case, dev, sample=None, tol=1e-2, check_stats=True):
     torch.cuda.synchronize()
     kinds = dict(seen)
     assert [k for kind, k in seen if kind == "conv_fwd"][0] == "conv_up2_fwd", seen       # (a later conv_fwd entry = the old data-gradient path)
-    if cin % 128 == 0:                                 # (the data gradient's output tiles are 128 input channels wide)
+    dfw = ops._desc(n, h, w, cin, 2 * h, 2 * w, cout, 3, 1, 1, 1, torch.bfloat16, torch.bfloat16, 0, True)
+    if ops._up2_supported(dfw, True):                  # (128-channel output tiles, at least one tile per CU: else the 3x3 kernels at the high resolution)
         assert kinds.get("conv_up2_dgrad") == "conv_up2_dgrad", seen
     e_y, e_x = _rel(y[sample], ref), _rel(xd.grad[sample], xs.grad)
     e_w, e_b = _rel(wd.grad, ws.grad), _rel(bd.grad, bs.grad)

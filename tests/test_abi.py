@@ -120,7 +120,7 @@ def test_loss_seg_falls_through_to_the_reference_module(monkeypatch):
     import importlib
     import sys
     import losses
-    ref = "/root/reference"
+    ref = os.environ.get("MAS_REFERENCE_ROOT") or "/root/reference"       # (read before the variable is cleared below)
     for k in [k for k in sys.modules if k == "losses.loss_seg"]:
         del sys.modules[k]
     losses.__path__[:] = losses.__path__[:1]
@@ -139,3 +139,19 @@ def test_loss_seg_falls_through_to_the_reference_module(monkeypatch):
     assert torch.isfinite(cls()(q, t, pr))
     del sys.modules["losses.loss_seg"]
     losses.__path__[:] = losses.__path__[:1]
+
+
+def test_loss_seg_plain_import_form(tmp_path):
+    """``from losses.loss_seg import X`` / ``import losses.loss_seg`` -- the forms a ``_target_: losses.loss_seg....`` string
+    or a user script takes -- never consult the package's ``__getattr__``; they resolve because ``__path__`` is extended when the
+    package is imported.  Checked in a fresh interpreter against a stand-in checkout (any directory with a losses/loss_seg.py)."""
+    import subprocess
+    import sys
+    fake = tmp_path / "refroot"
+    (fake / "losses").mkdir(parents=True)
+    (fake / "losses" / "loss_seg.py").write_text("class VQVAEWithBCELoss:\n    marker = 'stand-in'\nclass BCELossWithQuant:\n    pass\n")
+    code = ("import sys; sys.path.insert(0, %r); from losses.loss_seg import VQVAEWithBCELoss as A; import losses.loss_seg as M; import losses; "
+            "assert A.marker == 'stand-in' and M.VQVAEWithBCELoss is A and losses.VQVAEWithBCELoss is A; print('plain import ok')"
+            % os.path.join(ROOT, "make-a-scene_amd"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MAS_REFERENCE_ROOT=str(fake)), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "plain import ok" in r.stdout, r.stdout + r.stderr

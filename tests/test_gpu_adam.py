@@ -97,3 +97,45 @@ def test_unsupported_variants_raise():
     for kw in (dict(amsgrad=True), dict(maximize=True), dict(capturable=True)):
         with pytest.raises(NotImplementedError):
             Adam(p, **kw)
+
+
+def test_edge_cases_empty_parameter_device_step_and_mixed_step_counts():
+    """(1) a parameter of numel 0 with a gradient is accepted, as torch.optim.Adam accepts it; (2) a state whose `step`
+    lives on the device (loaded from torch.optim.Adam(fused=True)) is moved to the host once; (3) parameters of one group on
+    different step counts each take the kernel with their own bias corrections (no fall-back to the slow path for all but the first)."""
+    from mas_hip.optim import Adam
+    dev = _dev()
+    torch.manual_seed(0)
+    empty = torch.nn.Parameter(torch.zeros(0, device=dev))
+    empty.grad = torch.zeros(0, device=dev)
+    opt = Adam([empty], lr=1e-2)
+    opt.step()                                               # must not raise ("empty batch")
+    # mixed step counts: b joins after a has taken two steps
+    a0, b0 = torch.randn(1000, device=dev), torch.randn(777, device=dev)
+    ga, gb = torch.randn(1000, device=dev), torch.randn(777, device=dev)
+    a, b = torch.nn.Parameter(a0.clone()), torch.nn.Parameter(b0.clone())
+    ra, rb = torch.nn.Parameter(a0.clone()), torch.nn.Parameter(b0.clone())
+    opt, ref = Adam([a, b], lr=1e-2), torch.optim.Adam([ra, rb], lr=1e-2)
+    for k in range(5):
+        a.grad, ra.grad = ga * (k + 1), ga * (k + 1)
+        if k >= 2:
+            b.grad, rb.grad = gb * (k + 1), gb * (k + 1)
+        opt.step()
+        ref.step()
+    torch.cuda.synchronize()
+    assert torch.allclose(a, ra, rtol=2e-6, atol=2e-6) and torch.allclose(b, rb, rtol=2e-6, atol=2e-6)
+    assert int(opt.state[a]["step"]) == 5 and int(opt.state[b]["step"]) == 3
+    # device-resident `step` (fused torch Adam's state layout)
+    fa = torch.nn.Parameter(a0.clone())
+    fused = torch.optim.Adam([fa], lr=1e-2, fused=True)
+    fa.grad = ga.clone()
+    fused.step()
+    ma = torch.nn.Parameter(fa.detach().clone())
+    mine = Adam([ma], lr=1e-2)
+    mine.load_state_dict(copy.deepcopy(fused.state_dict()))          # (load_state_dict keeps tensors of matching dtype / device: no aliasing)
+    ma.grad, fa.grad = ga * 2, ga * 2
+    mine.step()
+    fused.step()
+    torch.cuda.synchronize()
+    assert mine.state[ma]["step"].device.type == "cpu" and int(mine.state[ma]["step"]) == 2
+    assert torch.allclose(ma, fa, rtol=2e-6, atol=2e-6)
