@@ -52,6 +52,9 @@ SEG_CFG = dict(ddconfig=dict(z_channels=256, in_channels=159, out_channels=159, 
 TR_CFG = dict(num_layers=24, hidden_dim=1024, num_attn_heads=16, image_vocab_size=8192, seg_vocab_size=256,
               text_vocab_size=49408 + 256, image_tokens_per_dim=32, seg_tokens_per_dim=16, text_length=256)
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+# what v_mfma_f32_32x32x16_bf16 from registers alone sustains on RANDOM bf16 operands on this part: the package power limit holds such a
+# loop at 1.865 GHz (constant operands: 2477 TFLOP/s at 2.386 GHz) -- measured, profiles/r05_energy_budget.txt (tools/probes/mfma_power.hip)
+RANDOM_DATA_MFMA_CEILING_TFLOPS = 1890.0
 PEAK_HBM_GBS = 8000.0
 FWD_BWD_GFLOP_PER_IMG = 1337.53     # SURVEY.md section 8(d), counted on the reference with torch flop_counter
 TR_FWD_GFLOP_PER_SAMPLE = 1185.4    # full S x S attention count
@@ -226,6 +229,12 @@ def cpu_baseline(batch, budget_s=150, all_cores=False):
 
 
 # --------------------------------------------------------------------------------------------------------------------
+# GradReducer + zero_grad: set_to_none=False keeps .grad a view of the flat bucket and lets autograd ADD the next gradient into it (no
+# flatten copy, but one in-place add launch per parameter); set_to_none=True hands autograd fresh tensors and the bucket is flattened by
+# one batched copy.  A/B at world size 1: profiles/r05_dropin_defaults.txt
+_REDUCER_SET_TO_NONE = os.environ.get("MAS_BENCH_REDUCER_SET_TO_NONE", "1") == "1"      # (measured: -1.5 ms per step against the in-place scheme)
+
+
 def _adam(args, params, **kw):
     """reference train.py:99-103: torch.optim.Adam.  --optimizer mas (default) = the same update from one kernel launch"""
     if getattr(args, "optimizer", "mas") == "mas":
@@ -293,7 +302,10 @@ def _setup_dist(args):
     dev = torch.device("cuda", local_rank)
     ddp = world > 1 or os.environ.get("MAS_BENCH_FORCE_DDP") == "1"     # the env knob exercises the N>1 code path on one GPU
     if ddp:
-        os.environ.setdefault("MAS_WGRAD_OVERSUB", "2")     # wgrad grids at 2 work-groups per CU: a co-running RCCL kernel costs half a round
+        # (rounds 3-4 set MAS_WGRAD_OVERSUB=2 here -- weight-gradient grids at 2 work-groups per CU, so that a CU taken by a co-running RCCL
+        #  kernel costs half a round instead of a whole one.  Measured in round 5 at world size 1: +1.8 ms per step, every step (twice the
+        #  split-K slabs), against an expected saving of < 1 ms for the 2-4 ms per step a 381 MB all-reduce is in flight.  Off by default;
+        #  the knob stays: profiles/r05_dropin_defaults.txt)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
@@ -454,9 +466,9 @@ def run_vq(args):
         if reducer is not None:
             reducer.finish()
         opt.step()
-        # with the reducer the gradients stay views of its flat buckets and the next backward accumulates into them in place
-        # (no 381 MB gather copy per step); without it the reference's own set_to_none behaviour
-        opt.zero_grad(set_to_none=reducer is None)
+        # the reference's own set_to_none behaviour; with the reducer too since round 5 (its buckets are then flattened by one batched copy
+        # each -- keeping .grad a view of the bucket made autograd ADD into it: 345 in-place add launches per step, +1.5 ms)
+        opt.zero_grad(set_to_none=reducer is None or _REDUCER_SET_TO_NONE)
         return loss
 
     torch.cuda.reset_peak_memory_stats(dev)
@@ -527,7 +539,7 @@ def run_vq(args):
             # what this tile design can reach on this silicon: the shipped kernel with everything but its MFMAs and LDS fragment reads
             # compiled out (profiles/r02_wide_store_ablation.txt / DESIGN R2.2: 0.466 ms at the ~1.6 GHz the chip sustains under this
             # load = 1.33 PFLOP/s): the vendor peak `frac` is priced against assumes 2.4 GHz
-            out["roofline"]["mfma_only_floor_ms"] = 0.466
+            out["roofline"]["mfma_only_floor_ms"] = 0.400
             # the whole step's shader clock and package power (hwmon, sampled every 20 ms over the timed region): the convolution kernels
             # run into the ~1.4 kW package cap and the firmware lowers the clock (profiles/r04_clock_power.txt: 1.70-1.76 GHz under the wide
             # kernel); `frac` above is priced against the vendor peak at 2.4 GHz, `frac_of_peak_at_sustained_clock` against the same matrix
@@ -540,6 +552,11 @@ def run_vq(args):
             else:
                 out["roofline"]["sustained_clock_mhz"] = None
             out["roofline"]["mfma_only_floor_source"] = "committed ablation (kbench, MFMA + LDS reads only), not measured by this run"
+            # the ceiling of ANY bf16 kernel on real data on this part (a register-only MFMA loop on random operands sits on the power
+            # limit at 1.865 GHz): committed measurement, not made by this run
+            out["roofline"]["random_data_mfma_ceiling_tflops"] = RANDOM_DATA_MFMA_CEILING_TFLOPS
+            out["roofline"]["frac_of_random_data_mfma_ceiling"] = round(ach / RANDOM_DATA_MFMA_CEILING_TFLOPS, 4)
+            out["roofline"]["random_data_mfma_ceiling_source"] = "profiles/r05_energy_budget.txt (tools/probes/mfma_power.hip, >= 5 s loops, hwmon-sampled)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch, all_cores=args.cpu_baseline_all_cores)
         if world == 1 and not args.no_also and os.environ.get("MAS_BENCH_ALSO", "1") == "1":

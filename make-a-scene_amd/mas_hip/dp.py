@@ -19,6 +19,11 @@ Semantics match DDP's: gradients are averaged over ranks; a parameter that recei
 rank contributes zeros (all ranks must agree on which parameters are trainable in a step, as with
 ``find_unused_parameters=False``); parameters are broadcast from rank 0 at construction.
 
+Use it with ``optimizer.zero_grad(set_to_none=True)`` (the reference's and torch's default): autograd then hands each bucket fresh gradient
+tensors and the bucket is flattened by one batched copy.  With ``set_to_none=False`` the gradients stay views of the flat buffer and
+autograd ADDS the next step's gradients into them -- correct (the copy is skipped) but one in-place add launch per parameter: measured
++1.5 ms per VQ-IMG step (profiles/r05_dropin_defaults.txt).
+
 Contract: ``finish()`` follows EVERY synchronising ``backward()``.  Gradient accumulation (the reference's
 ``accumulate_grad``, conf/img_config.yaml:13) runs the first k-1 micro-steps under ``with reducer.no_sync():``
 (hooks idle, ``.grad`` accumulates locally as usual) and the k-th outside it, exactly like DDP's ``no_sync``.  A

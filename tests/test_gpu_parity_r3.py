@@ -201,7 +201,7 @@ def test_img256_encoder_backward_with_reference_dz(golden_dir, mode, copies):
     bf16: GroupNorm's backward subtracts the group means, so most of each gradient cancels and rounding noise is amplified
     layer by layer towards the input (measured rel-L2: 3.0e-2 at quant_conv.0 ... 1.0e-1 at encoder.model.0.weight, 1.3e-1 at its
     bias).  The yardstick is the reference ITSELF under torch.autocast(bfloat16) on the CPU, recorded in the fixture
-    (3.8e-2 ... 1.0e-1, 1.2e-1): each of our gradients must be within 1.5x of the reference's own bf16 deviation in rel-L2 and 2x in
+    (3.8e-2 ... 1.0e-1, 1.2e-1): each of our gradients must be within 1.2x (1.5x until round 5) of the reference's own bf16 deviation in rel-L2 and 2x in
     max-rel (the maximum over a 128-element GroupNorm weight gradient is a noisy statistic: a different summation order in ONE kernel
     moved encoder.model.1.norm1.weight from 0.8x to 1.57x of the reference's figure while its rel-L2 stayed at 1.006x; floor 5e-2),
     and the encoder gradient norm within 2 % of the fp32 reference."""
@@ -221,7 +221,7 @@ def test_img256_encoder_backward_with_reference_dz(golden_dir, mode, copies):
         got = params[k].grad.detach().float().cpu()[sl] / copies
         e2, em = rel_l2(got, g["grad:" + k]), relerr(got, g["grad:" + k])
         r2, rm = float(g["refbf16_l2:" + k]), float(g["refbf16_max:" + k])
-        lim2, limm = (2e-4, 5e-4) if mode == "fp32" else (max(1.5 * r2, 5e-2), max(2.0 * rm, 5e-2))
+        lim2, limm = (2e-4, 5e-4) if mode == "fp32" else (max(1.2 * r2, 5e-2), max(2.0 * rm, 5e-2))
         print("  %s copies=%d %-36s rel-L2 %.3e max-rel %.3e   (reference's own bf16 autocast: %.3e / %.3e)" % (mode, copies, k, e2, em, r2, rm))
         if e2 > lim2 or em > limm:
             bad.append((k, e2, em, lim2, limm))

@@ -31,7 +31,7 @@ from test_gpu_parity_r3 import IMG, _build, _dev, rel_l2, relerr  # noqa: E402
 def test_img256_decoder_backward_with_reference_drec(golden_dir, mode, copies):
     """Our decoder is fed the REFERENCE's z_q and its backward the REFERENCE's dL/drec: what differs from the reference's decoder
     gradients is kernel / storage error only.  fp32 (exact-fp32 MFMA kernels): every recorded gradient and dL/dz_q within 2e-4
-    rel-L2 / 5e-4 max-rel.  bf16: within 1.5x (rel-L2) / 2x (max-rel) of what the reference ITSELF loses under
+    rel-L2 / 5e-4 max-rel.  bf16: within 1.2x (rel-L2; 1.5x until round 5: measured 0.80-1.02x) / 2x (max-rel) of what the reference ITSELF loses under
     torch.autocast(bfloat16) on the CPU (recorded in the fixture), floors 3e-2 / 5e-2: the reference's autocast keeps GroupNorm and
     the residual stream in fp32, ours stores every tensor between kernels in bf16.  copies=16 replicates the image (every parameter
     gradient is 16x the reference's): the 256^2 / 128^2 layers then run the wide / LDS-DMA kernels with several tiles per work-group."""
@@ -57,7 +57,7 @@ def test_img256_decoder_backward_with_reference_drec(golden_dir, mode, copies):
     for k, got, ref in items:
         e2, em = rel_l2(got, ref), relerr(got, ref)
         r2, rm = float(g["refbf16_l2:" + k]), float(g["refbf16_max:" + k])
-        lim2, limm = (2e-4, 5e-4) if mode == "fp32" else (max(1.5 * r2, 3e-2), max(2.0 * rm, 5e-2))
+        lim2, limm = (2e-4, 5e-4) if mode == "fp32" else (max(1.2 * r2, 3e-2), max(2.0 * rm, 5e-2))
         print("  %s copies=%d %-40s rel-L2 %.3e max-rel %.3e   (reference's own bf16 autocast: %.3e / %.3e)" % (mode, copies, k, e2, em, r2, rm))
         if e2 > lim2 or em > limm:
             bad.append((k, e2, em, lim2, limm))

@@ -48,7 +48,21 @@ def measure(name, cmd, files, tail_s, env=None, flops=None):
     return ms, tfs, avg(mhz), avg(w)
 
 
+def main_up2(sec):
+    """joules per launch of the Upsample convolution (128 -> 128, 128^2 -> 256^2, batch 32) in its sub-pixel form against the 3x3 kernel
+    with the x2 folded into the addresses (MAS_CONV_UP2=0): fewer FLOPs are fewer joules, and under the cap joules are time"""
+    files = _find()
+    print("sources:", files)
+    kb = [sys.executable, os.path.join(ROOT, "tools", "kbench.py")]
+    for c, hw in ((128, 128), (256, 64), (512, 32)):
+        base = kb + ["conv_fwd", "--c", str(c), "--hw", str(hw), "--ups", "1", "--stats", "1"]
+        measure(f"Upsample conv {c}->{c} @{hw}->{2*hw}: sub-pixel (conv_up2)", base + ["--iters", str(int(sec / 0.3e-3))], files, sec - 1.5, env={"MAS_CONV_UP2": "1"})
+        measure(f"Upsample conv {c}->{c} @{hw}->{2*hw}: 3x3 at the high resolution", base + ["--iters", str(int(sec / 0.5e-3))], files, sec - 1.5, env={"MAS_CONV_UP2": "0"})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "up2":
+        return main_up2(float(sys.argv[2]) if len(sys.argv) > 2 else 5.0)
     sec = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
     files = _find()
     print("sources:", files)
