@@ -222,6 +222,13 @@ int mas_wgrad_reduce(const float* part, const float* part_bias, int nsplit, floa
 int mas_conv_up2_supported(const MasConvDesc* d);
 int mas_conv_up2_dgrad_supported(const MasConvDesc* d);
 int mas_conv_up2_dgrad(const MasConvDesc* d, const void* dy, const void* w_packed_t, void* dx, void* stream);
+/* The weight gradient of the same layer in the same form (conv_wgrad_dma.hip with 2x2 taps per phase): mas_conv_up2_wgrad_splits(d) =
+ * slabs PER PHASE (0: unsupported, take mas_conv_wgrad_partial); mas_conv_up2_wgrad_partial writes part [4][nsplit][Cout][2][2][Cin] fp32
+ * and (when non-NULL) part_bias [4 * nsplit][Cout], every element once, plain stores; mas_wgrad_reduce_up2 adds the slabs in a fixed
+ * order and folds the 4 x 4 phase taps into dw_oihw [Cout][Cin][3][3] / dbias [Cout] (bitwise reproducible run to run).              */
+int mas_conv_up2_wgrad_splits(const MasConvDesc* d);
+int mas_conv_up2_wgrad_partial(const MasConvDesc* d, const void* x, const void* dy, float* part, float* part_bias, void* stream);
+int mas_wgrad_reduce_up2(const float* part, const float* part_bias, int nsplit, float* dw_oihw, float* dbias, int Cout, int Cin, void* stream);
 
 /* ---- vector quantiser  (replaces Codebook.forward's distance / argmin / gather / loss,
  * modules.py:501-509; never materialises d[M,K]).

@@ -32,6 +32,9 @@ struct DmaWgradParams {
     int Hl, Wl, pad_top, pad_left, act, upsample;
     int tiles_h, tiles_w, n_pt, n_co_t, n_ci_t, nsplit;
     unsigned long long* dbg;                       // -DD_TIMELINE builds only
+    // KS = 2 (the sub-pixel form of Upsample + conv, see below): dy is the HIGH-resolution tensor walked as four phase images
+    int dy_px, dy_row, dy_ph_px, dy_ph_row;        // bytes between low-resolution neighbours of a phase image; offset of phase column / row
+    unsigned dy_img, dy_bytes;                     // bytes of one image of dy / of the whole tensor
 };
 
 constexpr int D_THW = 8, D_TWW = 16, D_PH = 10, D_PW = 18, D_NPP = 180;
@@ -77,8 +80,16 @@ template <int I> struct d_ic { static constexpr int v = I; };
 //            4.6k cycles of MFMA pipe and serialise on top of that (measured 7.5k); four waves would each carry half the instruction
 //            stream.  It does not fit: 80 + 24 fragment registers leave 24 of the 128-register cap for everything else, the
 //            compiler spills 88 registers into the loop.
-template <bool ACT, int SPLIT>
+// KS = 2 (round 5): the weight gradient of `Upsample` + 3x3 (reference models/modules.py:44-59) in its sub-pixel form (conv_up2.hip): for
+// output phase (a, b) the phase image dy_ab[i][j] = dy[2i + a][2j + b] is correlated with the 2x2 window x[i + a - 1 + r][j + b - 1 + s] of the
+// LOW-resolution input -- 16 tap-correlations per low-resolution pixel instead of 36.  Same kernel: the grid carries the phase
+// (blockIdx % 4), the patch origin moves by (a, b) (pad_top = 1 - a, pad_left = 1 - b), the dY DMA plan walks dy at pixel stride 2, a
+// tile accumulates 4 taps instead of 9 (its step 9 is idle), and the slab of a work-group is [Cout][2x2][Cin] behind the phase's slabs;
+// mas_wgrad_reduce_up2 folds the 4 x 4 phase taps back into the 3x3 gradient.  The launch is HBM-bound (dy once, x four times = the
+// same bytes as the 3x3 form, 2.25x fewer MFMAs).
+template <bool ACT, int SPLIT, int KS = 3>
 __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradParams p) {
+    static_assert(KS == 3 || (KS == 2 && SPLIT == 1 && !ACT), "the 2x2 phase form: prologue-free, 8 waves");
     constexpr int NW = 8 * SPLIT, NT = 512 * SPLIT;
     constexpr int DYK = 4 / SPLIT;                 // dY pieces per wave
     constexpr int XK = SPLIT == 1 ? 3 : 2;         // patch piece slots per wave (piece = wave + NW k, valid below 23)
@@ -95,12 +106,15 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
     const int wco = (wt & 3) * 32, wci = (wt >> 2) * 32;
 
     int bid = blockIdx.x;
+    const int phase = KS == 2 ? bid & 3 : 0;       // (a, b) = (phase >> 1, phase & 1)
+    if constexpr (KS == 2) bid >>= 2;
+    const int pad_top = KS == 2 ? 1 - (phase >> 1) : p.pad_top, pad_left = KS == 2 ? 1 - (phase & 1) : p.pad_left;
     const int split = bid % p.nsplit; bid /= p.nsplit;
     const int ci_t = bid % p.n_ci_t; const int co_t = bid / p.n_ci_t;
     const int co0 = co_t * 128, ci0 = ci_t * 64;
     const int n_mine = (p.n_pt - split + p.nsplit - 1) / p.nsplit;     // tiles of this work-group: split, split + nsplit, ...
 
-    const d_i32x4 rs_dy = d_rsrc(p.dy, (unsigned)((size_t)p.N * p.Ho * p.Wo * p.Cout * 2));
+    const d_i32x4 rs_dy = d_rsrc(p.dy, KS == 2 ? p.dy_bytes : (unsigned)((size_t)p.N * p.Ho * p.Wo * p.Cout * 2));
     const d_i32x4 rs_x = d_rsrc(p.x, (unsigned)((size_t)p.N * p.H * p.W * p.Cin * 2));
     const d_i32x4 rs_ss = d_rsrc(p.ss, ACT ? (unsigned)((size_t)p.N * p.Cin * 8) : 0u);
 
@@ -113,10 +127,11 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
     struct TC { int n, h0, w0, idx, ud, ux; bool fd, fx; };
     const int ups = p.upsample ? 1 : 0;
     auto finish_tc = [&](TC& c) {
-        c.ud = (((c.n * p.Ho + c.h0 + wave) * p.Wo + c.w0) * p.Cout + co0) * 2;
+        if constexpr (KS == 2) c.ud = (int)((unsigned)c.n * p.dy_img) + (c.h0 + wave) * p.dy_row + c.w0 * p.dy_px + (phase >> 1) * p.dy_ph_row + (phase & 1) * p.dy_ph_px + co0 * 2;
+        else c.ud = (((c.n * p.Ho + c.h0 + wave) * p.Wo + c.w0) * p.Cout + co0) * 2;
         c.ux = (((c.n * p.H + (c.h0 >> ups)) * p.W + (c.w0 >> ups)) * p.Cin + ci0) * 2;
         c.fd = (c.h0 + D_THW <= p.Ho) && (c.w0 + D_TWW <= p.Wo);
-        c.fx = (c.h0 >= p.pad_top) && (c.h0 - p.pad_top + D_PH <= p.Hl) && (c.w0 >= p.pad_left) && (c.w0 - p.pad_left + D_PW <= p.Wl);
+        c.fx = (c.h0 >= pad_top) && (c.h0 - pad_top + D_PH <= p.Hl) && (c.w0 >= pad_left) && (c.w0 - pad_left + D_PW <= p.Wl);
     };
     const int adv_w = (p.nsplit % p.tiles_w) * D_TWW, adv_q = p.nsplit / p.tiles_w;
     const int adv_h = (adv_q % p.tiles_h) * D_THW, adv_n = adv_q / p.tiles_h;
@@ -144,14 +159,15 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
     // pixel P = 8 (wave + NW k) + (lane >> 3) -> (pr, pc) relative to the tile's (h0 - pad_top, w0 - pad_left); with the Upsample fold
     // (h0, w0 even) the source pixel is ((h0 >> 1) + ((pr - pad_top) >> 1), ...).  Dead lanes (P >= 180) carry the out-of-range marker.
     static_assert(SPLIT == 1 || true, "");
-    const int dyL = ((lane >> 4) * p.Cout + ((((lane >> 2) & 3) ^ ((lane >> 4) & 3)) * 32) + (lane & 3) * 8) * 2;
+    const int dy_px = KS == 2 ? p.dy_px : p.Cout * 2;            // bytes between horizontally adjacent pixels of the (phase) image
+    const int dyL = (lane >> 4) * dy_px + (((((lane >> 2) & 3) ^ ((lane >> 4) & 3)) * 32) + (lane & 3) * 8) * 2;
     int xL[XK], prpc[XK];                          // prpc: patch row | patch column << 8 of the lane's pixel (the bounds test of edge tiles)
 #pragma unroll
     for (int k = 0; k < XK; ++k) {
         const int P = (wave + NW * k) * 8 + (lane >> 3);
         const int pr = (P * 3641) >> 16, pc = P - pr * D_PW;
         prpc[k] = pr | (pc << 8);
-        const int r = (pr - p.pad_top) >> ups, cc = (pc - p.pad_left) >> ups;           // arithmetic shifts: -1 >> 1 == -1
+        const int r = (pr - pad_top) >> ups, cc = (pc - pad_left) >> ups;               // arithmetic shifts: -1 >> 1 == -1
         const int blk = ((lane >> 2) & 1) ^ ((P >> 1) & 1);
         xL[k] = (P < D_NPP) ? ((r * p.W + cc) * p.Cin + blk * 32 + (lane & 3) * 8) * 2 : D_OOB;
     }
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
         const int piece = wave * DYK + k;
         int vo;
         if constexpr (SPLIT == 1) {                 // pixel row `wave`, column 4 k + (lane >> 4): lane constant + uniform base
-            vo = dyL + (c.ud + k * 8 * p.Cout);
+            vo = dyL + (c.ud + k * 4 * dy_px);
             if (!c.fd) {                            // ragged tile (uniform branch): rows / columns past the map read as zeros
                 const bool ok = (c.h0 + wave < p.Ho) && (c.w0 + 4 * k + (lane >> 4) < p.Wo);
                 vo = ok ? vo : D_OOB;
@@ -184,7 +200,7 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
     // block (lane >> 2) & 1 holding logical block ^ ((pixel >> 1) & 1), slot lane & 3
     auto x_inb = [&](int k, const TC& c) -> bool {                // is the lane's patch pixel a pixel of the image (else: zero padding)
         const int pr = prpc[k] & 0xff, pc = prpc[k] >> 8;
-        return (unsigned)(c.h0 - p.pad_top + pr) < (unsigned)p.Hl && (unsigned)(c.w0 - p.pad_left + pc) < (unsigned)p.Wl;
+        return (unsigned)(c.h0 - pad_top + pr) < (unsigned)p.Hl && (unsigned)(c.w0 - pad_left + pc) < (unsigned)p.Wl;
     };
     auto x_issue = [&](const TC& c, int buf, int k) {
         if (wave + NW * k >= 23) return;
@@ -283,10 +299,10 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
     // iteration's barrier.  Every wave waits for its own pieces (vmcnt(0)) before it arrives.
     // Buffers: dY(t) in t & 1 (last read in step 7 of its tile, before the barrier that precedes the first write of dY(t+2));
     // patch(t) in t % 3 (read until step 8 of iteration t, AFTER that iteration's barrier, hence the third buffer).
-    f32x16 acc[SPLIT == 1 ? 9 : 5];
+    f32x16 acc[SPLIT == 1 ? KS * KS : 5];
     auto run = [&](auto HALF_T) {
         constexpr int HALF = decltype(HALF_T)::v;
-        constexpr int LO = SPLIT == 1 ? 0 : (HALF ? 5 : 0), HI = SPLIT == 1 ? 9 : (HALF ? 9 : 5);
+        constexpr int LO = SPLIT == 1 ? 0 : (HALF ? 5 : 0), HI = SPLIT == 1 ? KS * KS : (HALF ? 9 : 5);
 #ifdef D_NO_ACT_PREFETCH   // A/B builds: round 2's rule (the prologue variant spent those 12 registers on address temporaries)
         constexpr bool PREFETCH = SPLIT == 1 && !ACT;
 #else
@@ -303,9 +319,9 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
         auto kw_needed = [&](int pr, int kw) {                    // does step pr of this wave use the patch fragment kw ?
             bool need = false;
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int t = kh * 3 + kw, rr = pr - kh;
-                if (t >= LO && t < HI && rr >= 0 && rr < D_THW) need = true;
+            for (int kh = 0; kh < KS; ++kh) {
+                const int t = kh * KS + kw, rr = pr - kh;
+                if (kw < KS && t >= LO && t < HI && rr >= 0 && rr < D_THW) need = true;
             }
             return need;
         };
@@ -354,10 +370,10 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
         };
         auto mfma_kh = [&](int pr, int kh) {
             const int rr = pr - kh;
-            if (rr < 0 || rr >= D_THW) return;
+            if (rr < 0 || rr >= D_THW || kh >= KS) return;
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int t = kh * 3 + kw;
+            for (int kw = 0; kw < KS; ++kw) {
+                const int t = kh * KS + kw;
                 if (t < LO || t >= HI) continue;
 #ifdef D_ABL_NOMFMA     // timing experiment only
                 acc[t - LO][0] += (float)aw[rr % 3][0] + (float)bf[PREFETCH ? (pr & 1) : 0][kw][0];
@@ -459,13 +475,13 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
             // this work-group's own slab of the partial table: plain coalesced stores (a half-wave writes 128 consecutive bytes).  The
             // fp32 atomics they replace cost 45-60 us per launch on every shape but the largest (18.9 M read-modify-writes at the L2:
             // profiles/r03_wgrad_commit.txt) and made the sums depend on arrival order
-            float* pw = p.part + (size_t)split * ((size_t)p.Cout * 9 * p.Cin);
+            float* pw = p.part + (size_t)(phase * p.nsplit + split) * ((size_t)p.Cout * (KS * KS) * p.Cin);
 #pragma unroll
             for (int t = LO; t < HI; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + wco + acc_row(lane, r);
-                    pw[((size_t)co * 9 + t) * p.Cin + ci] = acc[t - LO][r];
+                    pw[((size_t)co * (KS * KS) + t) * p.Cin + ci] = acc[t - LO][r];
                 }
         } else {
 #pragma unroll
@@ -490,15 +506,15 @@ __global__ __launch_bounds__(512 * SPLIT) void conv_wgrad_dma_kernel(DmaWgradPar
         if (tid < 128) {
             float t = 0.0f;
             for (int k = 0; k < NT / 16; ++k) t += red[k * 128 + tid];
-            if (p.part_bias) p.part_bias[(size_t)split * p.Cout + co0 + tid] = t;
+            if (p.part_bias) p.part_bias[(size_t)(phase * p.nsplit + split) * p.Cout + co0 + tid] = t;
             else atomicAdd(p.dbias + co0 + tid, t);
         }
     }
 }
 
-template <bool ACT, int SPLIT>
+template <bool ACT, int SPLIT, int KS = 3>
 int launch_dma(DmaWgradParams p, hipStream_t s) {
-    auto kern = conv_wgrad_dma_kernel<ACT, SPLIT>;
+    auto kern = conv_wgrad_dma_kernel<ACT, SPLIT, KS>;
     static mas_devmask_t attr_mask{0};
     unsigned long long attr_bit;
     if (mas_attr_needed(attr_mask, &attr_bit)) {
@@ -506,8 +522,8 @@ int launch_dma(DmaWgradParams p, hipStream_t s) {
             MAS_FAIL(MAS_ELAUNCH, "conv_wgrad_dma: cannot set dynamic LDS size %d", D_LDS);
         mas_attr_done(attr_mask, attr_bit);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.n_co_t * p.n_ci_t * p.nsplit)), dim3(512 * SPLIT), D_LDS, s, p);
-    MAS_CHECK_LAUNCH("conv_wgrad_dma");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.n_co_t * p.n_ci_t * p.nsplit * (KS == 2 ? 4 : 1))), dim3(512 * SPLIT), D_LDS, s, p);
+    MAS_CHECK_LAUNCH(KS == 2 ? "conv_wgrad_up2" : "conv_wgrad_dma");
     return MAS_OK;
 }
 
@@ -608,4 +624,48 @@ extern "C" int mas_conv_wgrad_partial(const MasConvDesc* d, const void* x, const
     p.x = (const unsigned char*)x; p.ss = scale_shift; p.dy = (const unsigned char*)dy; p.dw = nullptr; p.dbias = nullptr;
     p.part = part; p.part_bias = part_bias;
     return dma_launch(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- Upsample + conv, sub-pixel form: the weight gradient as split-K partials of the 4 x 2x2 phase correlations (KS = 2 above) --------
+// d describes the FORWARD convolution (upsample = 1; H x W the input map, Ho x Wo = 2H x 2W, 3x3, stride 1, pads 1, bf16, no prologue).
+static bool up2_wgrad_setup(const MasConvDesc* d, DmaWgradParams& p) {
+    static const int mode = mas_env_int("MAS_CONV_UP2_WGRAD", 1), mode_all = mas_env_int("MAS_CONV_UP2", 1);
+    if (!mode || !mode_all || !d) return false;
+    if (!d->upsample || d->ks != 3 || d->stride != 1 || d->pad_top != 1 || d->pad_left != 1 || d->act != MAS_ACT_NONE) return false;
+    if (d->in_dtype != MAS_BF16 || d->Ho != 2 * d->H || d->Wo != 2 * d->W || d->N <= 0 || d->H <= 0 || d->W <= 0) return false;
+    if (d->Cin % 64 != 0 || d->Cout % 128 != 0) return false;
+    const long long xb = (long long)d->N * d->H * d->W * d->Cin * 2, yb = (long long)d->N * d->Ho * d->Wo * d->Cout * 2;
+    if (xb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return false;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->H; p.Wo = d->W; p.Cout = d->Cout;      // the tiles walk the LOW-resolution grid
+    p.Hl = d->H; p.Wl = d->W; p.pad_top = 1; p.pad_left = 1; p.act = MAS_ACT_NONE; p.upsample = 0;
+    p.tiles_h = mas_cdiv(p.Ho, D_THW); p.tiles_w = mas_cdiv(p.Wo, D_TWW);
+    p.n_pt = p.N * p.tiles_h * p.tiles_w;
+    p.n_co_t = d->Cout / 128; p.n_ci_t = d->Cin / 64;
+    p.dbg = nullptr; p.ss = nullptr;
+    p.dy_ph_px = d->Cout * 2; p.dy_ph_row = d->Wo * d->Cout * 2; p.dy_px = 2 * p.dy_ph_px; p.dy_row = 2 * p.dy_ph_row;
+    p.dy_img = (unsigned)((size_t)d->Ho * d->Wo * d->Cout * 2); p.dy_bytes = (unsigned)yb;
+    static const int oversub = mas_env_int("MAS_WGRAD_OVERSUB", 1);
+    int nsplit = mas_cdiv(mas_num_cus() * (oversub > 0 ? oversub : 1), p.n_co_t * p.n_ci_t * 4);      // per phase: the four phases fill the chip together
+    if (nsplit > p.n_pt) nsplit = p.n_pt;
+    if (nsplit < 1) nsplit = 1;
+    p.nsplit = nsplit;
+    // narrow maps waste the 8 x 16-pixel tiles (and conv_up2's forward keeps them on the 3x3 kernels too): same rule as the forward
+    static const int any_width = mas_env_int("MAS_CONV_WIDE_ANY_WIDTH", 0);
+    if (!any_width && d->W < 32) return false;
+    return true;
+}
+
+// slabs PER PHASE (the partial table holds 4 x that many slabs of [Cout][2x2][Cin], the bias table 4 x that many rows), 0 = unsupported
+extern "C" int mas_conv_up2_wgrad_splits(const MasConvDesc* d) {
+    DmaWgradParams p;
+    return up2_wgrad_setup(d, p) ? p.nsplit : 0;
+}
+
+extern "C" int mas_conv_up2_wgrad_partial(const MasConvDesc* d, const void* x, const void* dy, float* part, float* part_bias, void* stream) {
+    MAS_ENTER();
+    if (!d || !x || !dy || !part) MAS_FAIL(MAS_EINVAL, "conv_up2_wgrad_partial: null argument");
+    DmaWgradParams p;
+    if (!up2_wgrad_setup(d, p)) MAS_FAIL(MAS_EUNSUPPORTED, "conv_up2_wgrad_partial: unsupported convolution (mas_conv_up2_wgrad_splits == 0)");
+    p.x = (const unsigned char*)x; p.dy = (const unsigned char*)dy; p.dw = nullptr; p.dbias = nullptr; p.part = part; p.part_bias = part_bias;
+    return launch_dma<false, 1, 2>(p, reinterpret_cast<hipStream_t>(stream));
 }

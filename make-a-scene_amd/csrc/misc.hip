@@ -562,6 +562,78 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// ---- Upsample + conv, sub-pixel form (conv_up2.hip, conv_wgrad_dma.hip KS = 2): part [4 phases][nsplit][Cout][2x2][Cin] -> dw OIHW 3x3.
+// dWp[a][b][r][s] (the fixed-order sum of the phase's slabs) is the gradient of the phase weight Wp[a][b][r][s] = sum of W[kh][kw] over
+// kh in R(a, r), kw in R(b, s); so dW[kh][kw] = sum over (a, b) of dWp[a][b][r(a, kh)][s(b, kw)], r(0, .) = {0, 1, 1}, r(1, .) = {0, 0, 1}.
+// A block owns (one output channel) x (64 input channels): thread (q, g) sums slabs g, g + 8, ... of its four input channels for all
+// 16 phase taps, the eight group sums are added in order (bitwise reproducible), the 64 x 9 results leave as one contiguous run.
+__global__ __launch_bounds__(128) void wgrad_reduce_up2_kernel(const float* __restrict__ part, const float* __restrict__ part_bias, int nsplit,
+                                                               float* __restrict__ dw, float* __restrict__ db, int Cout, int Cin, int ci_chunks) {
+    __shared__ float red[8][16][64];                                // [slab group][phase tap][ci]: 32 KiB
+    const int nwb = Cout * ci_chunks;
+    if ((int)blockIdx.x >= nwb) {                                   // bias: part_bias [4 * nsplit][Cout]
+        const int o = ((int)blockIdx.x - nwb) * 128 + (int)threadIdx.x;
+        if (o < Cout) {
+            float acc = 0.0f;
+            for (int sp = 0; sp < 4 * nsplit; ++sp) acc += part_bias[(long long)sp * Cout + o];
+            db[o] = acc;
+        }
+        return;
+    }
+    const int o = (int)blockIdx.x / ci_chunks, i0 = ((int)blockIdx.x % ci_chunks) * 64;
+    const int q = threadIdx.x & 15, g = threadIdx.x >> 4;            // 16 float4 lanes x 8 slab groups
+    const int i = i0 + q * 4;
+    const long long slab = (long long)Cout * 4 * Cin;
+    if (i < Cin) {
+        f32x4 acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int sp = g; sp < nsplit; sp += 8) {
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                const float* src = part + ((long long)ph * nsplit + sp) * slab + ((long long)o * 4) * Cin + i;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[ph * 4 + t] += *reinterpret_cast<const f32x4*>(src + (long long)t * Cin);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4*>(&red[g][k][q * 4]) = acc[k];
+    }
+    __syncthreads();
+    const int ni = Cin - i0 < 64 ? Cin - i0 : 64;
+    float* dst = dw + ((long long)o * Cin + i0) * 9;                 // [i][kh][kw]
+    for (int j = threadIdx.x; j < ni * 9; j += 128) {
+        const int il = j / 9, t = j - il * 9, kh = t / 3, kw = t - kh * 3;
+        float v = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int r = a == 0 ? (kh > 0) : (kh > 1), s_ = b == 0 ? (kw > 0) : (kw > 1);
+                const int k = (2 * a + b) * 4 + 2 * r + s_;
+                float u = 0.0f;
+#pragma unroll
+                for (int gg = 0; gg < 8; ++gg) u += red[gg][k][il];
+                v += u;
+            }
+        dst[j] = v;
+    }
+}
+
+extern "C" int mas_wgrad_reduce_up2(const float* part, const float* part_bias, int nsplit, float* dw_oihw, float* dbias, int Cout, int Cin,
+                                    void* stream) {
+    MAS_ENTER();
+    if (!part || !dw_oihw || nsplit <= 0 || Cout <= 0 || Cin <= 0) MAS_FAIL(MAS_EINVAL, "wgrad_reduce_up2: bad argument");
+    if (dbias && !part_bias) MAS_FAIL(MAS_EINVAL, "wgrad_reduce_up2: dbias without part_bias");
+    if (Cin % 4 != 0 || (reinterpret_cast<uintptr_t>(part) & 15)) MAS_FAIL(MAS_EINVAL, "wgrad_reduce_up2: Cin % 4 == 0 and a 16-byte aligned table required");
+    const int ci_chunks = (Cin + 63) / 64;
+    const long long blocks = (long long)Cout * ci_chunks + (dbias ? (Cout + 127) / 128 : 0);
+    hipLaunchKernelGGL(wgrad_reduce_up2_kernel, dim3((unsigned)blocks), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), part, part_bias, nsplit,
+                       dw_oihw, dbias, Cout, Cin, ci_chunks);
+    MAS_CHECK_LAUNCH("wgrad_reduce_up2");
+    return MAS_OK;
+}
+
 extern "C" int mas_wgrad_reduce(const float* part, const float* part_bias, int nsplit, float* dw_oihw, float* dbias, int Cout, int Cin,
                                 int ks, void* stream) {
     MAS_ENTER();

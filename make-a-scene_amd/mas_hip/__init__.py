@@ -81,6 +81,9 @@ _SIGNATURES = {
     "mas_conv_up2_supported": (_i, [C.POINTER(ConvDesc)]),
     "mas_conv_up2_dgrad_supported": (_i, [C.POINTER(ConvDesc)]),
     "mas_conv_up2_dgrad": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p]),
+    "mas_conv_up2_wgrad_splits": (_i, [C.POINTER(ConvDesc)]),
+    "mas_conv_up2_wgrad_partial": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p]),
+    "mas_wgrad_reduce_up2": (_i, [_p, _p, _i, _p, _p, _i, _i, _p]),
     "mas_conv_wgrad_splits": (_i, [C.POINTER(ConvDesc)]),
     "mas_conv_wgrad_partial": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
     "mas_wgrad_reduce": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _p]),

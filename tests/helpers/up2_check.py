@@ -53,6 +53,8 @@ def run_case(case, dev, sample=None, tol=1e-2, check_stats=True):
     dfw = ops._desc(n, h, w, cin, 2 * h, 2 * w, cout, 3, 1, 1, 1, torch.bfloat16, torch.bfloat16, 0, True)
     if ops._up2_supported(dfw, True):                  # (128-channel output tiles, at least one tile per CU: else the 3x3 kernels at the high resolution)
         assert kinds.get("conv_up2_dgrad") == "conv_up2_dgrad", seen
+    if ops._up2_wgrad_splits(dfw) > 0:                 # the weight gradient in the phase form too (conv_wgrad_dma.hip KS = 2 + mas_wgrad_reduce_up2)
+        assert kinds.get("conv_wgrad") == "conv_wgrad_up2", seen
     e_y, e_x = _rel(y[sample], ref), _rel(xd.grad[sample], xs.grad)
     e_w, e_b = _rel(wd.grad, ws.grad), _rel(bd.grad, bs.grad)
     print(case, "fwd %.2e dgrad %.2e wgrad %.2e dbias %.2e" % (e_y, e_x, e_w, e_b))

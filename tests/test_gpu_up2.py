@@ -129,9 +129,9 @@ def test_bitwise_reproducible_and_follows_the_optimizer():
         y = ops.norm_act_conv(x, w, None, stride=1, padding=(1, 1, 1, 1), upsample=True)
         assert ops.last_kernel() == "conv_up2_fwd"
         y.float().square().mean().backward()
-        outs.append((y.detach().clone(), x.grad.clone()))
+        outs.append((y.detach().clone(), x.grad.clone(), w.grad.clone()))
         w.grad = None
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert all(torch.equal(u, v) for u, v in zip(outs[0], outs[1]))          # forward, data gradient and weight gradient: bitwise run to run
     y0 = outs[0][0]
     ops.norm_act_conv(x, w, None, stride=1, padding=(1, 1, 1, 1), upsample=True).float().square().mean().backward()
     opt.step()

@@ -166,3 +166,53 @@ def test_stream_kernel_staging_plan_covers_the_halo_patch_once(th):
     assert pix == list(range(th * 16))
     # deferred stores: 4 NJ per lane, one per stage, all within the 8 stages that follow the tile
     assert 4 * nj <= 8
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# conv_up2.hip (round 5): `Upsample` + 3x3 (reference models/modules.py:44-59) as four 2x2 phase convolutions on the low-resolution map
+# ---------------------------------------------------------------------------------------------------------------------------------
+_R = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}          # 3x3 taps behind window position r of phase a
+
+
+def _phase_weights(wt):
+    """Wp[a][b][r][s] = sum of W[kh][kw] over kh in R(a, r), kw in R(b, s) (MAS_WLAYOUT_UP2, include/mas_hip.h)"""
+    wp = {}
+    for a in (0, 1):
+        for b in (0, 1):
+            for r in (0, 1):
+                for s in (0, 1):
+                    wp[a, b, r, s] = sum(wt[:, :, kh, kw] for kh in _R[a, r] for kw in _R[b, s])
+    return wp
+
+
+@pytest.mark.parametrize("h,w", [(5, 7), (8, 8), (1, 3)])
+def test_upsample_conv_is_four_phase_convolutions(h, w):
+    """forward: y[2i + a][2j + b] = sum over (r, s) of Wp[a][b][r][s] x[i + a - 1 + r][j + b - 1 + s] (zero outside the map);
+    data gradient: dx[i][j] = sum over (a, b, r, s) of Wp[a][b][r][s]^T dy[2 (i + 1 - a - r) + a][2 (j + 1 - b - s) + b]
+    -- the two index maps conv_up2_kernel walks (patch offset (a, b) forward, (1 - a, 1 - b) with flipped taps backward)"""
+    n, cin, cout = 2, 3, 4
+    x = _rand(n, cin, h, w, seed=11).requires_grad_(True)
+    wt = _rand(cout, cin, 3, 3, seed=12)
+    y_ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wt, padding=1)
+    dy = _rand(*y_ref.shape, seed=13)
+    y_ref.backward(dy)
+    wp = _phase_weights(wt)
+    xd = x.detach()
+    xp = F.pad(xd, (1, 1, 1, 1))                           # xp[i + 1] = x[i]
+    y = torch.zeros_like(y_ref)
+    for a in (0, 1):
+        for b in (0, 1):
+            for r in (0, 1):
+                for s in (0, 1):
+                    win = xp[:, :, a + r:a + r + h, b + s:b + s + w]                    # x[i + a - 1 + r][j + b - 1 + s]
+                    y[:, :, a::2, b::2] += torch.einsum("oc,nchw->nohw", wp[a, b, r, s], win)
+    assert torch.allclose(y, y_ref.detach(), rtol=1e-12, atol=1e-12)
+    dx = torch.zeros_like(xd)
+    for a in (0, 1):
+        for b in (0, 1):
+            dph = F.pad(dy[:, :, a::2, b::2], (1, 1, 1, 1))                             # phase image of dy, dph[i + 1] = D_ab[i]
+            for r in (0, 1):
+                for s in (0, 1):
+                    win = dph[:, :, 2 - a - r:2 - a - r + h, 2 - b - s:2 - b - s + w]   # D_ab[i + 1 - a - r][j + 1 - b - s]
+                    dx += torch.einsum("oc,nohw->nchw", wp[a, b, r, s], win)
+    assert torch.allclose(dx, x.grad, rtol=1e-12, atol=1e-12)

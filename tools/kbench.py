@@ -60,9 +60,12 @@ def main():
         p = a.ks // 2
         flops = 2.0 * a.ks * a.ks * c * co * n * h * h
         if a.kind == "wgrad":
-            dy = torch.randn(n, co, h, h, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
-            fn = lambda: ops.conv_wgrad_raw(x, ss, dy, n, h, h, c, h, h, co, a.ks, 1, p, p, a.act, False, True)
+            ho = 2 * h if a.ups else h             # --ups 1: Upsample's convolution (x is the low-resolution map, dy the x2 one)
+            dy = torch.randn(n, co, ho, ho, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
+            fn = lambda: ops.conv_wgrad_raw(x, ss, dy, n, h, h, c, ho, ho, co, a.ks, 1, p, p, a.act, bool(a.ups), True)
             byt = (x.numel() + dy.numel()) * esz
+            if a.ups:
+                flops *= 4.0
         else:
             wp = ops.ConvWeight(torch.nn.Parameter(w), a.kind == "dgrad")   # packed (once: the Parameter is cached) in the layout the library prefers
             res = torch.randn(n, co, h, h, device=dev).to(dt).contiguous(memory_format=torch.channels_last) if a.res else None
