@@ -203,3 +203,43 @@ def test_encoder_backward_distinct_images_vs_oracle_gradients(mode):
         assert worst < gate, worst
     finally:
         ops.set_compute_dtype(old)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# 3. MAS_SAVE_ACT=0: the weight gradients recompute the GroupNorm+SiLU activation in their loaders instead of reading the saved tensor
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_save_activations_switch_gives_the_same_gradients_with_less_memory():
+    """``ops.set_save_activations(False)``: same forward, the materialised activation is not kept, the weight
+    gradient's fused prologue forms it again from x and the scale / shift table -- rounded exactly as ``mas_gn_act`` rounds it, so the
+    gradients agree to the summation order of the two weight-gradient instantiations; the saved-tensor high-water mark drops."""
+    from mas_hip import ops
+    from models.modules import ResnetBlock
+    dev = _dev()
+    old = ops.compute_dtype()
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(3)
+        blk = ResnetBlock(in_channels=128, out_channels=128, dropout=0.0).to(dev)
+        x = torch.randn(8, 128, 64, 64, device=dev).bfloat16().float()
+        dy = torch.randn(8, 128, 64, 64, device=dev)
+        res = {}
+        for keep in (True, False):
+            ops.set_save_activations(keep)
+            blk.zero_grad(set_to_none=True)
+            xd = x.clone().requires_grad_(True)
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats(dev)
+            base = torch.cuda.memory_allocated(dev)
+            y = blk(xd)
+            held = torch.cuda.memory_allocated(dev) - base           # what the autograd graph keeps alive after the forward
+            y.backward(dy.to(y.dtype))
+            torch.cuda.synchronize()
+            res[keep] = (y.detach().clone(), xd.grad.clone(), {k: v.grad.clone() for k, v in blk.named_parameters()}, held)
+        assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+        for k in res[True][2]:
+            assert _rel(res[False][2][k], res[True][2][k]) < 2e-3, k
+        act_bytes = 2 * 8 * 128 * 64 * 64 * 2                       # the two activation tensors of the block, bf16
+        assert res[True][3] - res[False][3] >= 0.9 * act_bytes, (res[True][3], res[False][3])
+    finally:
+        ops.set_save_activations(True)
+        ops.set_compute_dtype(old)

@@ -21,21 +21,28 @@ KB="timeout 100 python tools/kbench.py"
   for act in 0 2; do MAS_WGRAD_DMA=0 $KB wgrad --n 32 --c 128 --hw 256 --act $act | tail -1; done
   echo "-- other shapes"
   $KB gn_stats --n 32 --c 128 --hw 256 | tail -1
-  $KB gn_bwd --n 32 --c 128 --hw 256 | grep "^gn_bwd"
+  $KB gn_bwd --n 32 --c 128 --hw 256 --three 1 | grep "^gn_bwd"
   $KB vq --n 32 | tail -1
   for s in "512 32" "256 64" "128 128" "256 128" "512 64"; do set -- $s
     $KB conv_fwd --n 32 --c $1 --hw $2 --act 2 | tail -1; $KB wgrad --n 32 --c $1 --hw $2 --act 2 | tail -1
   done
+  echo "-- Upsample + conv (sub-pixel form: conv_up2.hip, conv_wgrad_dma KS = 2), forward with statistics / weight gradient; then the same on the 3x3 kernels"
+  for s in "128 128" "256 64" "512 32"; do set -- $s
+    $KB conv_fwd --n 32 --c $1 --hw $2 --ups 1 --stats 1 | tail -1; $KB wgrad --n 32 --c $1 --hw $2 --ups 1 | tail -1
+  done
+  for s in "128 128" "256 64" "512 32"; do set -- $s
+    MAS_CONV_UP2=0 $KB conv_fwd --n 32 --c $1 --hw $2 --ups 1 --stats 1 | tail -1; MAS_CONV_UP2=0 $KB wgrad --n 32 --c $1 --hw $2 --ups 1 | tail -1
+  done
   $KB conv_fwd --n 32 --c 128 --hw 256 --stride 2 | tail -1
   $KB sp_attn --iters 50 | grep sp_attn
-  $KB gn_bwd --n 32 --c 128 --hw 256 --res 1 | grep "^gn_bwd"
+  $KB gn_bwd --n 32 --c 128 --hw 256 --res 1 --three 1 | grep "^gn_bwd"
   $KB gn_fwd --c 512 --hw 16 | grep gn_fwd
   $KB attn --n 8 | tail -2
   $KB attn --n 32 | tail -2
   timeout 60 tools/probes/mfma_peak
 } 2>&1 | grep -v amdgpu.ids > $O/kbench.txt
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/pf_vq -o vq -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pf_vq.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/pf_vq -o vq -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-also --no-encoder-stack > /tmp/pf_vq.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/pf_tr -o tr -- python $R/bench.py --workload transformer --steps 3 --warmup 1 > /tmp/pf_tr.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pf_enc -o enc -- python $R/tools/enc_fwd.py > /tmp/pf_enc.log 2>&1
 cd $R
