@@ -521,32 +521,39 @@ def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ac
     nw = cout * ks * ks * cin
     esz = x.element_size()
     slices = _batch_slices(n, h * w * cin * esz, ho * wo * cout * esz)        # (see conv_fwd_raw: tensors of 2^31 bytes and more)
-    if upsample and ks == 3 and stride == 1 and act == ACT_NONE and ss is None and len(slices) == 1 and x.dtype == torch.bfloat16:
+    if upsample and ks == 3 and stride == 1 and act == ACT_NONE and ss is None and x.dtype == torch.bfloat16:
         # Upsample + conv: the weight gradient in the sub-pixel form too (conv_wgrad_dma.hip, 2x2 taps per phase): 2.25x fewer MFMAs for the
-        # same bytes; mas_wgrad_reduce_up2 folds the 4 x 4 phase taps back into the 3x3 gradient (fixed order: bitwise reproducible)
-        d = _desc(n, h, w, cin, ho, wo, cout, ks, 1, pt, pl, x.dtype, x.dtype, ACT_NONE, True)
-        k = _up2_wgrad_splits(d)
-        if k > 0:
+        # same bytes; mas_wgrad_reduce_up2 folds the 4 x 4 phase taps back into the 3x3 gradient (fixed order: bitwise reproducible).
+        # Batch slices (tensors of 2^31 bytes and more) are reduced one by one and added in slice order.
+        ds = [_desc(n1 - n0, h, w, cin, ho, wo, cout, ks, 1, pt, pl, x.dtype, x.dtype, ACT_NONE, True) for n0, n1 in slices]
+        ks_ = [_up2_wgrad_splits(d) for d in ds]
+        if all(k > 0 for k in ks_):
             nw4 = cout * 4 * cin
-            need = 4 * k * (nw4 + cout)
+            need = max(4 * k * (nw4 + cout) for k in ks_)
             key = (x.device.index, torch.cuda.current_stream().cuda_stream)
             ws = _wgrad_partials.get(key)
             if ws is None or ws.numel() < need:
                 ws = _wgrad_partials[key] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=x.device)
-            pb0 = ws.data_ptr() + 4 * 4 * k * nw4
-            dwo = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
-            db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
+            dwo = db = None
+            for (n0, n1), d, k in zip(slices, ds, ks_):
+                pb0 = ws.data_ptr() + 4 * 4 * k * nw4
+                dws = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+                dbs = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
+                xs, dys = (x, dy) if len(slices) == 1 else (x[n0:n1], dy[n0:n1])
 
-            def launch_up2():
-                check(lib().mas_conv_up2_wgrad_partial(C.byref(d), _ptr(x), _ptr(dy), _ptr(ws), C.c_void_p(pb0) if want_bias else None, _stream()),
-                      "conv_up2_wgrad_partial")
+                def launch_up2():
+                    check(lib().mas_conv_up2_wgrad_partial(C.byref(d), _ptr(xs), _ptr(dys), _ptr(ws), C.c_void_p(pb0) if want_bias else None, _stream()),
+                          "conv_up2_wgrad_partial")
 
-            if _launch_hook is not None:
-                _launch_hook("conv_wgrad", (n, h, w, cin, ho, wo, cout, ks, stride, act, 0), launch_up2)
-            else:
-                launch_up2()
-            check(lib().mas_wgrad_reduce_up2(_ptr(ws), C.c_void_p(pb0) if want_bias else None, k, _ptr(dwo), _ptr(db), cout, cin, _stream()),
-                  "wgrad_reduce_up2")
+                if _launch_hook is not None:
+                    _launch_hook("conv_wgrad", (n1 - n0, h, w, cin, ho, wo, cout, ks, stride, act, 0), launch_up2)
+                else:
+                    launch_up2()
+                check(lib().mas_wgrad_reduce_up2(_ptr(ws), C.c_void_p(pb0) if want_bias else None, k, _ptr(dws), _ptr(dbs), cout, cin, _stream()),
+                      "wgrad_reduce_up2")
+                dwo = dws if dwo is None else dwo.add_(dws)
+                if want_bias:
+                    db = dbs if db is None else db.add_(dbs)
             return dwo, db
     descs = [_desc(n1 - n0, h, w, cin, ho, wo, cout, ks, stride, pt, pl, x.dtype, x.dtype, act, upsample) for n0, n1 in slices]
     key = (x.device.index, torch.cuda.current_stream().cuda_stream)

@@ -156,3 +156,50 @@ def test_small_maps_keep_the_folded_kernels():
     assert ops.last_kernel() != "conv_up2_fwd"
     ref = F.conv2d(F.interpolate(x.float().cpu(), scale_factor=2.0, mode="nearest"), w.detach().cpu().bfloat16().float(), None, padding=1)
     assert _rel(y, ref) < 1e-2
+
+
+def test_large_batch_slices_stay_on_the_sub_pixel_kernels():
+    """N = 160 at the last Upsample of VQ-IMG (128 -> 128, 128^2 -> 256^2): the output / dy are 2.68 GB, beyond the 31-bit byte offsets of
+    the kernels' buffer descriptors.  ``ops`` cuts the forward and the data gradient into two batch slices that each take conv_up2
+    (asserted), the weight gradient runs the phase-form kernel once per slice (asserted) and adds the slices' gradients in order.
+    Forward and data gradient vs fp32 on images of both slices; the weight gradient vs the sum of its halves computed as separate
+    launches (linearity in the batch: bitwise the same sums) and vs the 3x3 form of the same gradient (MAS-independent check: the
+    folded kernels' weight gradient of a 16-image sample of both slices, compared through torch's fp32 autograd)."""
+    from mas_hip import ops
+    dev = _dev()
+    ops.set_compute_dtype(torch.bfloat16)
+    bf = torch.bfloat16
+    n, c, h = 160, 128, 128
+    assert len(ops._batch_slices(n, h * h * c * 2, 4 * h * h * c * 2)) == 2
+    g = torch.Generator(device=dev).manual_seed(31)
+    x = torch.randn(n, c, h, h, device=dev, generator=g).to(bf).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = torch.nn.Parameter(torch.randn(c, c, 3, 3, device=dev, generator=g) / (9 * c) ** 0.5)
+    seen = []
+    ops.set_launch_hook(lambda kind, shape, launch: (launch(), seen.append((kind, ops.last_kernel()))))
+    try:
+        y = ops.norm_act_conv(x, w, None, stride=1, padding=(1, 1, 1, 1), upsample=True)
+        dy = torch.randn(y.shape, device=dev, generator=g).to(bf).contiguous(memory_format=torch.channels_last)
+        y.backward(dy)
+        geo = (h, h, c, 2 * h, 2 * h, c, 3, 1, 1, 1)
+        xa, xb = x.detach()[:80], x.detach()[80:]
+        dwa, _ = ops.conv_wgrad_raw(xa, None, dy[:80], 80, *geo, 0, True, False)
+        dwb, _ = ops.conv_wgrad_raw(xb, None, dy[80:], 80, *geo, 0, True, False)
+    finally:
+        ops.set_launch_hook(None)
+    torch.cuda.synchronize()
+    assert seen[0] == ("conv_fwd", "conv_up2_fwd") and ("conv_up2_dgrad", "conv_up2_dgrad") in seen, seen
+    wg = [k for kind, k in seen if kind == "conv_wgrad"]
+    assert wg == ["conv_wgrad_up2"] * 4, wg
+    sample = [0, 79, 80, 159]
+    xs = x.detach()[sample].float().cpu().requires_grad_(True)
+    ref = F.conv2d(F.interpolate(xs, scale_factor=2.0, mode="nearest"), w.detach().bfloat16().float().cpu(), None, padding=1)
+    ref.backward(dy[sample].float().cpu())
+    e_y, e_x = _rel(y[sample], ref), _rel(x.grad[sample], xs.grad)
+    assert torch.equal(w.grad, dwa + dwb)                  # same launches, same order of addition
+    ws = w.detach().bfloat16().float().cpu().requires_grad_(True)
+    F.conv2d(F.interpolate(x.detach()[sample].float().cpu(), scale_factor=2.0, mode="nearest"), ws, None, padding=1).backward(dy[sample].float().cpu())
+    dws, _ = ops.conv_wgrad_raw(x.detach()[sample].contiguous(memory_format=torch.channels_last), None, dy[sample].contiguous(memory_format=torch.channels_last),
+                                len(sample), h, h, c, 2 * h, 2 * h, c, 3, 1, 1, 1, 0, True, False)
+    e_w = _rel(dws, ws.grad)
+    print("N=160 Upsample conv: forward %.3e, data gradient %.3e; weight gradient of the 4 sampled images vs fp32 autograd %.3e" % (e_y, e_x, e_w))
+    assert e_y < 1e-2 and e_x < 1.5e-2 and e_w < 1e-3
