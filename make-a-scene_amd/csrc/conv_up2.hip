@@ -433,7 +433,7 @@ int mas_conv_up2_fwd_launch(const MasConvDesc* d, const void* x, const void* w_p
 
 extern "C" int mas_conv_up2_dgrad_supported(const MasConvDesc* d) {
     if (!up2_geometry_ok(d)) return 0;
-    if (d->Cout % 64 != 0 || d->Cin % 128 != 0) return 0;
+    if (d->Cout % 64 != 0 || d->Cin % 128 != 0 || d->Cin > U_MAXCOUT) return 0;       // (the kernel's outputs are the forward's input channels)
     return up2_tiles_ok(d, d->Cin / 128) ? 1 : 0;
 }
 
