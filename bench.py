@@ -414,6 +414,17 @@ def _replica_spread(model, ddp):
     return float((hi - lo).item())
 
 
+def _emit(out):
+    """the ONE JSON line, as the last thing on stdout: RCCL prints its version banner through C stdio, which (stdout being a pipe) sits in
+    libc's buffer until exit and would otherwise land AFTER this line -- flush libc first"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
+
+
 def _par(world, args, ddp):
     return f"dp{world}" + ((" (DistributedDataParallel" if args.dp == "ddp" else " (mas_hip.dp.GradReducer: 128 MiB flat buckets,")
                            + " RCCL all-reduce overlapped with backward)" if ddp else "")
@@ -563,9 +574,11 @@ def run_vq(args):
             del model, net, opt, x                               # free the HBM the other workloads need
             torch.cuda.empty_cache()
             out["also"] = _also_workloads()
-        print(json.dumps(out), flush=True)
+        final_line = out
     if ddp:
         dist.destroy_process_group()
+    if rank == 0:
+        _emit(final_line)                 # after the process group is gone: nothing of RCCL's can follow the line
 
 
 def _also_workloads(budget_s=240):
@@ -717,9 +730,11 @@ def run_transformer(args, e2e):
                                "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg, 4),
                                "launches_timed": len(ms), "algorithmic_gflop_per_launch": round(fl / 1e9, 1)}
-        print(json.dumps(out), flush=True)
+        final_line = out
     if ddp:
         dist.destroy_process_group()
+    if rank == 0:
+        _emit(final_line)                 # after the process group is gone: nothing of RCCL's can follow the line
 
 
 def main():
