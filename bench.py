@@ -414,14 +414,19 @@ def _replica_spread(model, ddp):
     return float((hi - lo).item())
 
 
-def _emit(out):
-    """the ONE JSON line, as the last thing on stdout: RCCL prints its version banner through C stdio, which (stdout being a pipe) sits in
-    libc's buffer until exit and would otherwise land AFTER this line -- flush libc first"""
+def _flush_libc():
     try:
         import ctypes
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
+    sys.stdout.flush()
+
+
+def _emit(out):
+    """the ONE JSON line, as the last thing on stdout: RCCL prints its version banner through C stdio, which (stdout being a pipe) sits in
+    libc's buffer until exit and would otherwise land AFTER this line -- flush libc first"""
+    _flush_libc()
     print(json.dumps(out), flush=True)
 
 
@@ -576,6 +581,8 @@ def run_vq(args):
             out["also"] = _also_workloads()
         final_line = out
     if ddp:
+        _flush_libc()                     # every rank: whatever C-level output it holds goes out BEFORE rank 0's line
+        dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         _emit(final_line)                 # after the process group is gone: nothing of RCCL's can follow the line
@@ -732,6 +739,8 @@ def run_transformer(args, e2e):
                                "launches_timed": len(ms), "algorithmic_gflop_per_launch": round(fl / 1e9, 1)}
         final_line = out
     if ddp:
+        _flush_libc()                     # every rank: whatever C-level output it holds goes out BEFORE rank 0's line
+        dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         _emit(final_line)                 # after the process group is gone: nothing of RCCL's can follow the line
