@@ -608,6 +608,7 @@ int mas_conv3x3_wide_launch(const MasConvDesc* d, const void* x, const float* sc
 int mas_conv3x3_wide_stat_rows(const MasConvDesc* d);
 int mas_conv1x1_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s);
 int mas_conv_thin_fwd_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s);
+int mas_conv_thin_out_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s);
 int mas_conv_s2_fwd_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s);
 bool mas_conv_up2_fwd_eligible(const MasConvDesc* d);                        // conv_up2.hip
 int mas_conv_up2_stat_rows(const MasConvDesc* d);
@@ -674,6 +675,9 @@ static int conv_fwd_impl(const MasConvDesc* d, const void* x, const float* scale
         if (rc != 0) return rc < 0 ? rc : MAS_OK;
         // 8 -> 128 channels (conv_in's forward, conv_out's data gradient): conv_thin.hip
         rc = mas_conv_thin_fwd_try(d, x, w_packed, bias, residual, y, reinterpret_cast<hipStream_t>(stream));
+        if (rc != 0) return rc < 0 ? rc : MAS_OK;
+        // 128 -> 8 channels (conv_out's forward): conv_thin.hip
+        rc = mas_conv_thin_out_try(d, x, w_packed, bias, residual, y, reinterpret_cast<hipStream_t>(stream));
         if (rc != 0) return rc < 0 ? rc : MAS_OK;
         // Downsample (3x3 stride 2): conv_s2.hip
         rc = mas_conv_s2_fwd_try(d, x, w_packed, bias, residual, y, reinterpret_cast<hipStream_t>(stream));

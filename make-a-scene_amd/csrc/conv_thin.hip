@@ -281,6 +281,139 @@ __global__ __launch_bounds__(TH_NT, 2) void conv_thin_fwd_kernel(ThinFwdParams p
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_thin_out_kernel (round 5) -- 3x3 / stride 1 / pad 1, C -> 8 channels (conv_out's forward, reference models/modules.py:364 with
+// its 3 output channels padded to one 16-byte slot by ops.norm_act_conv):
+//   y[pixel][co] = sum over (tap, ci) of W[co][tap][ci] * x[pixel + tap - 1][ci] + bias[co]
+// The general kernel ran it on 32-cout tiles against 64-channel chunks (0.26 ms at 128 channels @256^2 x 32 where the input's HBM time is
+// 0.09 ms).  Here: the wide kernel's patch machinery at half height -- 8 x 32-pixel tiles, 32-channel chunks of the (8 + 2) x (32 + 2)
+// halo patch double-buffered by LDS-DMA (64-byte rows, 16-byte slot ^ ((pixel >> 2) & 3)) -- a wave owns two tile rows (two 32 x 32
+// accumulator blocks: rows = pixels, columns = couts, 8 of 32 live), the weights of all chunks sit in LDS for the life of the
+// work-group ([chunk][tap][8 couts][64 B], copied once out of the K64 image conv_fwd.hip uses), 36 MFMAs per chunk and wave.  The
+// accumulators reach memory through a wave-private LDS tile ([pixel][8 couts]) so that a store instruction writes whole pixels.
+// HBM-bound by construction; persistent work-groups.
+struct ThinOutParams {
+    const unsigned char* x; const unsigned char* w; const float* bias; unsigned char* y;
+    int N, H, W, Cin, n_chunks, rows_pad, tiles_h, tiles_w, n_tiles;
+};
+constexpr int TO_TH = 8, TO_TW = 32, TO_PW = TO_TW + 2, TO_NPIX = (TO_TH + 2) * TO_PW;       // 340 patch pixels
+constexpr int TO_NPIECE = 22;                  // 340 pixels x 64 B -> 22 DMA pieces of 1 KiB (16 pixels each)
+constexpr int TO_PATCH = TO_NPIECE * 1024;
+constexpr int TO_MAXCHUNKS = 4;                // Cin <= 128: 70 KiB of LDS, two work-groups per CU (44 KiB of patch in flight per CU)
+constexpr int TO_W = 0;                        // LDS map: weights [n_chunks][9][8][64 B], then 2 patches, then 4 waves x 2 rows x [32 pixels][8 x 4 B]
+constexpr int TO_P = TO_MAXCHUNKS * 9 * 512;
+constexpr int TO_O = TO_P + 2 * TO_PATCH;
+constexpr int TO_LDS = TO_O + 4 * 2 * 1024;
+
+template <typename OutT>
+__global__ __launch_bounds__(TH_NT, 2) void conv_thin_out_kernel(ThinOutParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char th_smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)th_smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31;
+    const th_i32x4 rs_x = th_rsrc(p.x, (unsigned)((size_t)p.N * p.H * p.W * p.Cin * 2));
+
+    // ---- weights -> LDS, once: slot (chunk32 q, tap, cout r < 8, logical 16-byte slot ls < 4) from the K64 image
+    //      [chunk64][tap][rows_pad][128 B], physical slot = logical ^ ((row >> 1) & 7)
+    for (int u = tid; u < p.n_chunks * 9 * 8 * 4; u += TH_NT) {
+        const int ls = u & 3, r = (u >> 2) & 7, qt = u >> 5, tap = qt % 9, q = qt / 9;
+        const int ls64 = (q & 1) * 4 + ls;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(p.w + ((size_t)((q >> 1) * 9 + tap) * p.rows_pad + r) * 128 + ((ls64 ^ ((r >> 1) & 7)) << 4));
+        *reinterpret_cast<u32x4*>(th_smem + TO_W + ((q * 9 + tap) * 8 + r) * 64 + ls * 16) = v;
+    }
+    float bias = 0.0f;
+    if (p.bias && l31 < 8) bias = p.bias[l31];
+
+    // ---- patch DMA: wave w moves pieces w, w + 4, ... < 22; lane -> patch pixel 16 piece + (lane >> 2), physical slot lane & 3 (the swizzle
+    //      goes on the SOURCE slot); pixels outside the image (the zero padding) and the dead tail of the last piece read as zeros
+    auto issue = [&](int t, int chunk, int buf) {
+        const int tw_i = t % p.tiles_w; const int qq = t / p.tiles_w;
+        const int th_i = qq % p.tiles_h, n = qq / p.tiles_h;
+        const int h0 = th_i * TO_TH - 1, w0 = tw_i * TO_TW - 1;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int piece = wave + 4 * k;
+            if (piece < TO_NPIECE) {
+                const int q = piece * 16 + (lane >> 2), pr = q / TO_PW, pc = q - pr * TO_PW;
+                const int ih = h0 + pr, iw = w0 + pc;
+                const bool ok = q < TO_NPIX && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                const int sl = (lane & 3) ^ ((q >> 2) & 3);
+                th_dma16(rs_x, __builtin_amdgcn_readfirstlane(lds0 + TO_P + buf * TO_PATCH + piece * 1024),
+                         ok ? (((n * p.H + ih) * p.W + iw) * p.Cin + chunk * 32 + sl * 8) * 2 : TH_OOB);
+            }
+        }
+    };
+    // ---- fragment addresses.  Pixel operand: patch pixel P = (2 wave + j + kh) * 34 + l31 + kw, logical slot 2 kk + g (conv3x3_wide.hip);
+    //      weight operand: cout l31 & 7 (columns 8..31 are multiplied into accumulator columns nobody stores), slot 2 kk + g
+    auto b_addr = [&](int P) { return P * 64 + (((g ^ (P >> 2)) & 3) << 4); };
+    const int pj0 = (2 * wave) * TO_PW + l31;
+    const int w_off = (l31 & 7) * 64 + g * 16;
+
+    const int first = blockIdx.x, stride = gridDim.x;
+    if (first < p.n_tiles) issue(first, 0, 0);
+    int buf = 0;
+    for (int t = first; t < p.n_tiles; t += stride) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        for (int c = 0; c < p.n_chunks; ++c) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // this wave's pieces of the chunk have landed (and the weights are written)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (c + 1 < p.n_chunks) issue(t, c + 1, buf ^ 1);
+            else if (t + stride < p.n_tiles) issue(t + stride, 0, buf ^ 1);
+            const unsigned char* pb = th_smem + TO_P + buf * TO_PATCH;
+            const unsigned char* wb = th_smem + TO_W + c * (9 * 512) + w_off;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + tap * 512 + kk * 32);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(pb + (b_addr(pj0 + (j + kh) * TO_PW + kw) ^ (kk << 5)));
+                        mma16(acc[j], pf, wf);                                   // D[pixel][cout]
+                    }
+                }
+            }
+            buf ^= 1;
+        }
+        // ---- epilogue: lanes l31 < 8 hold cout l31 of 16 pixels each -> wave-private LDS tile [row j][pixel][8 x fp32] -> whole pixels to memory
+        const int tw_i = t % p.tiles_w; const int qq = t / p.tiles_w;
+        const int th_i = qq % p.tiles_h, n = qq / p.tiles_h;
+        float* ot = reinterpret_cast<float*>(th_smem + TO_O + wave * 2048);
+        if (l31 < 8) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[(j * 32 + acc_row(lane, r)) * 8 + l31] = acc[j][r] + bias;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // (LDS operations of one wave complete in order)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int oh = th_i * TO_TH + 2 * wave + j;
+            if constexpr (sizeof(OutT) == 4) {                                   // 32 B per pixel: lane -> (pixel lane >> 1, half lane & 1)
+                const int px = lane >> 1, ow = tw_i * TO_TW + px;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ot + (j * 32 + px) * 8 + (lane & 1) * 4);
+                if (oh < p.H && ow < p.W) *reinterpret_cast<f32x4*>(p.y + (((size_t)(n * p.H + oh) * p.W + ow) * 8 + (lane & 1) * 4) * 4) = v;
+            } else {                                                              // 16 B per pixel: lanes 0..31
+                const int ow = tw_i * TO_TW + l31;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ot + (j * 32 + l31) * 8), b = *reinterpret_cast<const f32x4*>(ot + (j * 32 + l31) * 8 + 4);
+                u32x4 o;
+                bf16_t* ob = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ob[e] = (bf16_t)a[e]; ob[4 + e] = (bf16_t)b[e]; }
+                if (g == 0 && oh < p.H && ow < p.W) *reinterpret_cast<u32x4*>(p.y + ((size_t)(n * p.H + oh) * p.W + ow) * 16) = o;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
 
 static bool thin_wgrad_setup(const MasConvDesc* d, ThinWgradParams& p, bool& big_is_x) {
@@ -337,5 +470,34 @@ int mas_conv_thin_fwd_try(const MasConvDesc* d, const void* x, const void* w_pac
     if (grid > p.n_tiles) grid = p.n_tiles;
     hipLaunchKernelGGL(conv_thin_fwd_kernel, dim3((unsigned)grid), dim3(TH_NT), TF_LDS + 4 * 8192, s, p);
     MAS_CHECK_LAUNCH("conv_thin_fwd");
+    return 1;
+}
+
+// 3x3 / stride 1 / pad 1 / bf16 in, C -> 8 channels (C = 64 or 128), no prologue, no residual: conv_out's forward.  Returns 1 if
+// launched, 0 if conv_fwd.hip should take it
+int mas_conv_thin_out_try(const MasConvDesc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, hipStream_t s) {
+    static const int on = mas_env_int("MAS_CONV_THIN", 1), on_out = mas_env_int("MAS_CONV_THIN_OUT", 1);
+    if (!on || !on_out || residual) return 0;
+    if (d->ks != 3 || d->stride != 1 || d->upsample || d->act != MAS_ACT_NONE || d->pad_top != 1 || d->pad_left != 1) return 0;
+    if (d->in_dtype != MAS_BF16 || (d->out_dtype != MAS_BF16 && d->out_dtype != MAS_F32) || d->w_layout != MAS_WLAYOUT_K64) return 0;
+    if (d->Cout != 8 || d->Cin % 64 != 0 || d->Cin > 32 * TO_MAXCHUNKS || d->Ho != d->H || d->Wo != d->W) return 0;
+    if ((long long)d->N * d->H * d->W * d->Cin * 2 >= 0x7fffffffLL) return 0;
+    ThinOutParams p;
+    p.x = (const unsigned char*)x; p.w = (const unsigned char*)w_packed; p.bias = bias; p.y = (unsigned char*)y;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.n_chunks = d->Cin / 32; p.rows_pad = 128;
+    p.tiles_h = mas_cdiv(d->H, TO_TH); p.tiles_w = mas_cdiv(d->W, TO_TW); p.n_tiles = d->N * p.tiles_h * p.tiles_w;
+    int grid = 8 * mas_num_cus();                                                // two resident work-groups per CU (70 KiB of LDS each), four rounds
+    if (grid > p.n_tiles) grid = p.n_tiles;
+    static mas_devmask_t attr_mask{0};
+    unsigned long long attr_bit;
+    if (mas_attr_needed(attr_mask, &attr_bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_out_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, TO_LDS) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_out_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, TO_LDS) != hipSuccess)
+            MAS_FAIL(MAS_ELAUNCH, "conv_thin_out: cannot set dynamic LDS size %d", TO_LDS);
+        mas_attr_done(attr_mask, attr_bit);
+    }
+    if (d->out_dtype == MAS_F32) hipLaunchKernelGGL(conv_thin_out_kernel<float>, dim3((unsigned)grid), dim3(TH_NT), TO_LDS, s, p);
+    else hipLaunchKernelGGL(conv_thin_out_kernel<bf16_t>, dim3((unsigned)grid), dim3(TH_NT), TO_LDS, s, p);
+    MAS_CHECK_LAUNCH("conv_thin_out");
     return 1;
 }

@@ -107,7 +107,7 @@ def _reference(x, w, b, dy, stride, pad4, sample):
     ("downsample_128_256", 16, 128, 128, 256, 3, 2, (0, 1, 0, 1), ("conv_s2_fwd", "conv_s2_dgrad", "wgrad_s2")),
     ("downsample_256_64", 16, 256, 256, 64, 3, 2, (0, 1, 0, 1), ("conv_s2_fwd", "conv_s2_dgrad", "wgrad_s2")),
     ("conv_in_rgb_256", 16, 3, 128, 256, 3, 1, (1, 1, 1, 1), ("conv_thin_fwd", None, "wgrad_thin")),
-    ("conv_out_rgb_256", 16, 128, 3, 256, 3, 1, (1, 1, 1, 1), (None, "conv_thin_fwd", "wgrad_thin")),
+    ("conv_out_rgb_256", 16, 128, 3, 256, 3, 1, (1, 1, 1, 1), ("conv_thin_out", "conv_thin_fwd", "wgrad_thin")),     # (forward: round 5)
     ("nin_shortcut_256_128_128", 16, 256, 128, 128, 1, 1, (0, 0, 0, 0), ("conv1x1", "conv1x1", "wgrad1x1")),
     ("nin_shortcut_512_256_64", 16, 512, 256, 64, 1, 1, (0, 0, 0, 0), ("conv1x1", "conv1x1", "wgrad1x1")),
 ], ids=lambda c: c[0])

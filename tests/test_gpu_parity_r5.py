@@ -243,3 +243,35 @@ def test_save_activations_switch_gives_the_same_gradients_with_less_memory():
     finally:
         ops.set_save_activations(True)
         ops.set_compute_dtype(old)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# 4. conv_out's forward on its thin kernel (conv_thin.hip conv_thin_out_kernel: C -> 8 channels)
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [(16, 128, 256, 256, torch.float32), (3, 128, 37, 45, torch.float32), (2, 64, 24, 70, torch.bfloat16), (5, 128, 8, 32, torch.bfloat16)],
+                         ids=lambda c: "x".join(str(v).replace("torch.", "") for v in c))
+def test_conv_out_forward_on_the_thin_kernel(case):
+    """reference models/modules.py:364 (128 -> 3 channels, the 3 padded to one 16-byte slot by ops.norm_act_conv): fp32 output as the
+    Decoder asks for it and bf16 output, whole and ragged 8 x 32-pixel tiles, one and two 64-channel K64 chunks; kernel asserted"""
+    from mas_hip import ops
+    dev = _dev()
+    n, cin, h, w, out_dt = case
+    old = ops.compute_dtype()
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        g = torch.Generator().manual_seed(cin + h + w)
+        x = torch.randn(n, cin, h, w, generator=g).bfloat16()
+        wt = (torch.randn(3, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).bfloat16().float()
+        b = 0.1 * torch.randn(3, generator=g)
+        sample = sorted({0, n // 2, n - 1})
+        ref = F.conv2d(x[sample].float(), wt, b, padding=1)
+        y = ops.norm_act_conv(x.to(dev).contiguous(memory_format=torch.channels_last), torch.nn.Parameter(wt.to(dev)), torch.nn.Parameter(b.to(dev)),
+                              stride=1, padding=(1, 1, 1, 1), out_dtype=out_dt)
+        assert ops.last_kernel() == "conv_thin_out", ops.last_kernel()
+        torch.cuda.synchronize()
+        assert y.shape == (n, 3, h, w) and y.dtype == out_dt
+        e = _rel(y[sample], ref)
+        print(case, "conv_out forward: %.3e" % e)
+        assert e < (2e-3 if out_dt == torch.float32 else 1e-2), e
+    finally:
+        ops.set_compute_dtype(old)
