@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAS_ABI_VERSION 6
+#define MAS_ABI_VERSION 7
 
 enum { MAS_OK = 0, MAS_EINVAL = -1, MAS_EUNSUPPORTED = -2, MAS_ELAUNCH = -3, MAS_EWORKSPACE = -4 };
 enum { MAS_F32 = 0, MAS_BF16 = 1 };
@@ -315,6 +315,14 @@ int mas_layernorm_bwd(const void* x, const void* dy, const float* gamma, const f
 int mas_layernorm_bwd_add(const void* x, const void* dy, const float* gamma, const float* mean_rstd, const void* dx_add, void* dx,
                           float* dgamma, float* dbeta, int in_dtype, int out_dtype, int rows, int D,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* mas_layernorm_bwd_colsum: mas_layernorm_bwd_add that ALSO returns dx_colsum[D] (fp32) = the column sums of dx as stored (rounded to
+ *   in_dtype; fixed summation order) -- the bias gradient of the Linear layer whose output this LayerNorm normalises (out_proj / lin2
+ *   in front of the sandwich LayerNorms, reference models/transformer.py:201-203,207-209: grad_bias = grad_output.sum(0) with
+ *   grad_output = this dx), which otherwise costs a mas_colsum pass over dx.  dx_colsum NULL = mas_layernorm_bwd_add.             */
+int mas_layernorm_bwd_colsum(const void* x, const void* dy, const float* gamma, const float* mean_rstd, const void* dx_add, void* dx,
+                             float* dgamma, float* dbeta, float* dx_colsum, int in_dtype, int out_dtype, int rows, int D,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* mas_colsum: out[c] = sum over rows of x[r][c] (fp32 accumulation, fixed summation order: bitwise run-to-run deterministic).
  *   The bias gradient of the transformer's Linear layers (torch.nn.Linear in reference models/transformer.py:31,34,125,126:

@@ -458,17 +458,34 @@ __global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnPara
     const int n_tiles = q_last / KT2 + 1;
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the Q fragments are USED here, before the loop: the compiler then places its own wait for their global loads here and not in
+    // front of the first MFMA of every tile -- where a vmcnt(0) also waits for the DMA of the NEXT tile that was issued a few
+    // instructions earlier (the counter cannot tell the two apart), i.e. exposes the whole prefetch latency once per tile
+    // (round 5: the forward without the per-tile DMA wait, profiles/r05_attn_ablation.txt)
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) asm volatile("" ::"v"(qf[kk]));
     __syncthreads();
 
     auto tile = [&](int it, auto stage_c) {
         constexpr int ST = decltype(stage_c)::value;
         const int k0 = it * KT2;
         const bool more = it + 1 < n_tiles;
+#ifndef FA_ABL_NODMA
         if (more) issue(k0 + KT2, ST ^ 1);
+#else
+        (void)more;
+#endif
         if (k0 <= qw + 31) {                         // wave-uniform: otherwise the tile is entirely above this wave's diagonal
             const unsigned char* kt = fa_smem + ST * F2_STAGE;
             const unsigned char* vt = kt + F2_TILE;
             f32x16 s[2];
+#ifdef FA_ABL_NOQK
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[sub][r] = (float)it;
+            (void)kt;
+#else
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
@@ -479,6 +496,7 @@ __global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnPara
                     mma16(s[sub], kf, qf[kk]);
                 }
             }
+#endif
             if ((k0 + KT2 - 1 > qw) || (k0 + KT2 > p.S)) {          // tile touches the diagonal or the sequence end: mask
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
@@ -488,6 +506,10 @@ __global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnPara
                         if (!(key <= query && key < p.S)) s[sub][r] = -1e30f;
                     }
             }
+#ifdef FA_ABL_NOSOFTMAX                    // (ablation builds, tools/experiments/gpu_r5_12.sh: where the forward's time goes)
+            const float alpha = 1.0f;
+            l += s[0][0];
+#else
             float tmax = -1e30f;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
@@ -496,6 +518,11 @@ __global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnPara
             tmax = fmaxf(tmax, fa_other_half(tmax)) * c2;
             const float m_new = fmaxf(m, tmax);
             const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+#ifdef FA_ABL_NOEXP
+#define FA_EXP2(x) (x)
+#else
+#define FA_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
 #ifdef FA_SCALAR_SOFTMAX   // one v_fma / v_exp / v_add per score (build with -fno-slp-vectorize): packed fp32 VALU beside MFMAs is priced as an
             float rs0 = 0.0f, rs1 = 0.0f;                           // anti-lever in MI355X_MICROARCH.md (2 v_pk_add +26 cycles vs 2 v_fma per gap)
             const float nm = -m_new;
@@ -503,8 +530,8 @@ __global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnPara
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const float t0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][r], c2, nm));
-                    const float t1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][r + 1], c2, nm));
+                    const float t0 = FA_EXP2(__builtin_fmaf(s[sub][r], c2, nm));
+                    const float t1 = FA_EXP2(__builtin_fmaf(s[sub][r + 1], c2, nm));
                     s[sub][r] = t0; s[sub][r + 1] = t1;
                     rs0 += t0; rs1 += t1;
                 }
@@ -527,6 +554,7 @@ __global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnPara
             rsum += fa_other_half(rsum);
             l = l * alpha + rsum;
             m = m_new;
+#endif
             if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
                 for (int i = 0; i < NMI; ++i)
@@ -540,15 +568,22 @@ __global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnPara
                     bf16x8 pf;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pf[j] = (T)s[sub][8 * t + j];
+#ifdef FA_ABL_NOPV
+                    asm volatile("" ::"v"(pf));
+                    (void)vt;
+#else
 #pragma unroll
                     for (int i = 0; i < NMI; ++i) {
                         const unsigned char* a0 = vt + va[i] + (sub * 32 + 16 * t) * 128;
                         mma16(oacc[i], fa_tr_frag(a0, a0 + 8 * 128), pf);
                     }
+#endif
                 }
         }
+#ifndef FA_ABL_NOBAR
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of the next tile have landed
         __syncthreads();
+#endif
     };
     for (int it = 0; it < n_tiles; it += 2) {
         tile(it, std::integral_constant<int, 0>{});

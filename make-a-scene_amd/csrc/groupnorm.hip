@@ -286,25 +286,28 @@ __global__ __launch_bounds__(NT) void gn_bwd_partial_pk(const bf16_t* __restrict
     const int r0 = sp * rows_per, r1 = min(HW, r0 + rows_per);
     const long long total = (long long)(r1 - r0) * upp;
     const int cu = tid % upp;
-    f32x2 sc[4], sh[4], xr[4], xb[4], s1[4], s2[4];  // xhat = x * rstd - mean * rstd (one v_pk_fma)
+    // the second sum is kept RAW (sum du * x): sum du * xhat = rstd * (sum du * x) - mean * rstd * (sum du) is formed by the finalize
+    // kernel in fp64 -- 16 registers (108 -> 92: five waves per SIMD) and one v_pk_fma per pair less in a loop whose VALU time (~10
+    // issue slots per element, a third of them the two transcendentals of silu') is within 25 % of its HBM time: 128 ch @256^2 x 96
+    // 1.514 -> 1.459 ms for the three launches (profiles/r05_gn_tuning.txt)
+    f32x2 sc[4], sh[4], s1[4], s2[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int c = cu * 8 + 2 * p + h;
             sc[p][h] = ss[((size_t)n * C + c) * 2 + 0]; sh[p][h] = ss[((size_t)n * C + c) * 2 + 1];
-            const float mu = mean_rstd[((size_t)n * G + c / cpg) * 2 + 0], rs = mean_rstd[((size_t)n * G + c / cpg) * 2 + 1];
-            xr[p][h] = rs; xb[p][h] = -mu * rs;
             s1[p][h] = 0.0f; s2[p][h] = 0.0f;
         }
     }
+    (void)cpg; (void)mean_rstd;
     auto acc2 = [&](const u32x4& rx, const u32x4& rd) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const f32x2 xe = bf16pair_f32(rx[p]);
             f32x2 du = bf16pair_f32(rd[p]);
             if constexpr (SILU) du = du * dsilu2_f(xe * sc[p] + sh[p]);
-            s1[p] += du; s2[p] += du * (xe * xr[p] + xb[p]);
+            s1[p] += du; s2[p] += du * xe;
         }
     };
     const bf16_t* xb_ = x + ((size_t)n * HW + r0) * C;
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_partial_pk(const bf16_t* __restrict
 // and per-sample contributions to dgamma/dbeta: nsum[n][c][2] = {S2, S1}
 __global__ __launch_bounds__(NT) void gn_bwd_finalize(const float* __restrict__ partial, int HW, int C, int G, int nsplit,
                                                       const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
-                                                      float* __restrict__ coef, float* __restrict__ nsum) {
+                                                      float* __restrict__ coef, float* __restrict__ nsum, int raw) {
     const int n = blockIdx.x, tid = threadIdx.x;
     const int cpg = C / G;
     extern __shared__ double dred[];
@@ -362,6 +365,10 @@ __global__ __launch_bounds__(NT) void gn_bwd_finalize(const float* __restrict__ 
         for (; sp < nsplit; ++sp) {
             const float* p = partial + ((size_t)(n * nsplit + sp) * C + c) * 2;
             a += (double)p[0]; b += (double)p[1];
+        }
+        if (raw) {                                   // b arrived as sum du * x (gn_bwd_partial_pk): -> sum du * xhat
+            const double mu = mean_rstd[((size_t)n * G + c / cpg) * 2 + 0], rs = mean_rstd[((size_t)n * G + c / cpg) * 2 + 1];
+            b = rs * (b - mu * a);
         }
         cs[2 * c] = a; cs[2 * c + 1] = b;
         nsum[((size_t)n * C + c) * 2 + 0] = (float)b;   // -> dgamma
@@ -861,7 +868,8 @@ extern "C" int mas_gn_act(const void* x, void* a, int dtype, int N, int HW, int 
     if (C % epu || NT % (C / epu)) MAS_FAIL(MAS_EUNSUPPORTED, "gn_act: C=%d: C/%d must divide %d", C, epu, NT);
     const long long units_per_n = (long long)HW * C / epu;
     int gx = (int)((units_per_n + NT - 1) / NT);
-    const int cap = mas_cdiv(4096, N) > 0 ? mas_cdiv(4096, N) : 1;
+    static const int act_blocks = mas_env_int("MAS_GN_ACT_BLOCKS", 8192);
+    const int cap = mas_cdiv(act_blocks, N) > 0 ? mas_cdiv(act_blocks, N) : 1;
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -982,7 +990,7 @@ extern "C" int mas_gn_bwd_3pass(const void* x, const void* da, const void* dres,
     const size_t lds1 = ((size_t)2 * C + (size_t)NT * epu * 2) * sizeof(float);
     const bool pk = dtype == MAS_BF16;                               // (NT % (C / 8) == 0 was checked above)
     const long long units_per_n = (long long)HW * C / epu;
-    constexpr int apply_blocks = 4096;
+    static const int apply_blocks = mas_env_int("MAS_GN_APPLY_BLOCKS", 8192);
     const int nsplit = pick_split(N, HW);
     if (pk && silu)
         hipLaunchKernelGGL(gn_bwd_partial_pk<true>, dim3(N * nsplit), dim3(NT), lds1, s, (const bf16_t*)x, (const bf16_t*)da, HW, C, G, nsplit, mean_rstd, scale_shift, partial, gn_reverse());
@@ -991,11 +999,15 @@ extern "C" int mas_gn_bwd_3pass(const void* x, const void* da, const void* dres,
     else
         hipLaunchKernelGGL(gn_bwd_partial<float>, dim3(N * nsplit), dim3(NT), lds1, s, (const float*)x, (const float*)da, HW, C, G, nsplit, act, mean_rstd, scale_shift, partial, gn_reverse());
     MAS_CHECK_LAUNCH("gn_bwd_partial");
-    hipLaunchKernelGGL(gn_bwd_finalize, dim3(N), dim3(NT), (size_t)2 * C * sizeof(double), s, partial, HW, C, G, nsplit, gamma, mean_rstd, coef, nsum);
+    hipLaunchKernelGGL(gn_bwd_finalize, dim3(N), dim3(NT), (size_t)2 * C * sizeof(double), s, partial, HW, C, G, nsplit, gamma, mean_rstd, coef, nsum,
+                       pk ? 1 : 0);
     MAS_CHECK_LAUNCH("gn_bwd_finalize");
     int gx = (int)((units_per_n + NT - 1) / NT);
-    // 4096 blocks over the batch (16 per CU: the write stream wants more requests in flight than 8 gave it, 0.528 -> 0.479 ms at 128 ch
-    // @256^2), but at least four 16-byte units per thread (512 ch @32^2 loses 8 % on thinner blocks)
+    // MAS_GN_APPLY_BLOCKS (8192) blocks over the batch: the grid is (gx, N) and x-fastest, so the budget sets how many IMAGES are walked at
+    // once -- 2048 resident blocks / gx.  Round 3 went 2048 -> 4096 (0.528 -> 0.479 ms at 128 ch @256^2: the write stream wants requests
+    // in flight); round 5 4096 -> 8192 (eight images in flight instead of sixteen: fewer DRAM fronts; gn_act 0.197 -> 0.184, the step
+    // -0.35 ms, profiles/r05_gn_tuning.txt; 16384+ is flat or worse with a residual stream).  At least four 16-byte units per thread
+    // (512 ch @32^2 loses 8 % on thinner blocks)
     int cap = mas_cdiv(apply_blocks, N) > 0 ? mas_cdiv(apply_blocks, N) : 1;
     const long long thick = units_per_n / (4LL * NT);
     if (cap > thick) cap = thick > 0 ? (int)thick : 1;

@@ -170,20 +170,24 @@ __global__ __launch_bounds__(NT) void layernorm_fwd_kernel(const TI* __restrict_
 }
 
 // backward: g = dy*gamma, xhat = (x-mean)*rstd, dx = rstd*(g - mean_D(g) - xhat*mean_D(g*xhat));
-// per-block partial sums of dgamma = sum_rows dy*xhat and dbeta = sum_rows dy: partial[blk][2][D]
-template <typename TI, typename TO>
+// per-block partial sums of dgamma = sum_rows dy*xhat and dbeta = sum_rows dy: partial[blk][NP][D], NP = 2, or 3 with CS: the third row
+// is the column sum of dx AS STORED (rounded to TI) -- the bias gradient of the Linear layer whose output this LayerNorm normalises
+// (out_proj / lin2 in front of the sandwich LayerNorms, reference transformer.py:201-203,207-209), which otherwise is a mas_colsum
+// pass over dx plus its fold launch.
+template <typename TI, typename TO, bool CS>
 __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const TI* __restrict__ x, const TO* __restrict__ dy,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
                                                            TI* __restrict__ dx, float* __restrict__ partial, int rows, int D,
                                                            const TI* __restrict__ dx_add) {
+    constexpr int NP = CS ? 3 : 2;
     constexpr int VEC = 16 / (int)sizeof(TI) < 16 / (int)sizeof(TO) ? 16 / (int)sizeof(TI) : 16 / (int)sizeof(TO);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = D / VEC;
-    float ag[LN_KMAX][VEC], ab[LN_KMAX][VEC];
+    float ag[LN_KMAX][VEC], ab[LN_KMAX][VEC], ac[CS ? LN_KMAX : 1][VEC];
 #pragma unroll
     for (int k = 0; k < LN_KMAX; ++k)
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { ag[k][e] = 0.0f; ab[k][e] = 0.0f; }
+        for (int e = 0; e < VEC; ++e) { ag[k][e] = 0.0f; ab[k][e] = 0.0f; if (CS) ac[k][e] = 0.0f; }
     for (int row = blockIdx.x * (NT / 64) + wave; row < rows; row += gridDim.x * (NT / 64)) {
         const float mean = mean_rstd[2 * (size_t)row], rstd = mean_rstd[2 * (size_t)row + 1];
         const TI* xr = x + (size_t)row * D;
@@ -223,58 +227,81 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const TI* __restrict_
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) o[e] += sk[e];
                 }
+                if (CS) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) ac[k][e] += (float)(TI)o[e];
+                }
                 st_n<TI, VEC>(dr + c * VEC, o);
             }
         }
     }
     // fixed-order reduction over the block's waves through LDS, then one partial row per block
-    __shared__ float red[(NT / 64)][2][64 * 8 + 1];            // per k: [wave][gamma|beta][lane*VEC + e]
+    __shared__ float red[(NT / 64)][NP][64 * 8 + 1];           // per k: [wave][gamma|beta|dx][lane*VEC + e]
 #pragma unroll
     for (int k = 0; k < LN_KMAX; ++k) {
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { red[wave][0][lane * VEC + e] = ag[k][e]; red[wave][1][lane * VEC + e] = ab[k][e]; }
+        for (int e = 0; e < VEC; ++e) {
+            red[wave][0][lane * VEC + e] = ag[k][e]; red[wave][1][lane * VEC + e] = ab[k][e];
+            if (CS) red[wave][NP - 1][lane * VEC + e] = ac[k][e];
+        }
         __syncthreads();
-        for (int i = threadIdx.x; i < 2 * 64 * VEC; i += NT) {
+        for (int i = threadIdx.x; i < NP * 64 * VEC; i += NT) {
             const int which = i / (64 * VEC), j = i % (64 * VEC);
             const int col = k * 64 * VEC + j;
             if (col < D) {
                 float a = 0.0f;
 #pragma unroll
                 for (int w = 0; w < NT / 64; ++w) a += red[w][which][j];
-                partial[((size_t)blockIdx.x * 2 + which) * D + col] = a;
+                partial[((size_t)blockIdx.x * NP + which) * D + col] = a;
             }
         }
     }
 }
 
-// dgamma / dbeta = fixed-order sum of the per-block partials [nblk][2][D].  Two stages so that the whole chip takes part (round 1
-// ran D/32 = 32 work-groups over 8 MB of partials: 40 us per LayerNorm backward, 7 % of a MakeAScene step): stage 1, grid
-// (D/32, LN_SLICES): work-group (cb, sl) sums partial rows sl, sl + LN_SLICES, ... of its 32 columns into tmp[sl][2][D]; stage 2
-// (the same kernel on tmp, one slice) writes dgamma / dbeta.  Order of summation is fixed: bitwise run-to-run deterministic.
-constexpr int LN_SLICES = 8;
-__global__ __launch_bounds__(NT) void layernorm_param_reduce(const float* __restrict__ partial, int nblk, int D, int nslice,
-                                                             float* __restrict__ out_g, float* __restrict__ out_b, int out_stride) {
-    __shared__ float red[8][2][32];
-    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int col = blockIdx.x * 32 + c, sl = blockIdx.y;
-    float a = 0.0f, b = 0.0f;
-    if (col < D)
-        for (int k = sl + rg * nslice; k < nblk; k += 8 * nslice) { a += partial[((size_t)k * 2) * D + col]; b += partial[((size_t)k * 2 + 1) * D + col]; }
-    red[rg][0][c] = a; red[rg][1][c] = b;
+// dgamma / dbeta = fixed-order sum of the per-block partials [nblk][2][D] in ONE launch: grid (D/32, 2) -- work-group (cb, which) owns 32
+// columns of dgamma (which = 0), dbeta (1) or the column sum of dx (2, when asked for); 8 threads x float4 cover the 128-byte column segment of a partial row, 32 row groups
+// take rows rg, rg + 32, ... (four 16-byte loads in flight), LDS folds the row groups in a fixed order: bitwise run-to-run
+// deterministic.  (Round 1 ran D/32 work-groups of scalar loads over 8 MB of partials: 40 us per LayerNorm backward; rounds 2-4 two
+// launches -- 8 slices, then their sum -- 2 x 5.4 us + the dependent-launch gap, 196 launches per MakeAScene step.  64 work-groups of
+// 16-byte loads read the same 8 MB in one.)
+// The same kernel folds the column-sum slices (colsum below): row_stride / which_stride describe the table.
+__global__ __launch_bounds__(NT) void fold_rows_kernel(const float* __restrict__ partial, int nblk, int D, long long row_stride,
+                                                       long long which_stride, float* __restrict__ out_g, float* __restrict__ out_b,
+                                                       float* __restrict__ out_c) {
+    __shared__ float red[32][33];
+    const int cq = threadIdx.x & 7, rg = threadIdx.x >> 3, which = blockIdx.y;
+    const int col = blockIdx.x * 32 + cq * 4;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    if (col < D) {
+        const float* src = partial + (size_t)which * which_stride + col;
+        int k = rg;
+        for (; k + 96 < nblk; k += 128) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(k + 32 * u) * row_stride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a0 += v[u].x; a1 += v[u].y; a2 += v[u].z; a3 += v[u].w; }
+        }
+        for (; k < nblk; k += 32) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * row_stride);
+            a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+        }
+    }
+    red[rg][cq * 4 + 0] = a0; red[rg][cq * 4 + 1] = a1; red[rg][cq * 4 + 2] = a2; red[rg][cq * 4 + 3] = a3;
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int which = threadIdx.x >> 5;
+    if (threadIdx.x < 32) {
+        const int c = blockIdx.x * 32 + threadIdx.x;
         float t = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) t += red[r][which][c];
-        if (col < D) (which ? out_b : out_g)[(size_t)sl * out_stride + col] = t;
+        for (int r = 0; r < 32; ++r) t += red[r][threadIdx.x];
+        if (c < D) (which == 0 ? out_g : which == 1 ? out_b : out_c)[c] = t;
     }
 }
 
 // Column sums of a [rows][cols] matrix, two stages.  Stage 1: work-group (cb, sl) = one wave, one 16-byte vector of columns per
-// lane, rows sl, sl + nsl, ... (8 loads in flight per lane) -> tmp[sl][cols]; stage 2: 32 columns x 8 row groups per work-group add
-// the nsl <= 128 partial rows (fixed order: bitwise run-to-run deterministic).
+// lane, rows sl, sl + nsl, ... (8 loads in flight per lane) -> tmp[sl][cols]; stage 2 (fold_rows_kernel above): 32 columns x 32 row
+// groups per work-group add the nsl <= 128 partial rows (fixed order: bitwise run-to-run deterministic).
 constexpr int CS_NT = 64, CS_MAX_SLICES = 128;
 template <typename T>
 __global__ __launch_bounds__(CS_NT) void colsum_partial(const T* __restrict__ x, int rows, int cols, int nsl, float* __restrict__ tmp) {
@@ -305,21 +332,6 @@ __global__ __launch_bounds__(CS_NT) void colsum_partial(const T* __restrict__ x,
 #pragma unroll
     for (int e = 0; e < N; ++e) tmp[(size_t)sl * cols + c0 + e] = acc[e];
 }
-__global__ __launch_bounds__(256) void colsum_final(const float* __restrict__ tmp, int nsl, int cols, float* __restrict__ out) {
-    __shared__ float red[8][32];
-    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5, col = blockIdx.x * 32 + c;
-    float t = 0.0f;
-    if (col < cols)
-        for (int k = rg; k < nsl; k += 8) t += tmp[(size_t)k * cols + col];
-    red[rg][c] = t;
-    __syncthreads();
-    if (threadIdx.x < 32 && col < cols) {
-        float a = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) a += red[r][c];
-        out[col] = a;
-    }
-}
 int colsum_slices(int rows, int cols, int vec) {
     const int col_blocks = mas_cdiv(cols, CS_NT * vec);
     int nsl = mas_cdiv(4 * mas_num_cus(), col_blocks > 0 ? col_blocks : 1);      // ~4 one-wave work-groups per CU
@@ -328,9 +340,9 @@ int colsum_slices(int rows, int cols, int vec) {
     return nsl < 1 ? 1 : nsl;
 }
 
-int ln_blocks(int rows) {
+int ln_blocks(int rows, int per_cu = 4) {
     int nb = mas_cdiv(rows, NT / 64);
-    const int cap = 4 * mas_num_cus();
+    const int cap = per_cu * mas_num_cus();
     return nb < cap ? nb : cap;
 }
 
@@ -396,30 +408,44 @@ extern "C" int mas_layernorm_fwd(const void* x, const float* gamma, const float*
 
 extern "C" size_t mas_layernorm_bwd_workspace(int rows, int D) {
     if (rows <= 0 || D <= 0) return 0;
-    return ((size_t)ln_blocks(rows) + LN_SLICES) * 2 * (size_t)D * sizeof(float);      // per-block partials + the stage-1 slices
+    return (size_t)ln_blocks(rows) * 3 * (size_t)D * sizeof(float);                    // the per-block partials (dgamma, dbeta, column sum of dx)
 }
 
-extern "C" int mas_layernorm_bwd_add(const void* x, const void* dy, const float* gamma, const float* mean_rstd, const void* dx_add,
-                                     void* dx, float* dgamma, float* dbeta, int in_dtype, int out_dtype, int rows, int D,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int mas_layernorm_bwd_colsum(const void* x, const void* dy, const float* gamma, const float* mean_rstd, const void* dx_add,
+                                        void* dx, float* dgamma, float* dbeta, float* dx_colsum, int in_dtype, int out_dtype, int rows, int D,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
     MAS_ENTER();
     if (!x || !dy || !gamma || !mean_rstd || !dx || !dgamma || !dbeta || !workspace) MAS_FAIL(MAS_EINVAL, "layernorm_bwd: null argument");
     if (int rc = ln_check(in_dtype, out_dtype, rows, D, "layernorm_bwd")) return rc;
     if (workspace_bytes < mas_layernorm_bwd_workspace(rows, D)) MAS_FAIL(MAS_EINVAL, "layernorm_bwd: workspace too small");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int nblk = ln_blocks(rows);
+    // (the column-sum variant holds 16 more accumulators: 142 VGPRs, three waves per SIMD -- so three work-groups per CU, all resident)
+    const int nblk = ln_blocks(rows, dx_colsum ? 3 : 4);
     float* partial = reinterpret_cast<float*>(workspace);
-#define MAS_LN_BWD(TI, TO) hipLaunchKernelGGL((layernorm_bwd_kernel<TI, TO>), dim3(nblk), dim3(NT), 0, s, (const TI*)x, (const TO*)dy, gamma, mean_rstd, (TI*)dx, partial, rows, D, (const TI*)dx_add)
+#define MAS_LN_BWD(TI, TO)                                                                                                                 \
+    do {                                                                                                                                   \
+        if (dx_colsum) hipLaunchKernelGGL((layernorm_bwd_kernel<TI, TO, true>), dim3(nblk), dim3(NT), 0, s, (const TI*)x, (const TO*)dy, gamma, \
+                                          mean_rstd, (TI*)dx, partial, rows, D, (const TI*)dx_add);                                        \
+        else hipLaunchKernelGGL((layernorm_bwd_kernel<TI, TO, false>), dim3(nblk), dim3(NT), 0, s, (const TI*)x, (const TO*)dy, gamma,      \
+                                mean_rstd, (TI*)dx, partial, rows, D, (const TI*)dx_add);                                                  \
+    } while (0)
     if (in_dtype == MAS_BF16 && out_dtype == MAS_BF16) MAS_LN_BWD(bf16_t, bf16_t);
     else if (in_dtype == MAS_BF16) MAS_LN_BWD(bf16_t, float);
     else if (out_dtype == MAS_BF16) MAS_LN_BWD(float, bf16_t);
     else MAS_LN_BWD(float, float);
 #undef MAS_LN_BWD
-    float* tmp = partial + (size_t)nblk * 2 * D;                      // [LN_SLICES][2][D]
-    hipLaunchKernelGGL(layernorm_param_reduce, dim3(mas_cdiv(D, 32), LN_SLICES), dim3(NT), 0, s, partial, nblk, D, LN_SLICES, tmp, tmp + D, 2 * D);
-    hipLaunchKernelGGL(layernorm_param_reduce, dim3(mas_cdiv(D, 32), 1), dim3(NT), 0, s, tmp, LN_SLICES, D, 1, dgamma, dbeta, 0);
+    const int np = dx_colsum ? 3 : 2;
+    hipLaunchKernelGGL(fold_rows_kernel, dim3(mas_cdiv(D, 32), np), dim3(NT), 0, s, partial, nblk, D, (long long)np * D, (long long)D, dgamma, dbeta,
+                       dx_colsum);
     MAS_CHECK_LAUNCH("layernorm_bwd");
     return MAS_OK;
+}
+
+extern "C" int mas_layernorm_bwd_add(const void* x, const void* dy, const float* gamma, const float* mean_rstd, const void* dx_add,
+                                     void* dx, float* dgamma, float* dbeta, int in_dtype, int out_dtype, int rows, int D,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    return mas_layernorm_bwd_colsum(x, dy, gamma, mean_rstd, dx_add, dx, dgamma, dbeta, nullptr, in_dtype, out_dtype, rows, D, workspace,
+                                    workspace_bytes, stream);
 }
 
 extern "C" int mas_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, void* dx,
@@ -449,7 +475,7 @@ extern "C" int mas_colsum(const void* x, int dtype, int rows, int cols, float* o
         hipLaunchKernelGGL(colsum_partial<bf16_t>, dim3(mas_cdiv(cols, CS_NT * 8), nsl), dim3(CS_NT), 0, s, (const bf16_t*)x, rows, cols, nsl, tmp);
     else
         hipLaunchKernelGGL(colsum_partial<float>, dim3(mas_cdiv(cols, CS_NT * 4), nsl), dim3(CS_NT), 0, s, (const float*)x, rows, cols, nsl, tmp);
-    hipLaunchKernelGGL(colsum_final, dim3(mas_cdiv(cols, 32)), dim3(256), 0, s, tmp, nsl, cols, out);
+    hipLaunchKernelGGL(fold_rows_kernel, dim3(mas_cdiv(cols, 32), 1), dim3(NT), 0, s, tmp, nsl, cols, (long long)cols, 0LL, out, out, out);
     MAS_CHECK_LAUNCH("colsum");
     return MAS_OK;
 }

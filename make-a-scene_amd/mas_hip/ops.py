@@ -1106,7 +1106,7 @@ class _LayerNorm(torch.autograd.Function):
     x / dx have the input's dtype, y / residual / dy have ``out_dtype``; statistics and arithmetic are fp32."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, eps, out_dtype):
+    def forward(ctx, x, weight, bias, residual, eps, out_dtype, want_colsum=False):
         _require_cuda(x, "layer_norm")
         _check_dtype(x, "layer_norm")
         d = x.shape[-1]
@@ -1122,27 +1122,65 @@ class _LayerNorm(torch.autograd.Function):
         check(lib().mas_layernorm_fwd(_ptr(x), _ptr(w32), _ptr(b32), _ptr(residual), _ptr(y), _ptr(mr), _DT[x.dtype],
                                       _DT[out_dtype], rows, d, float(eps), _stream()), "layernorm_fwd")
         ctx.save_for_backward(x, weight, mr)
-        ctx.has_res, ctx.out_dtype = residual is not None, out_dtype
+        ctx.has_res, ctx.out_dtype, ctx.want_colsum = residual is not None, out_dtype, bool(want_colsum)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, mr = ctx.saved_tensors
-        dx, dg, db = _layer_norm_bwd(x, weight, mr, dy.to(ctx.out_dtype).contiguous(), ctx.out_dtype, None)
-        return dx, dg, db, (dy.to(ctx.out_dtype) if ctx.has_res else None), None, None
+        dx, dg, db = _layer_norm_bwd(x, weight, mr, dy.to(ctx.out_dtype).contiguous(), ctx.out_dtype, None, ctx.want_colsum)
+        return dx, dg, db, (dy.to(ctx.out_dtype) if ctx.has_res else None), None, None, None
 
 
-def _layer_norm_bwd(x, weight, mr, dy, out_dtype, dx_add):
+class _ColsumHint:
+    """The column sums of ONE gradient tensor, computed by the kernel that wrote it, for the node that receives it next.
+
+    A LayerNorm whose input is the output of a Linear layer (``LayerNorm.forward(..., producer_bias_grad=True)``: the sandwich
+    LayerNorms behind ``out_proj`` / ``lin2``) accumulates the column sums of its dx inside its backward kernel
+    (``mas_layernorm_bwd_colsum``); ``_LinearBf16.backward`` asks here before it launches ``mas_colsum`` on that same tensor.  One slot:
+    the entry holds a STRONG reference to dx, so the allocator cannot hand the same address to another tensor while the entry exists,
+    and a hit requires the same storage address, element count, column count and version counter (no in-place write since) -- anything
+    else (a Dropout in between, an accumulation, a hook that replaced the gradient) misses and the Linear computes its own sums."""
+
+    def __init__(self):
+        self.slot = None
+        self.hits = 0                                # (tests / probes read this)
+
+    def put(self, dx, sums):
+        self.slot = (dx, dx.data_ptr(), dx.numel(), dx.shape[-1], dx._version, sums)
+
+    def take(self, dy2):
+        ent, self.slot = self.slot, None
+        if ent is None:
+            return None
+        dx, ptr, numel, cols, version, sums = ent
+        if (dy2.data_ptr() == ptr and dy2.numel() == numel and dy2.shape[-1] == cols and dy2.dtype == dx.dtype and dy2.device == dx.device
+                and dy2._version == version and dx._version == version):
+            self.hits += 1
+            return sums
+        return None
+
+    def clear(self):
+        self.slot = None
+
+
+_colsum_hint = _ColsumHint()
+
+
+def _layer_norm_bwd(x, weight, mr, dy, out_dtype, dx_add, want_colsum=False):
     d = x.shape[-1]
     rows = x.numel() // d
     dx = torch.empty_like(x)
     dg = torch.empty(d, dtype=torch.float32, device=x.device)
     db = torch.empty(d, dtype=torch.float32, device=x.device)
+    dc = torch.empty(d, dtype=torch.float32, device=x.device) if want_colsum else None
     wsb = lib().mas_layernorm_bwd_workspace(rows, d)
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
     w32 = weight.detach().float().contiguous()
-    check(lib().mas_layernorm_bwd_add(_ptr(x), _ptr(dy), _ptr(w32), _ptr(mr), _ptr(dx_add), _ptr(dx), _ptr(dg), _ptr(db), _DT[x.dtype],
-                                      _DT[out_dtype], rows, d, _ptr(ws), wsb, _stream()), "layernorm_bwd")
+    check(lib().mas_layernorm_bwd_colsum(_ptr(x), _ptr(dy), _ptr(w32), _ptr(mr), _ptr(dx_add), _ptr(dx), _ptr(dg), _ptr(db), _ptr(dc),
+                                         _DT[x.dtype], _DT[out_dtype], rows, d, _ptr(ws), wsb, _stream()), "layernorm_bwd")
+    if want_colsum:
+        _colsum_hint.put(dx, dc)
     return dx, dg.to(weight.dtype), db.to(weight.dtype)
 
 
@@ -1179,9 +1217,10 @@ class _LayerNormFork(torch.autograd.Function):
         return dx, dg, db, None, None
 
 
-def layer_norm(x, weight, bias, eps=1e-5, residual=None, out_dtype=None):
+def layer_norm(x, weight, bias, eps=1e-5, residual=None, out_dtype=None, producer_bias_grad=False):
     """``out_dtype`` None: the residual's dtype if one is given, else the autocast dtype when autocast is on (the
-    consumer is a Linear that would cast anyway), else the input's dtype."""
+    consumer is a Linear that would cast anyway), else the input's dtype.  ``producer_bias_grad``: x is the output of a Linear layer --
+    the backward kernel also sums its dx over the rows and leaves the result for that layer's bias gradient (``_ColsumHint``)."""
     if out_dtype is None:
         if residual is not None:
             out_dtype = residual.dtype
@@ -1191,7 +1230,7 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None, out_dtype=None):
             out_dtype = x.dtype
     if out_dtype not in _DT:
         raise RuntimeError(f"layer_norm: output dtype {out_dtype} not supported")
-    return _LayerNorm.apply(x, weight, bias, residual, eps, out_dtype)
+    return _LayerNorm.apply(x, weight, bias, residual, eps, out_dtype, bool(producer_bias_grad))
 
 
 def layer_norm_fork(x, weight, bias, eps=1e-5, out_dtype=None):
@@ -1298,7 +1337,11 @@ class _LinearBf16(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dw = torch.mm(dy2.t(), x2).float()     # (fp32 straight from the accumulators is outside TunableOp: +1 ms per step, DESIGN history R2)
             if ctx.needs_input_grad[2]:
-                db = colsum(dy2)
+                db = _colsum_hint.take(dy2)             # (the LayerNorm backward that wrote this very tensor summed it)
+                if db is None:
+                    db = colsum(dy2)
+            else:
+                _colsum_hint.clear()
         return dx, dw, db
 
 

@@ -36,10 +36,12 @@ class LayerNorm(nn.LayerNorm):
     """nn.LayerNorm parameters / state_dict keys, HIP forward + backward; ``residual`` fuses the ``x + LN(.)`` of the
     sandwich LayerNorms (reference transformer.py:201-203,207-209)."""
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, producer_bias_grad=False):
+        """``producer_bias_grad``: x is the output of a ``Linear`` (out_proj / lin2 in front of the sandwich LayerNorms): the backward
+        kernel then also produces that layer's bias gradient (the column sums of its dx) instead of a separate pass over dx."""
         if not self.elementwise_affine or len(self.normalized_shape) != 1:
             raise NotImplementedError("libmas_hip LayerNorm: affine, over the last dimension")
-        return ops.layer_norm(x, self.weight, self.bias, self.eps, residual)
+        return ops.layer_norm(x, self.weight, self.bias, self.eps, residual, producer_bias_grad=producer_bias_grad)
 
     def fork(self, x):
         """-> (LN(x), x): the normalised tensor and the skip connection as outputs of ONE autograd node (their gradients are added
@@ -196,13 +198,14 @@ class TransformerLayer(nn.Module):
         ln, skip = self.ln_in.fork(x) if fork else (self.ln_in(self._prescale(x)), x)
         attn_out, new_cache = self.attn(ln, mask, False, cache)
         if self.cogview_sandwich_layernorm:
-            x = self.first_ln_sandwich(self._prescale(attn_out), residual=skip)     # x + LN(attn_out), one pass
+            x = self.first_ln_sandwich(self._prescale(attn_out), residual=skip,     # x + LN(attn_out), one pass
+                                       producer_bias_grad=not self.cogview_layernorm_prescale)
         else:
             x = skip + attn_out
         ln, skip = self.ln_out.fork(x) if fork else (self.ln_out(self._prescale(x)), x)
         mlp_out = self.mlp(ln)
         if self.cogview_sandwich_layernorm:
-            return self.second_ln_sandwich(mlp_out, residual=skip), new_cache
+            return self.second_ln_sandwich(mlp_out, residual=skip, producer_bias_grad=not self.cogview_layernorm_prescale), new_cache
         return skip + mlp_out, new_cache
 
     def _forward_cached(self, x, cache):

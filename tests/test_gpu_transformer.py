@@ -326,6 +326,78 @@ def test_layer_norm_fork_adds_the_skip_gradient_in_kernel(in_dtype, out_dtype):
     assert rel(xo3.grad, xr3.grad) < tol
 
 
+@pytest.mark.parametrize("rows,d,tin,tout", [(3 * 1536, 1024, torch.bfloat16, torch.float32), (130, 200, torch.bfloat16, torch.bfloat16),
+                                             (37, 64, torch.float32, torch.float32), (4100, 1024, torch.float32, torch.bfloat16)])
+def test_layer_norm_bwd_colsum_of_dx(rows, d, tin, tout):
+    """mas_layernorm_bwd_colsum: dx / dgamma / dbeta are those of mas_layernorm_bwd_add bit for bit where the work-group count is the same,
+    and the extra output is the fp32 column sum of dx AS STORED (within 1e-6 of sum|dx| per column of an fp64 sum), run-to-run bitwise."""
+    from mas_hip import ops
+    g = torch.Generator().manual_seed(rows + d)
+    x = (2.0 * torch.randn(rows, d, generator=g) + 0.5).to(tin).cuda()
+    w = (1.0 + 0.2 * torch.randn(d, generator=g)).cuda()
+    b = (0.1 * torch.randn(d, generator=g)).cuda()
+    go = torch.randn(rows, d, generator=g).to(tout).cuda()
+    y = torch.empty(rows, d, dtype=tout, device="cuda")
+    mr = torch.empty(rows, 2, dtype=torch.float32, device="cuda")
+    L = ops.lib()
+    ops.check(L.mas_layernorm_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), mr.data_ptr(), ops._DT[tin], ops._DT[tout], rows, d, 1e-5,
+                                  ops._stream()), "ln fwd")
+    dx0, dg0, db0 = ops._layer_norm_bwd(x, w, mr, go, tout, None, False)
+    ops._colsum_hint.clear()
+    dx1, dg1, db1 = ops._layer_norm_bwd(x, w, mr, go, tout, None, True)
+    dc = ops._colsum_hint.slot[5]
+    assert torch.equal(dx0, dx1)
+    rel = lambda a, c: float((a.double() - c.double()).norm() / c.double().norm())
+    assert rel(dg1, dg0) < 1e-6 and rel(db1, db0) < 1e-6                    # (4 vs 3 work-groups per CU: another summation order)
+    ref = dx1.double().sum(0)
+    scale = dx1.double().abs().sum(0) + 1e-30
+    assert dc.dtype == torch.float32 and dc.shape == (d,)
+    assert float(((dc.double() - ref).abs() / scale).max()) < 1e-6
+    ops._layer_norm_bwd(x, w, mr, go, tout, None, True)
+    assert torch.equal(dc, ops._colsum_hint.slot[5])
+    ops._colsum_hint.clear()
+
+
+def test_linear_bias_gradient_from_the_layer_norm_backward():
+    """Linear -> LayerNorm(residual) as the transformer layer composes them (reference transformer.py:201-203): with
+    ``producer_bias_grad`` the Linear's bias gradient comes out of the LayerNorm backward kernel (one hit of the hand-off, no
+    mas_colsum launch) and equals the separate column sum to fp32 summation-order accuracy; every other gradient is bitwise the
+    same.  A tensor that is not the one the LayerNorm wrote (Dropout in between) misses and falls back."""
+    from mas_hip import ops
+    from models.transformer import LayerNorm, Linear
+    torch.manual_seed(11)
+    lin, ln = Linear(256, 512).cuda(), LayerNorm(512, eps=1e-5).cuda()
+    x = torch.randn(4, 300, 256, device="cuda")
+    skip = torch.randn(4, 300, 512, device="cuda")
+    gy = torch.randn(4, 300, 512, device="cuda")
+
+    def run(flag, drop=None):
+        for p in list(lin.parameters()) + list(ln.parameters()):
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            t = lin(xi)
+            if drop is not None:
+                t = drop(t)
+            out = ln(t, residual=skip, producer_bias_grad=flag)
+        (out.float() * gy).sum().backward()
+        return xi.grad.clone(), [p.grad.clone() for p in list(lin.parameters()) + list(ln.parameters())]
+
+    h0 = ops._colsum_hint.hits
+    gx0, g0 = run(False)
+    assert ops._colsum_hint.hits == h0
+    gx1, g1 = run(True)
+    assert ops._colsum_hint.hits == h0 + 1 and ops._colsum_hint.slot is None
+    assert torch.equal(gx0, gx1) and torch.equal(g0[0], g1[0])              # dx, dW: the same tensors went through the same GEMMs
+    rel = lambda a, c: float((a.double() - c.double()).norm() / c.double().norm())
+    assert rel(g1[1], g0[1]) < 1e-6                                          # the bias gradient: another (fixed) summation order
+    assert rel(g1[2], g0[2]) < 1e-6 and rel(g1[3], g0[3]) < 1e-6
+    torch.manual_seed(1)
+    gx2, g2 = run(True, torch.nn.Dropout(0.1))                               # the Linear receives dropout's gradient, not the LayerNorm's
+    assert ops._colsum_hint.hits == h0 + 1 and ops._colsum_hint.slot is None
+    assert torch.isfinite(g2[1]).all()
+
+
 def test_linear_bf16_shadow_weights_follow_the_optimizer():
     """The bf16 copies of the Linear parameters are refreshed together when an optimizer step (or any in-place write that bumps
     ``_version``) made them stale, reused between steps, and dropped by invalidate_weight_cache()."""

@@ -40,7 +40,7 @@ def _cpu_ops(monkeypatch):
             out[:, i] = (torch.softmax(qq @ k.transpose(-1, -2), -1) @ v).reshape(b, d)
         return out
 
-    def layer_norm(x, w, b_, eps=1e-5, residual=None, out_dtype=None):
+    def layer_norm(x, w, b_, eps=1e-5, residual=None, out_dtype=None, producer_bias_grad=False):
         y = F.layer_norm(x, (x.shape[-1],), w, b_, eps)
         return y if residual is None else residual + y
 
