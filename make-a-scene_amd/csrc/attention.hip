@@ -390,8 +390,27 @@ constexpr int F2_STAGE = 2 * F2_TILE;             // K then V
 constexpr int F2_LDS = 2 * F2_STAGE;              // 32 KB
 constexpr int F2_OOB = (int)0x80000000;
 
+// -DFA_TRACE (tools/build_file_variant.sh, never the shipped build): lane 0 of wave 3 of the heaviest work-group of (batch 0, head 0) sums
+// the 100 MHz wall clock over the phases of its key tiles (each phase closed by a read of its last result, so MFMA / LDS / VALU
+// latencies are inside the phase that caused them; every stamp is an s_memrealtime round trip of ~80 ns that lands in the phase it
+// closes); tools/kbench.py attn prints them.
+#ifdef FA_TRACE
+__device__ long long g_fa_trace[32];
+#define FA_T(i) do { if (fa_tr) { const long long now_ = wall_clock64(); fa_acc[i] += now_ - fa_last; fa_last = now_; } } while (0)
+#define FA_FORCE(x) do { if (fa_tr) asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(fa_sink) : "v"(x)); } while (0)
+#else
+#define FA_T(i) do { } while (0)
+#define FA_FORCE(x) do { } while (0)
+#endif
 __global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnParams p) {
     using T = bf16_t;
+#ifdef FA_TRACE
+    const bool fa_tr = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 192;
+    long long fa_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long fa_t0 = wall_clock64();
+    long long fa_last = fa_t0;
+    int fa_sink = 0;
+#endif
     constexpr int HD = 64, KT2 = 64, NKK = 4, NMI = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)fa_smem;
@@ -458,6 +477,7 @@ __global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnPara
     const int n_tiles = q_last / KT2 + 1;
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FA_T(0);                                         // prologue: Q loads + the first tile's DMA
     // the Q fragments are USED here, before the loop: the compiler then places its own wait for their global loads here and not in
     // front of the first MFMA of every tile -- where a vmcnt(0) also waits for the DMA of the NEXT tile that was issued a few
     // instructions earlier (the counter cannot tell the two apart), i.e. exposes the whole prefetch latency once per tile
@@ -475,6 +495,7 @@ __global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnPara
 #else
         (void)more;
 #endif
+        FA_T(1);                                     // DMA issue
         if (k0 <= qw + 31) {                         // wave-uniform: otherwise the tile is entirely above this wave's diagonal
             const unsigned char* kt = fa_smem + ST * F2_STAGE;
             const unsigned char* vt = kt + F2_TILE;
@@ -497,6 +518,8 @@ __global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnPara
                 }
             }
 #endif
+            FA_FORCE(s[1][15]);
+            FA_T(2);                                                // K fragment reads + score MFMAs
             if ((k0 + KT2 - 1 > qw) || (k0 + KT2 > p.S)) {          // tile touches the diagonal or the sequence end: mask
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
@@ -561,6 +584,9 @@ __global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnPara
 #pragma unroll
                     for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
             }
+            FA_FORCE(l);
+            FA_FORCE(s[1][15]);
+            FA_T(3);                                                // mask + softmax (+ rescale)
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -580,9 +606,13 @@ __global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnPara
 #endif
                 }
         }
+        FA_FORCE(oacc[1][15]);
+        FA_T(4);                                                     // converts + V^T fragment reads + P V MFMAs
 #ifndef FA_ABL_NOBAR
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of the next tile have landed
+        FA_T(5);                                                     // wait for the next tile's DMA
         __syncthreads();
+        FA_T(6);                                                     // work-group barrier
 #endif
     };
     for (int it = 0; it < n_tiles; it += 2) {
@@ -604,8 +634,23 @@ __global__ __launch_bounds__(NT, 4) void attn_causal_fwd_bf16_v2_kernel(AttnPara
             }
         if (p.lse && g == 0) p.lse[((size_t)b * p.H + h) * p.S + query] = m * 0.6931471805599453f + __logf(l);
     }
+#ifdef FA_TRACE
+    FA_T(7);                                         // epilogue
+    if (fa_tr) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g_fa_trace[i] = fa_acc[i];
+        g_fa_trace[8] = n_tiles; g_fa_trace[9] = fa_t0; g_fa_trace[10] = fa_last;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == gridDim.y - 1 && threadIdx.x == 0) { g_fa_trace[11] = fa_t0; g_fa_trace[12] = wall_clock64(); }   // the lightest block of the same head
+    (void)fa_sink;
+#endif
 }
 
+#ifdef FA_TRACE
+}  // namespace
+extern "C" int mas_fa_trace(long long* out32) { return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_fa_trace), sizeof(long long) * 32); }
+namespace {
+#endif
 int launch_fwd_fast_v2(const AttnParams& p, hipStream_t s) {
     AttnParams q = p;
     q.lpt = fa_lpt();

@@ -117,6 +117,20 @@ def main():
         fl = 4.0 * b * h * sq * sq * hd / 2          # causal: half of the full S x S products
         ms = timeit(lambda: ops.causal_attention(qkv.detach(), h), a.iters)
         print(f"attn fwd B={b} H={h} S={sq} hd={hd} {a.dtype}: {ms:.4f} ms  {fl/ms/1e9:.1f} TFLOP/s (causal FLOPs)")
+        import ctypes
+        from mas_hip import lib
+        tr = getattr(lib(), "mas_fa_trace", None)           # only in a -DFA_TRACE variant build (tools/build_file_variant.sh)
+        if tr is not None:
+            ops.causal_attention(qkv.detach(), h); torch.cuda.synchronize()
+            buf = (ctypes.c_longlong * 32)()
+            tr.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
+            tr(buf)
+            t = list(buf)
+            names = ["prologue (Q, first DMA)", "DMA issue", "K reads + score MFMAs", "mask + softmax", "cvt + V reads + PV MFMAs", "DMA wait", "barrier", "epilogue"]
+            nt = max(int(t[8]), 1)
+            print(f"attn fwd phases of wave 3 of the heaviest work-group ({nt} key tiles; us total / ns per tile): "
+                  + "; ".join(f"{nm} {t[i]/100:.2f}" + (f" / {t[i]*10/nt:.0f}" if 1 <= i <= 6 else "") for i, nm in enumerate(names)))
+            print(f"  that work-group ran {(t[10]-t[9])/100:.2f} us; the lightest work-group of the same head started {(t[11]-t[9])/100:.2f} us after it and ran {(t[12]-t[11])/100:.2f} us")
         go = torch.randn(b, sq, h * hd, device=dev).to(dt)
         def fb():
             qkv.grad = None
