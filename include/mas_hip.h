@@ -241,8 +241,9 @@ size_t mas_vq_workspace(int M, int K);
 int    mas_vq_argmin_fwd(const float* z, const float* codebook, int M, int K, int D,
                          int64_t* idx, float* zq, float* sqerr, void* workspace, size_t ws_bytes, void* stream);
 /* backward of (z_q straight-through, loss):  dz = g_zq + g_loss*2/(M*D)*(z-e[idx]);
- * dcodebook[idx] += g_loss*beta*2/(M*D)*(e[idx]-z)   (dcodebook zero-filled by caller).
- * g_loss is a device scalar.                                                          */
+ * dcodebook[idx] += g_loss*beta*2/(M*D)*(e[idx]-z).  For D <= 256, D % 4 == 0 (every codebook_dim of mas_vq_argmin_fwd) EVERY row of
+ * dcodebook is written, summed in a fixed order (no atomics: bitwise run-to-run deterministic, no zero fill needed); other D add
+ * with fp32 atomics into a buffer the caller zero-filled.  g_loss is a device scalar.                                            */
 int    mas_vq_bwd(const float* z, const float* codebook, const int64_t* idx, const float* g_zq,
                   const float* g_loss, float beta, int M, int K, int D, float* dz, float* dcodebook, void* stream);
 

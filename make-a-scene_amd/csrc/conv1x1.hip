@@ -332,16 +332,106 @@ static bool pw_wgrad_setup(const MasConvDesc* d, PwWgradParams& p) {
     return true;
 }
 
-// split-K factor of the 1x1 weight-gradient kernel for this convolution, 0 when it does not take it (mas_conv_wgrad_splits forwards here)
+// ---- fp32 1x1 weight gradient (quant_conv / post_quant_conv around the quantiser: reference models/vqvae.py, fp32 also under autocast) --
+// dW[co][ci] = sum_p dy[p][co] x[p][ci] in exact fp32 FMAs, split over the pixels into slabs [nsplit][Cout][Cin] that mas_wgrad_reduce
+// folds in a fixed order: bitwise run-to-run deterministic, where the general fp32 kernel of conv_wgrad.hip commits with fp32 atomics
+// (round 5: these two layers and the codebook were the last parameter gradients of the VQ-IMG step that were not).  A work-group =
+// 64 couts x 64 cins x one pixel slice, 32 pixels per LDS stage, 4 x 4 outputs per thread.  1 GFLOP per layer: no MFMA needed.
+namespace {
+constexpr int PF_NT = 256, PF_T = 64, PF_PX = 32;
+struct PwF32Params {
+    const float* dy; const float* x; float* part; float* part_bias;
+    int M, Cout, Cin, n_co_t, n_ci_t, nsplit, px_per_split;
+};
+__global__ __launch_bounds__(PF_NT) void wgrad1x1_f32_kernel(PwF32Params p) {
+    __shared__ __attribute__((aligned(16))) float dys[PF_PX][PF_T];
+    __shared__ __attribute__((aligned(16))) float xs[PF_PX][PF_T];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    int b = blockIdx.x;
+    const int split = b % p.nsplit; b /= p.nsplit;
+    const int ci_t = b % p.n_ci_t, co_t = b / p.n_ci_t;
+    const int co0 = co_t * PF_T, ci0 = ci_t * PF_T;
+    const int p_lo = split * p.px_per_split, p_hi = min(p.M, p_lo + p.px_per_split);
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+    float bsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int pb = p_lo; pb < p_hi; pb += PF_PX) {
+        __syncthreads();
+#pragma unroll
+        for (int u = tid; u < PF_PX * PF_T / 4; u += PF_NT) {                 // two float4 per thread and tensor
+            const int pr = u / (PF_T / 4), c4 = (u % (PF_T / 4)) * 4;
+            const int px = pb + pr;
+            f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f}, c = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (px < p_hi) {
+                if (co0 + c4 < p.Cout) a = *reinterpret_cast<const f32x4*>(p.dy + (size_t)px * p.Cout + co0 + c4);       // (Cout, Cin % 4 == 0)
+                if (ci0 + c4 < p.Cin) c = *reinterpret_cast<const f32x4*>(p.x + (size_t)px * p.Cin + ci0 + c4);
+            }
+            *reinterpret_cast<f32x4*>(&dys[pr][c4]) = a;
+            *reinterpret_cast<f32x4*>(&xs[pr][c4]) = c;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int pr = 0; pr < PF_PX; ++pr) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&dys[pr][ty * 4]);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(&xs[pr][tx * 4]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bsum[i] += a[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(a[i], c[j], acc[i][j]);
+            }
+        }
+    }
+    float* pw = p.part + (size_t)split * ((size_t)p.Cout * p.Cin);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = co0 + ty * 4 + i, ci = ci0 + tx * 4;
+        if (co < p.Cout && ci < p.Cin) *reinterpret_cast<f32x4*>(pw + (size_t)co * p.Cin + ci) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+        if (p.part_bias && ci_t == 0 && tx == 0 && co < p.Cout) p.part_bias[(size_t)split * p.Cout + co] = bsum[i];
+    }
+}
+bool pw_f32_setup(const MasConvDesc* d, PwF32Params& p) {
+    static const int on = mas_env_int("MAS_WGRAD1X1_F32", 1);
+    if (!on) return false;
+    if (d->ks != 1 || d->stride != 1 || d->upsample || d->act != MAS_ACT_NONE || d->pad_top || d->pad_left) return false;
+    if (d->in_dtype != MAS_F32 || d->Cin % 4 || d->Cout % 4 || d->Ho != d->H || d->Wo != d->W) return false;
+    const long long M = (long long)d->N * d->H * d->W;
+    if (M <= 0 || M >= 0x7fffffffLL) return false;
+    p.M = (int)M; p.Cout = d->Cout; p.Cin = d->Cin; p.n_co_t = mas_cdiv(d->Cout, PF_T); p.n_ci_t = mas_cdiv(d->Cin, PF_T);
+    const int tiles = p.n_co_t * p.n_ci_t;
+    int ns = mas_cdiv(2 * mas_num_cus(), tiles);                               // ~two work-groups per CU
+    const int max_ns = mas_cdiv(p.M, 4 * PF_PX);                                  // at least four LDS stages per work-group
+    if (ns > max_ns) ns = max_ns;
+    if (ns > 256) ns = 256;
+    if (ns < 1) ns = 1;
+    p.px_per_split = mas_roundup(mas_cdiv(p.M, ns), PF_PX);
+    p.nsplit = mas_cdiv(p.M, p.px_per_split);
+    return true;
+}
+}  // namespace
+
+// split-K factor of the 1x1 weight-gradient kernels for this convolution, 0 when neither takes it (mas_conv_wgrad_splits forwards here)
 int mas_wgrad1x1_splits(const MasConvDesc* d) {
     PwWgradParams p;
-    return pw_wgrad_setup(d, p) ? p.nsplit : 0;
+    if (pw_wgrad_setup(d, p)) return p.nsplit;
+    PwF32Params q;
+    return pw_f32_setup(d, q) ? q.nsplit : 0;
 }
 
 // part [nsplit][Cout][Cin] fp32 and (non-NULL) part_bias [nsplit][Cout], every element written once (see mas_conv_wgrad_partial)
 int mas_wgrad1x1_partial(const MasConvDesc* d, const void* x, const void* dy, float* part, float* part_bias, hipStream_t s) {
     PwWgradParams p;
-    if (!pw_wgrad_setup(d, p)) return 0;
+    if (!pw_wgrad_setup(d, p)) {
+        PwF32Params q;
+        if (!pw_f32_setup(d, q)) return 0;
+        q.dy = (const float*)dy; q.x = (const float*)x; q.part = part; q.part_bias = part_bias;
+        hipLaunchKernelGGL(wgrad1x1_f32_kernel, dim3((unsigned)(q.n_co_t * q.n_ci_t * q.nsplit)), dim3(PF_NT), 0, s, q);
+        MAS_CHECK_LAUNCH("wgrad1x1_f32");
+        return 1;
+    }
     p.dy = (const unsigned char*)dy; p.x = (const unsigned char*)x; p.part = part; p.part_bias = part_bias;
     hipLaunchKernelGGL(wgrad1x1_kernel, dim3((unsigned)(p.n_co_t * p.n_ci_t * p.nsplit)), dim3(PW_NT), PW_LDS, s, p);
     MAS_CHECK_LAUNCH("wgrad1x1");

@@ -154,6 +154,55 @@ __global__ __launch_bounds__(NT) void vq_bwd_kernel(const float* __restrict__ z,
     }
 }
 
+// The codebook gradient without atomics (round 5: the scatter-add above was the last order-dependent sum of the VQ-IMG step besides
+// the fp32 1x1 convolutions).  A work-group owns VB_CODES codebook rows; its four waves scan one quarter of the M indices each (64 per
+// ballot), and for every position that picked one of its codes a wave adds the 4 D-float row -c beta (z - e) into its OWN LDS
+// accumulator, in position order; the four accumulators are folded in wave order and EVERY row of the range is stored (zeros
+// included: the output needs no fill).  Fixed order: bitwise run-to-run deterministic.  D <= 256, D % 4 == 0.
+constexpr int VB_CODES = 8;
+__global__ __launch_bounds__(NT) void vq_bwd_codebook_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                             const int64_t* __restrict__ idx, const float* __restrict__ g_loss, float beta,
+                                                             int M, int K, int D, float* __restrict__ dcb) {
+    __shared__ __attribute__((aligned(16))) float accs[NT / 64][VB_CODES][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k0 = blockIdx.x * VB_CODES;
+    for (int i = tid; i < (NT / 64) * VB_CODES * 256; i += NT) (&accs[0][0][0])[i] = 0.0f;
+    __syncthreads();
+    const float cbeta = -(g_loss ? g_loss[0] : 0.0f) * 2.0f / (float)((long long)M * D) * beta;
+    const int per = (M + NT / 64 - 1) / (NT / 64);
+    const int lo = wave * per, hi = min(M, lo + per);
+    const int d4 = lane * 4;
+    for (int base = lo; base < hi; base += 64) {
+        const int m_l = base + lane;
+        const int k_l = m_l < hi ? (int)idx[m_l] - k0 : -1;
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(k_l >= 0 && k_l < VB_CODES);
+        while (mask) {
+            const int bit = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int kk = __builtin_amdgcn_readlane(k_l, bit);
+            const int m = base + bit;
+            if (d4 < D) {
+                const f32x4 zv = *reinterpret_cast<const f32x4*>(z + (size_t)m * D + d4);
+                const f32x4 ev = *reinterpret_cast<const f32x4*>(cb + (size_t)(k0 + kk) * D + d4);
+                f32x4 a = *reinterpret_cast<f32x4*>(&accs[wave][kk][d4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] += cbeta * (zv[e] - ev[e]);
+                *reinterpret_cast<f32x4*>(&accs[wave][kk][d4]) = a;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < VB_CODES * D; i += NT) {
+        const int code = i / D, d = i - code * D;
+        if (k0 + code < K) {
+            float t = accs[0][code][d];
+#pragma unroll
+            for (int w = 1; w < NT / 64; ++w) t += accs[w][code][d];
+            dcb[(size_t)(k0 + code) * D + d] = t;
+        }
+    }
+}
+
 int pick_ksplit(int M, int K) {
     const int rb = mas_cdiv(M, ROWS_PER_BLOCK), ntiles = mas_cdiv(K, CODES_PER_TILE);
     int ks = mas_cdiv(1024, rb);
@@ -205,12 +254,19 @@ extern "C" int mas_vq_bwd(const float* z, const float* codebook, const int64_t* 
                           float beta, int M, int K, int D, float* dz, float* dcodebook, void* stream) {
     MAS_ENTER();
     if (!z || !codebook || !idx) MAS_FAIL(MAS_EINVAL, "vq_bwd: null argument");
-    (void)K;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     long long total = (long long)M * D;
     int blocks = (int)((total + NT - 1) / NT);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(vq_bwd_kernel, dim3(blocks), dim3(NT), 0, s, z, codebook, idx, g_zq, g_loss, beta, M, D, dz, dcodebook);
-    MAS_CHECK_LAUNCH("vq_bwd");
+    static const int det = mas_env_int("MAS_VQ_BWD_DET", 1);
+    const bool fixed_order = det && dcodebook && K > 0 && D <= 256 && D % 4 == 0;       // (else: fp32 atomics into a zeroed dcodebook)
+    if (dz || (dcodebook && !fixed_order)) {
+        hipLaunchKernelGGL(vq_bwd_kernel, dim3(blocks), dim3(NT), 0, s, z, codebook, idx, g_zq, g_loss, beta, M, D, dz, fixed_order ? nullptr : dcodebook);
+        MAS_CHECK_LAUNCH("vq_bwd");
+    }
+    if (fixed_order) {
+        hipLaunchKernelGGL(vq_bwd_codebook_kernel, dim3((unsigned)mas_cdiv(K, VB_CODES)), dim3(NT), 0, s, z, codebook, idx, g_loss, beta, M, K, D, dcodebook);
+        MAS_CHECK_LAUNCH("vq_bwd_codebook");
+    }
     return MAS_OK;
 }

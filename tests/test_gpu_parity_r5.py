@@ -275,3 +275,75 @@ def test_conv_out_forward_on_the_thin_kernel(case):
         assert e < (2e-3 if out_dt == torch.float32 else 1e-2), e
     finally:
         ops.set_compute_dtype(old)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# 5. the last order-dependent sums of the VQ-IMG step: codebook gradient and the fp32 1x1 weight gradients, now in a fixed order
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [(32, 256, 16, 8192), (3, 256, 7, 16), (2, 64, 5, 100), (1, 32, 3, 9)], ids=lambda c: "x".join(map(str, c)))
+def test_vq_codebook_gradient_fixed_order(case):
+    """mas_vq_bwd (reference models/modules.py:501-519 through autograd: d/de of beta * mse(z.detach(), e[idx])): every row of the
+    codebook gradient equals the fp64 scatter-add, rows no position picked are exactly zero, collisions (16 codes for 147 positions)
+    are summed right, and three runs agree bit for bit; the atomics path (MAS_VQ_BWD_DET=0 is read once per process, so only the
+    default is exercised here) gave 1-3e-7 run-to-run differences on the same inputs"""
+    from mas_hip import ops
+    dev = _dev()
+    n, d, hw, k = case
+    g = torch.Generator().manual_seed(n * 131 + k)
+    z = torch.randn(n, d, hw, hw, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    cb = (0.5 * torch.randn(k, d, generator=g)).to(dev)
+
+    def run():
+        zi = z.clone().requires_grad_(True)
+        ci = cb.clone().requires_grad_(True)
+        zq, loss, idx = ops.vq_lookup(zi, ci, 0.25)
+        ((zq * 0.0).sum() + 3.0 * loss).backward()
+        return ci.grad.clone(), idx.clone(), zi.grad.clone()
+
+    g1, idx, dz1 = run()
+    g2, _, dz2 = run()
+    g3, _, _ = run()
+    assert torch.equal(g1, g2) and torch.equal(g1, g3) and torch.equal(dz1, dz2)
+    zf = z.permute(0, 2, 3, 1).reshape(-1, d).double()
+    e = cb.double()[idx.reshape(-1)]
+    m = zf.shape[0]
+    ref = torch.zeros(k, d, dtype=torch.float64, device=dev)
+    ref.index_add_(0, idx.reshape(-1), 3.0 * 0.25 * 2.0 / (m * d) * (e - zf))
+    used = torch.zeros(k, dtype=torch.bool, device=dev)
+    used[idx.reshape(-1)] = True
+    assert float(g1[~used].abs().max()) == 0.0 if (~used).any() else True
+    err = float((g1.double() - ref).abs().max() / ref.abs().max())
+    print(case, "codebook gradient vs fp64 scatter-add: %.3e" % err)
+    assert err < 1e-6, err
+
+
+@pytest.mark.parametrize("case", [(32, 256, 256, 16, 16), (3, 256, 64, 9, 7), (2, 12, 20, 5, 5)], ids=lambda c: "x".join(map(str, c)))
+def test_fp32_1x1_weight_gradient_fixed_order(case):
+    """quant_conv / post_quant_conv (reference models/vqvae.py: 1x1 convolutions around the quantiser, fp32 also when the model computes in
+    bf16): weight and bias gradient from split-K slabs of exact fp32 FMAs (wgrad1x1_f32_kernel + the fixed-order fold) against fp64,
+    three runs bit-identical; ragged 64-channel tiles and pixel slices"""
+    from mas_hip import ops
+    dev = _dev()
+    n, cin, cout, h, w = case
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(n, cin, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(n, cout, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+
+    def run():
+        return ops.conv_wgrad_raw(x, None, dy, n, h, w, cin, h, w, cout, 1, 1, 0, 0, ops.ACT_NONE, False, True)
+
+    dw1, db1 = run()
+    dw2, db2 = run()
+    dw3, db3 = run()
+    assert torch.equal(dw1, dw2) and torch.equal(dw1, dw3) and torch.equal(db1, db2) and torch.equal(db1, db3)
+    xf = x.permute(0, 2, 3, 1).reshape(-1, cin).double()
+    df = dy.permute(0, 2, 3, 1).reshape(-1, cout).double()
+    ref_w, ref_b = df.t() @ xf, df.sum(0)
+    ew = float((dw1.reshape(cout, cin).double() - ref_w).abs().max() / ref_w.abs().max())
+    eb = float((db1.double() - ref_b).abs().max() / ref_b.abs().max())
+    print(case, "fp32 1x1 wgrad vs fp64: dW %.3e db %.3e" % (ew, eb))
+    assert ew < 2e-6 and eb < 2e-6, (ew, eb)
+    if cin % 4 == 0 and cout % 4 == 0:
+        d = ops._desc(n, h, w, cin, h, w, cout, 1, 1, 0, 0, torch.float32, torch.float32, ops.ACT_NONE, False)
+        import ctypes
+        assert int(ops.lib().mas_conv_wgrad_splits(ctypes.byref(d))) > 0
