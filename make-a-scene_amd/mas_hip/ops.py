@@ -1230,7 +1230,10 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None, out_dtype=None, produce
             out_dtype = x.dtype
     if out_dtype not in _DT:
         raise RuntimeError(f"layer_norm: output dtype {out_dtype} not supported")
-    return _LayerNorm.apply(x, weight, bias, residual, eps, out_dtype, bool(producer_bias_grad))
+    # (only when x really is what a ``_LinearBf16`` node returned: any other producer -- nn.Linear outside autocast, a Dropout with
+    # p > 0, a prescale -- would never take the sums, and the slot would keep dx alive for nothing)
+    want = bool(producer_bias_grad) and x.grad_fn is not None and type(x.grad_fn).__name__.startswith("_LinearBf16")
+    return _LayerNorm.apply(x, weight, bias, residual, eps, out_dtype, want)
 
 
 def layer_norm_fork(x, weight, bias, eps=1e-5, out_dtype=None):

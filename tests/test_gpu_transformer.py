@@ -396,6 +396,17 @@ def test_linear_bias_gradient_from_the_layer_norm_backward():
     gx2, g2 = run(True, torch.nn.Dropout(0.1))                               # the Linear receives dropout's gradient, not the LayerNorm's
     assert ops._colsum_hint.hits == h0 + 1 and ops._colsum_hint.slot is None
     assert torch.isfinite(g2[1]).all()
+    # the hand-off itself: sums are given out for the very tensor they were computed from, once, and for nothing else
+    a, b = torch.randn(8, 16, device="cuda").bfloat16(), torch.randn(8, 16, device="cuda").bfloat16()
+    sums = torch.zeros(16, device="cuda")
+    ops._colsum_hint.put(a, sums)
+    assert ops._colsum_hint.take(b) is None and ops._colsum_hint.slot is None          # another tensor: miss, slot dropped
+    ops._colsum_hint.put(a, sums)
+    a.add_(1)                                                                          # written since: the version counter moved
+    assert ops._colsum_hint.take(a) is None
+    ops._colsum_hint.put(a, sums)
+    assert ops._colsum_hint.take(a.view(-1, 16)) is sums and ops._colsum_hint.take(a) is None
+    ops._colsum_hint.hits = h0 + 1
 
 
 def test_linear_bf16_shadow_weights_follow_the_optimizer():
