@@ -76,6 +76,24 @@ def test_three_launch_backward_vs_cpu_fp32(shape, act, res):
     assert _rel(dg, dg_ref) < 2e-3 and _rel(db, db_ref) < 2e-3, (_rel(dg, dg_ref), _rel(db, db_ref))
 
 
+@pytest.mark.parametrize("shift,scale", [(8.0, 1.0), (-20.0, 0.5), (3.0, 6.0)])
+def test_three_launch_backward_with_a_large_mean(shift, scale):
+    """The partial pass keeps its second sum raw (sum du * x) and the finalize kernel forms rstd * (sum du * x - mean * sum du) in
+    fp64 (round 5): inputs whose mean is 5-40 standard deviations away from zero (where that difference cancels most of its digits)
+    still give the gradients of torch's fp32 autograd on the same bf16-rounded operands"""
+    dev = _dev()
+    g = torch.Generator().manual_seed(int(abs(shift) * 10 + scale))
+    n, c, h, w = 3, 128, 40, 56
+    x = (torch.randn(n, c, h, w, generator=g) * scale + shift).bfloat16()
+    da = torch.randn(n, c, h, w, generator=g).bfloat16()
+    gamma = 1.0 + 0.1 * torch.randn(c, generator=g)
+    beta = 0.1 * torch.randn(c, generator=g)
+    for act in (1, 2):
+        rdx, rdg, rdb = _reference(x, da, None, gamma, beta, act)
+        dx, dg, db = _run(dev, x, da, None, gamma, beta, act)
+        assert _rel(dx, rdx) < 2e-2 and _rel(dg, rdg) < 2e-3 and _rel(db, rdb) < 2e-3, (act, _rel(dx, rdx), _rel(dg, rdg), _rel(db, rdb))
+
+
 def test_backward_is_bitwise_reproducible_also_under_concurrent_load():
     """Two quiet runs and one run beside a stream of large GEMMs: bit-identical dx / dgamma / dbeta -- the sums keep a fixed order."""
     dev = _dev()
