@@ -259,12 +259,12 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const TI* __restrict_
     }
 }
 
-// dgamma / dbeta = fixed-order sum of the per-block partials [nblk][2][D] in ONE launch: grid (D/32, 2) -- work-group (cb, which) owns 32
-// columns of dgamma (which = 0), dbeta (1) or the column sum of dx (2, when asked for); 8 threads x float4 cover the 128-byte column segment of a partial row, 32 row groups
-// take rows rg, rg + 32, ... (four 16-byte loads in flight), LDS folds the row groups in a fixed order: bitwise run-to-run
-// deterministic.  (Round 1 ran D/32 work-groups of scalar loads over 8 MB of partials: 40 us per LayerNorm backward; rounds 2-4 two
-// launches -- 8 slices, then their sum -- 2 x 5.4 us + the dependent-launch gap, 196 launches per MakeAScene step.  64 work-groups of
-// 16-byte loads read the same 8 MB in one.)
+// dgamma / dbeta = fixed-order sum of the per-block partials [nblk][NP][D] in ONE launch: grid (D/32, NP) -- work-group (cb, which) owns
+// 32 columns of dgamma (which = 0), dbeta (1) or the column sum of dx (2, when asked for); 8 threads x float4 cover the 128-byte
+// column segment of a partial row, 32 row groups take rows rg, rg + 32, ... (four 16-byte loads in flight), LDS folds the row groups
+// in a fixed order: bitwise run-to-run deterministic.  (Round 1 ran D/32 work-groups of scalar loads over 8 MB of partials: 40 us per
+// LayerNorm backward; rounds 2-4 two launches -- 8 slices, then their sum -- 2 x 5.4 us + the dependent-launch gap, 196 launches per
+// MakeAScene step.  64-96 work-groups of 16-byte loads read the same 8-12 MB in one.)
 // The same kernel folds the column-sum slices (colsum below): row_stride / which_stride describe the table.
 __global__ __launch_bounds__(NT) void fold_rows_kernel(const float* __restrict__ partial, int nblk, int D, long long row_stride,
                                                        long long which_stride, float* __restrict__ out_g, float* __restrict__ out_b,
