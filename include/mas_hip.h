@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAS_ABI_VERSION 7
+#define MAS_ABI_VERSION 8
 
 enum { MAS_OK = 0, MAS_EINVAL = -1, MAS_EUNSUPPORTED = -2, MAS_ELAUNCH = -3, MAS_EWORKSPACE = -4 };
 enum { MAS_F32 = 0, MAS_BF16 = 1 };
@@ -331,6 +331,28 @@ int mas_layernorm_bwd_colsum(const void* x, const void* dy, const float* gamma, 
  *   workspace: mas_colsum_workspace(rows, cols) bytes, caller-owned.                                                          */
 size_t mas_colsum_workspace(int rows, int cols);
 int mas_colsum(const void* x, int dtype, int rows, int cols, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * BatchNorm over [M][C] fp32 NHWC activations (ABI v8): the nn.SyncBatchNorm(embed_dim) behind quant_conv, reference models/vqvae.py:15-16
+ * (torch.nn.SyncBatchNorm: batch statistics exchanged across the process group in training, running statistics in evaluation).
+ * The library computes per-rank sums in a fixed order and takes GLOBAL sums back; the exchange itself (torch.distributed.all_reduce of
+ * the fp64 vector) is the host side's, exactly where torch's own SyncBatchNorm has it.  C % 4 == 0, C <= 1024.
+ *   mas_bn_partial_sums: sums[2 C + 1] (fp64) = { per-channel S1[C], S2[C], (double) M }:
+ *       dy == NULL : S1 = sum x,  S2 = sum x^2                      (forward statistics)
+ *       dy != NULL : S1 = sum dy, S2 = sum dy * (x - mean) * rstd   (backward; = dbeta, dgamma of this rank); mean_rstd [C][2] required
+ *   mas_bn_finalize   : from (global) sums: mean_rstd [C][2], scale_shift [C][2] (y = x * scale + shift with gamma / beta folded in;
+ *       gamma / beta NULL = 1 / 0) and the running statistics updated in place with `momentum` (unbiased variance, torch's convention;
+ *       running_* may be NULL); sums == NULL: evaluation mode, the pair comes from running_mean / running_var.
+ *   mas_bn_apply      : y = x * scale + shift.
+ *   mas_bn_bwd_apply  : dx = gamma * rstd * (dy - S1 / n - xhat * S2 / n) with the GLOBAL backward sums and n = sums[2 C].        */
+size_t mas_bn_workspace(int M, int C);
+int mas_bn_partial_sums(const float* x, const float* dy, const float* mean_rstd, int M, int C, double* sums, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int mas_bn_finalize(const double* sums, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                    float* running_var, float* mean_rstd, float* scale_shift, int C, void* stream);
+int mas_bn_apply(const float* x, const float* scale_shift, float* y, int M, int C, void* stream);
+int mas_bn_bwd_apply(const float* x, const float* dy, const float* mean_rstd, const float* gamma, const double* sums, float* dx, int M,
+                     int C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,210 @@
+// BatchNorm over [M][C] fp32 NHWC activations for gfx950: the `nn.SyncBatchNorm(embed_dim)` behind `quant_conv` (reference
+// models/vqvae.py:15-16), training (batch statistics, running-statistics update) and evaluation, forward and backward.
+//
+// The latent it normalises is tiny (32 x 16 x 16 x 256 fp32 = 8 MB): what matters is the launch count and a fixed summation order,
+// not bandwidth.  Every per-channel sum is two-stage -- per-work-group partial rows, then one fp64 fold in block order -- so the
+// statistics and both parameter gradients are bitwise reproducible run to run.  The sums leave the library as fp64 so that the host side
+// can all_reduce them across ranks (SyncBatchNorm's exchange: sum, sum of squares and element count in the forward; sum dy and
+// sum dy * xhat in the backward) and hand the GLOBAL sums back to the finalize / apply kernels, which read the element count from
+// device memory (no host synchronisation).
+#include "mas_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int BN_ROWS_PER_BLOCK = 128;
+constexpr int BN_MAX_BLOCKS = 1024;
+
+// per-work-group partial sums over a slice of rows: partial[blk][2][C]
+//   dy == nullptr: (sum x, sum x^2);  else (sum dy, sum dy * xhat) with xhat = (x - mean) * rstd
+// A thread owns a column quad q = tid % quads and walks rows rl, rl + R, ... of the slice (R = NT / quads row lanes); LDS folds the row
+// lanes in a fixed order.  C % 4 == 0, C <= 4 * NT.
+__global__ __launch_bounds__(NT) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ mean_rstd, int M, int C, int rows_per_block,
+                                                        float* __restrict__ partial) {
+    extern __shared__ float red[];                   // [R][2][C]
+    const int quads = C / 4, R = NT / quads > 0 ? NT / quads : 1;
+    const int tid = threadIdx.x, q = tid % quads, rl = tid / quads;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    f32x4 s1 = {0.0f, 0.0f, 0.0f, 0.0f}, s2 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (rl < R && q < quads) {
+        f32x4 mu = {0.0f, 0.0f, 0.0f, 0.0f}, rs = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (dy) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { mu[e] = mean_rstd[(4 * q + e) * 2]; rs[e] = mean_rstd[(4 * q + e) * 2 + 1]; }
+        }
+        for (int r = r0 + rl; r < r1; r += R) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)r * C + 4 * q);
+            if (dy) {
+                const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + (size_t)r * C + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * ((xv[e] - mu[e]) * rs[e]); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[(rl * 2 + 0) * C + 4 * q + e] = s1[e]; red[(rl * 2 + 1) * C + 4 * q + e] = s2[e]; }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * C; i += NT) {
+        float a = 0.0f;
+        for (int k = 0; k < R; ++k) a += red[k * 2 * C + i];
+        partial[(size_t)blockIdx.x * 2 * C + i] = a;
+    }
+}
+
+// sums[j] = sum over blocks of partial[blk][j] in fp64, block order; sums[2 C] = the element count of this rank
+__global__ __launch_bounds__(64) void bn_fold_kernel(const float* __restrict__ partial, int nblk, int C, double count, double* __restrict__ sums) {
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j < 2 * C) {
+        double a = 0.0;
+        int b = 0;
+        for (; b + 8 <= nblk; b += 8) {              // eight loads in flight, additions in block order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = partial[(size_t)(b + k) * 2 * C + j];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a += (double)v[k];
+        }
+        for (; b < nblk; ++b) a += (double)partial[(size_t)b * 2 * C + j];
+        sums[j] = a;
+    }
+    if (j == 0) sums[2 * C] = count;
+}
+
+// training: mean / rstd from the (global) sums, the affine pair y = x * scale + shift, and the running statistics (unbiased variance,
+// torch's convention); evaluation (sums == nullptr): the pair from the running statistics
+__global__ __launch_bounds__(NT) void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                         float* __restrict__ mean_rstd, float* __restrict__ scale_shift, int C) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= C) return;
+    double mean, var;
+    if (sums) {
+        const double n = sums[2 * C];
+        mean = sums[c] / n;
+        var = sums[C + c] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        if (running_var) running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * (n > 1.0 ? var * n / (n - 1.0) : var));
+    } else {
+        mean = running_mean[c];
+        var = running_var[c];
+    }
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? (double)gamma[c] : 1.0, b = beta ? (double)beta[c] : 0.0;
+    if (mean_rstd) { mean_rstd[2 * c] = (float)mean; mean_rstd[2 * c + 1] = (float)rstd; }
+    scale_shift[2 * c] = (float)(g * rstd);
+    scale_shift[2 * c + 1] = (float)(b - mean * g * rstd);
+}
+
+// y = x * scale + shift
+__global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale_shift, float* __restrict__ y,
+                                                      long long n4, int C) {
+    const int quads = C / 4;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
+        const int q = (int)(i % quads);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[e] * scale_shift[(4 * q + e) * 2] + scale_shift[(4 * q + e) * 2 + 1];
+        *reinterpret_cast<f32x4*>(y + i * 4) = o;
+    }
+}
+
+// dx = gamma * rstd * (dy - S1 / n - xhat * S2 / n) with the GLOBAL sums S1 = sum dy, S2 = sum dy * xhat and the global count n = sums[2 C]
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean_rstd,
+                                                          const float* __restrict__ gamma, const double* __restrict__ sums, float* __restrict__ dx,
+                                                          long long n4, int C) {
+    const int quads = C / 4;
+    const double n = sums[2 * C];
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
+        const int q = (int)(i % quads);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * q + e;
+            const float mu = mean_rstd[2 * c], rs = mean_rstd[2 * c + 1];
+            const float k1 = (float)(sums[c] / n), k2 = (float)(sums[C + c] / n);
+            const float g = gamma ? gamma[c] : 1.0f;
+            o[e] = g * rs * (dv[e] - k1 - (xv[e] - mu) * rs * k2);
+        }
+        *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+    }
+}
+
+int bn_blocks(int M) {
+    int nb = mas_cdiv(M, BN_ROWS_PER_BLOCK);
+    return nb > BN_MAX_BLOCKS ? BN_MAX_BLOCKS : (nb < 1 ? 1 : nb);
+}
+int bn_check(const char* what, int M, int C) {
+    if (M <= 0 || C <= 0) MAS_FAIL(MAS_EINVAL, "%s: bad shape M=%d C=%d", what, M, C);
+    if (C % 4 || C > 4 * NT) MAS_FAIL(MAS_EUNSUPPORTED, "%s: C=%d must be a multiple of 4 and <= %d", what, C, 4 * NT);
+    return MAS_OK;
+}
+int bn_grid(long long n4) {
+    long long g = (n4 + NT - 1) / NT;
+    const long long cap = 8LL * mas_num_cus();
+    return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" size_t mas_bn_workspace(int M, int C) {
+    if (M <= 0 || C <= 0) return 0;
+    return (size_t)bn_blocks(M) * 2 * (size_t)C * sizeof(float);
+}
+
+extern "C" int mas_bn_partial_sums(const float* x, const float* dy, const float* mean_rstd, int M, int C, double* sums, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    MAS_ENTER();
+    if (!x || !sums || !workspace) MAS_FAIL(MAS_EINVAL, "bn_partial_sums: null argument");
+    if (dy && !mean_rstd) MAS_FAIL(MAS_EINVAL, "bn_partial_sums: the backward sums need mean_rstd");
+    if (int rc = bn_check("bn_partial_sums", M, C)) return rc;
+    if (workspace_bytes < mas_bn_workspace(M, C)) MAS_FAIL(MAS_EWORKSPACE, "bn_partial_sums: workspace too small");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nblk = bn_blocks(M), rows_per_block = mas_cdiv(M, nblk);
+    const int quads = C / 4, R = NT / quads > 0 ? NT / quads : 1;
+    float* partial = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(nblk), dim3(NT), (size_t)R * 2 * C * sizeof(float), s, x, dy, mean_rstd, M, C, rows_per_block, partial);
+    MAS_CHECK_LAUNCH("bn_partial");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(mas_cdiv(2 * C, 64)), dim3(64), 0, s, partial, nblk, C, (double)M, sums);
+    MAS_CHECK_LAUNCH("bn_fold");
+    return MAS_OK;
+}
+
+extern "C" int mas_bn_finalize(const double* sums, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                               float* running_var, float* mean_rstd, float* scale_shift, int C, void* stream) {
+    MAS_ENTER();
+    if (!scale_shift || C <= 0) MAS_FAIL(MAS_EINVAL, "bn_finalize: null argument or C=%d", C);
+    if (!sums && (!running_mean || !running_var)) MAS_FAIL(MAS_EINVAL, "bn_finalize: evaluation mode needs the running statistics");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(mas_cdiv(C, NT)), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), sums, gamma, beta, eps, momentum,
+                       running_mean, running_var, mean_rstd, scale_shift, C);
+    MAS_CHECK_LAUNCH("bn_finalize");
+    return MAS_OK;
+}
+
+extern "C" int mas_bn_apply(const float* x, const float* scale_shift, float* y, int M, int C, void* stream) {
+    MAS_ENTER();
+    if (!x || !scale_shift || !y) MAS_FAIL(MAS_EINVAL, "bn_apply: null argument");
+    if (int rc = bn_check("bn_apply", M, C)) return rc;
+    const long long n4 = (long long)M * C / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(n4)), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), x, scale_shift, y, n4, C);
+    MAS_CHECK_LAUNCH("bn_apply");
+    return MAS_OK;
+}
+
+extern "C" int mas_bn_bwd_apply(const float* x, const float* dy, const float* mean_rstd, const float* gamma, const double* sums, float* dx, int M,
+                                int C, void* stream) {
+    MAS_ENTER();
+    if (!x || !dy || !mean_rstd || !sums || !dx) MAS_FAIL(MAS_EINVAL, "bn_bwd_apply: null argument");
+    if (int rc = bn_check("bn_bwd_apply", M, C)) return rc;
+    const long long n4 = (long long)M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(n4)), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), x, dy, mean_rstd, gamma, sums, dx, n4, C);
+    MAS_CHECK_LAUNCH("bn_bwd_apply");
+    return MAS_OK;
+}

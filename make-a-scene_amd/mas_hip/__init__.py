@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MAS_HIP_LIB") or os.path.join(_HERE, "libmas_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_AFFINE, ACT_AFFINE_SILU = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 WLAYOUT_K64, WLAYOUT_K32, WLAYOUT_UP2 = 0, 1, 2
 
 
@@ -105,6 +105,11 @@ _SIGNATURES = {
     "mas_layernorm_bwd_workspace": (_sz, [_i, _i]),
     "mas_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "mas_layernorm_bwd_add": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "mas_bn_workspace": (_sz, [_i, _i]),
+    "mas_bn_partial_sums": (_i, [_p, _p, _p, _i, _i, _p, _p, _sz, _p]),
+    "mas_bn_finalize": (_i, [_p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p]),
+    "mas_bn_apply": (_i, [_p, _p, _p, _i, _i, _p]),
+    "mas_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "mas_layernorm_bwd_colsum": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "mas_colsum_workspace": (_sz, [_i, _i]),
     "mas_colsum": (_i, [_p, _i, _i, _i, _p, _p, _sz, _p]),

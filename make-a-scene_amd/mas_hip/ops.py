@@ -950,6 +950,81 @@ def vq_lookup(z, codebook, beta):
 
 
 # --------------------------------------------------------------------------- #
+# SyncBatchNorm behind quant_conv (reference models/vqvae.py:15-16)
+# --------------------------------------------------------------------------- #
+def _bn_sums(x2d, dy2d, mean_rstd):
+    m, c = x2d.shape
+    sums = torch.empty(2 * c + 1, dtype=torch.float64, device=x2d.device)
+    wsb = lib().mas_bn_workspace(m, c)
+    ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=x2d.device)
+    check(lib().mas_bn_partial_sums(_ptr(x2d), _ptr(dy2d), _ptr(mean_rstd), m, c, _ptr(sums), _ptr(ws), wsb, _stream()), "bn_partial_sums")
+    return sums
+
+
+class _SyncBatchNorm(torch.autograd.Function):
+    """``torch.nn.SyncBatchNorm`` in training mode on an fp32 NHWC activation: per-rank sums (``mas_bn_partial_sums``, fixed order), ONE
+    all_reduce of the fp64 vector {sum, sum of squares, count} over ``group`` when it has more than one rank (torch's own module
+    gathers mean / invstd / count instead: the same statistics), then ``mas_bn_finalize`` (mean, rstd, the affine pair, running
+    statistics) and ``mas_bn_apply``; the backward exchanges {sum dy, sum dy * xhat} the same way and returns the LOCAL sums as
+    the weight / bias gradients, as torch does (data parallelism averages them afterwards)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running, eps, momentum, group):
+        running_mean, running_var = running                 # (buffers, updated in place: handed over in a tuple, outside autograd's view)
+        n, c, h, w = x.shape
+        x = nhwc(x, torch.float32)
+        x2 = x.permute(0, 2, 3, 1).reshape(-1, c)
+        sums = _bn_sums(x2, None, None)
+        if group is not None:
+            torch.distributed.all_reduce(sums, group=group)
+        mean_rstd = torch.empty((c, 2), dtype=torch.float32, device=x.device)
+        ss = torch.empty((c, 2), dtype=torch.float32, device=x.device)
+        w32 = weight.detach().float().contiguous() if weight is not None else None
+        b32 = bias.detach().float().contiguous() if bias is not None else None
+        check(lib().mas_bn_finalize(_ptr(sums), _ptr(w32), _ptr(b32), float(eps), float(momentum), _ptr(running_mean), _ptr(running_var),
+                                    _ptr(mean_rstd), _ptr(ss), c, _stream()), "bn_finalize")
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        check(lib().mas_bn_apply(_ptr(x), _ptr(ss), _ptr(y), n * h * w, c, _stream()), "bn_apply")
+        ctx.save_for_backward(x, w32 if w32 is not None else torch.empty(0, device=x.device), mean_rstd, sums[2 * c:].clone())
+        ctx.group, ctx.has_w, ctx.has_b = group, weight is not None, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w32, mean_rstd, count = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dy = nhwc(dy, torch.float32)
+        sums = _bn_sums(x.permute(0, 2, 3, 1).reshape(-1, c), dy.permute(0, 2, 3, 1).reshape(-1, c), mean_rstd)
+        db = sums[:c].float() if ctx.has_b else None            # this rank's sums: the parameter gradients
+        dg = sums[c:2 * c].float() if ctx.has_w else None
+        if ctx.group is not None:
+            torch.distributed.all_reduce(sums, group=ctx.group)
+            sums[2 * c:] = count                                # (= what the all_reduce summed; kept explicit: the forward's global count)
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        check(lib().mas_bn_bwd_apply(_ptr(x), _ptr(dy), _ptr(mean_rstd), _ptr(w32) if ctx.has_w else None, _ptr(sums), _ptr(dx), n * h * w, c,
+                                     _stream()), "bn_bwd_apply")
+        return dx, dg, db, None, None, None, None
+
+
+def sync_batch_norm(x, weight, bias, running_mean, running_var, eps, momentum, training, group=None):
+    """``nn.SyncBatchNorm.forward`` on a 4-D fp32 CUDA activation.  ``group``: a process group with more than one rank, or None (no
+    exchange).  Evaluation: the affine pair from the running statistics (``mas_bn_finalize`` with no sums) + ``mas_bn_apply``."""
+    _require_cuda(x, "sync_batch_norm")
+    n, c, h, w = x.shape
+    if training:
+        return _SyncBatchNorm.apply(x, weight, bias, (running_mean, running_var), eps, momentum, group)
+    x = nhwc(x, torch.float32)
+    ss = torch.empty((c, 2), dtype=torch.float32, device=x.device)
+    w32 = weight.detach().float().contiguous() if weight is not None else None
+    b32 = bias.detach().float().contiguous() if bias is not None else None
+    check(lib().mas_bn_finalize(None, _ptr(w32), _ptr(b32), float(eps), 0.0, _ptr(running_mean), _ptr(running_var), None, _ptr(ss), c, _stream()),
+          "bn_finalize")
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    check(lib().mas_bn_apply(_ptr(x), _ptr(ss), _ptr(y), n * h * w, c, _stream()), "bn_apply")
+    return y
+
+
+# --------------------------------------------------------------------------- #
 # single-head spatial attention core (AttnBlock, reference models/modules.py:174-187)
 # --------------------------------------------------------------------------- #
 class _SpatialAttention(torch.autograd.Function):

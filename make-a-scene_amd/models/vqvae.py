@@ -2,11 +2,11 @@
 (``ddconfig, n_embed, embed_dim, init_steps, reservoir_size``), same submodule names and
 ``state_dict`` keys (348 entries for conf/img_config.yaml), same ``encode/decode/decode_code/forward``.
 encoder -> quant_conv (1x1 conv + SyncBatchNorm) -> Codebook -> post_quant_conv -> decoder, every
-convolution / norm / lookup on the hand-written gfx950 kernels of libmas_hip.so."""
+convolution / norm (GroupNorm and, since round 5, the SyncBatchNorm) / lookup on the hand-written gfx950 kernels of libmas_hip.so."""
 import torch
 from torch import nn
 
-from .modules import Codebook, Conv2d, Decoder, Encoder
+from .modules import Codebook, Conv2d, Decoder, Encoder, SyncBatchNorm
 
 
 class VQBASE(nn.Module):
@@ -18,7 +18,7 @@ class VQBASE(nn.Module):
         # the latent tail is stored fp32 end to end: indices come from fp32 z
         qc = Conv2d(ddconfig["z_channels"], embed_dim, 1)
         qc.in_dtype = qc.out_dtype = torch.float32
-        self.quant_conv = nn.Sequential(qc, nn.SyncBatchNorm(embed_dim))
+        self.quant_conv = nn.Sequential(qc, SyncBatchNorm(embed_dim))
         self.post_quant_conv = Conv2d(embed_dim, ddconfig["z_channels"], 1)
         self.post_quant_conv.in_dtype = self.post_quant_conv.out_dtype = torch.float32
 

@@ -1,0 +1,143 @@
+"""SyncBatchNorm behind quant_conv (reference models/vqvae.py:15-16) on libmas_hip.so's BatchNorm kernels (batchnorm.hip; models.modules.SyncBatchNorm):
+against torch.nn.BatchNorm2d in one process (outputs, running statistics over two steps, all gradients, evaluation mode, cumulative
+momentum), bitwise run to run, and two ranks sharing the GPU over gloo against the full batch in one process.  (The model-level two-rank
+tests of tests/test_gpu_dp.py run through the same exchange.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _pair(c, momentum=0.1, affine=True, seed=0):
+    from models.modules import SyncBatchNorm
+    torch.manual_seed(seed)
+    ours = SyncBatchNorm(c, momentum=momentum, affine=affine).cuda()
+    ref = torch.nn.BatchNorm2d(c, momentum=momentum, affine=affine).cuda()
+    if affine:
+        with torch.no_grad():
+            ours.weight.copy_(1.0 + 0.2 * torch.randn(c)); ours.bias.copy_(0.1 * torch.randn(c))
+    ref.load_state_dict(ours.state_dict())
+    return ours, ref
+
+
+@pytest.mark.parametrize("shape", [(32, 256, 16, 16), (3, 12, 5, 7), (2, 1024, 4, 4), (1, 32, 1, 2), (5, 64, 33, 9)], ids=lambda s: "x".join(map(str, s)))
+def test_training_forward_backward_running_stats_vs_batchnorm2d(shape):
+    _dev()
+    n, c, h, w = shape
+    ours, ref = _pair(c)
+    g = torch.Generator().manual_seed(n * 7 + c)
+    for step in range(2):
+        x = (1.5 * torch.randn(n, c, h, w, generator=g) + 0.7).cuda().contiguous(memory_format=torch.channels_last)
+        gy = torch.randn(n, c, h, w, generator=g).cuda()
+        xo, xr = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        yo, yr = ours(xo), ref(xr)
+        assert yo.is_contiguous(memory_format=torch.channels_last) and yo.dtype == torch.float32
+        (yo * gy).sum().backward(); (yr * gy).sum().backward()
+        assert _rel(yo, yr) < 2e-5 and _rel(xo.grad, xr.grad) < 1e-4, (step, _rel(yo, yr), _rel(xo.grad, xr.grad))
+        assert _rel(ours.weight.grad, ref.weight.grad) < 2e-5 and _rel(ours.bias.grad, ref.bias.grad) < 2e-5
+        ours.weight.grad = ours.bias.grad = ref.weight.grad = ref.bias.grad = None
+    assert _rel(ours.running_mean, ref.running_mean) < 1e-5 and _rel(ours.running_var, ref.running_var) < 1e-5
+    assert int(ours.num_batches_tracked) == int(ref.num_batches_tracked) == 2
+    ours.eval(); ref.eval()
+    x = torch.randn(n, c, h, w, generator=g).cuda()
+    assert _rel(ours(x), ref(x)) < 2e-5
+    assert sorted(ours.state_dict().keys()) == sorted(ref.state_dict().keys())
+
+
+def test_cumulative_momentum_no_affine_and_fallbacks():
+    _dev()
+    ours, ref = _pair(64, momentum=None, affine=False)
+    g = torch.Generator().manual_seed(5)
+    for _ in range(3):
+        x = torch.randn(4, 64, 8, 8, generator=g).cuda()
+        assert _rel(ours(x), ref(x)) < 2e-5
+    assert _rel(ours.running_mean, ref.running_mean) < 1e-5 and _rel(ours.running_var, ref.running_var) < 1e-5
+    o1, r1 = _pair(32)
+    for m in (o1, r1):                                  # one value per channel in training: torch's error, also here
+        with pytest.raises(ValueError):
+            m(torch.randn(1, 32, 1, 1).cuda())
+    o6, r6 = _pair(6)                                   # C % 4 != 0: torch's own implementation takes it
+    x = torch.randn(2, 6, 4, 4).cuda()
+    assert _rel(o6(x), r6(x)) < 1e-5
+
+
+def test_bitwise_run_to_run():
+    _dev()
+    ours, _ = _pair(256)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(32, 256, 16, 16, generator=g).cuda()
+    gy = torch.randn(32, 256, 16, 16, generator=g).cuda()
+    outs = []
+    for _ in range(3):
+        ours.running_mean.zero_(); ours.running_var.fill_(1.0)
+        xi = x.clone().requires_grad_(True)
+        y = ours(xi)
+        (y * gy).sum().backward()
+        outs.append((y.detach().clone(), xi.grad.clone(), ours.weight.grad.clone(), ours.bias.grad.clone(), ours.running_var.clone()))
+        ours.weight.grad = ours.bias.grad = None
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], o))
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "make-a-scene_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ours, _ = _pair(64)
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(6, 64, 9, 5, generator=g) + 0.3).cuda()
+    gy = torch.randn(6, 64, 9, 5, generator=g).cuda()
+    lo, hi = (0, 2) if rank == 0 else (2, 6)             # uneven split: the exchange carries the counts
+    xi = x[lo:hi].clone().requires_grad_(True)
+    y = ours(xi)
+    (y * gy[lo:hi]).sum().backward()
+    gw, gb = ours.weight.grad.clone(), ours.bias.grad.clone()
+    dist.all_reduce(gw); dist.all_reduce(gb)            # (sum of the local sums = the full-batch parameter gradients)
+    np.savez(out + str(rank), y=y.detach().cpu().numpy(), dx=xi.grad.cpu().numpy(), gw=gw.cpu().numpy(), gb=gb.cpu().numpy(),
+             rm=ours.running_mean.cpu().numpy(), rv=ours.running_var.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_exchange_equals_the_full_batch(tmp_path):
+    """SyncBatchNorm's exchange (one all_reduce of the fp64 {sum, sum of squares, count} forward and of {sum dy, sum dy xhat} backward)
+    over gloo, two ranks with 2 and 4 images on the one GPU, against torch.nn.BatchNorm2d on all 6 images in this process"""
+    _dev()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "bn_rank")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = np.load(out + "0.npz"), np.load(out + "1.npz")
+    sys.path.insert(0, os.path.join(ROOT, "make-a-scene_amd"))
+    _, ref = _pair(64)
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(6, 64, 9, 5, generator=g) + 0.3).cuda().requires_grad_(True)
+    gy = torch.randn(6, 64, 9, 5, generator=g).cuda()
+    y = ref(x)
+    (y * gy).sum().backward()
+    rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+    assert rel(np.concatenate([r0["y"], r1["y"]]), y.detach().cpu().numpy()) < 2e-5
+    assert rel(np.concatenate([r0["dx"], r1["dx"]]), x.grad.cpu().numpy()) < 1e-4
+    assert rel(r0["gw"], ref.weight.grad.cpu().numpy()) < 2e-5 and rel(r0["gb"], ref.bias.grad.cpu().numpy()) < 2e-5
+    for r in (r0, r1):
+        assert rel(r["rm"], ref.running_mean.cpu().numpy()) < 1e-5 and rel(r["rv"], ref.running_var.cpu().numpy()) < 1e-5
