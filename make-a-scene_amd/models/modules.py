@@ -29,7 +29,10 @@ import torch.distributed as dist
 from mas_hip import ACT_AFFINE, ACT_AFFINE_SILU, ACT_NONE
 from mas_hip import ops
 
-_MAS_SYNCBN = os.environ.get("MAS_SYNCBN", "1") == "1"       # 0: nn.SyncBatchNorm's own (MIOpen / ATen) implementation
+# SyncBatchNorm: 1 (default) = batchnorm.hip wherever no cross-rank exchange is needed (one rank, or evaluation) and torch's own module for
+# the exchanging case; 2 = batchnorm.hip also WITH the exchange (one fp64 all_reduce each way; tested over gloo at two ranks, never run on
+# RCCL hardware -- there is no multi-GPU node here -- hence not the default); 0 = torch's implementation everywhere
+_MAS_SYNCBN = int(os.environ.get("MAS_SYNCBN", "1"))
 
 
 def nonlinearity(x):
@@ -49,26 +52,30 @@ def Normalize(in_channels):
 class SyncBatchNorm(nn.SyncBatchNorm):
     """``nn.SyncBatchNorm`` parameters, buffers and ``state_dict`` keys (reference models/vqvae.py:16: the normalisation behind
     ``quant_conv``) on ``libmas_hip.so``'s BatchNorm kernels (``batchnorm.hip``) for a 4-D fp32 CUDA input: per-rank sums in a fixed order,
-    one all_reduce of the fp64 sums across ``process_group`` in training when it has more than one rank, running statistics as torch
-    keeps them.  ``MAS_SYNCBN=0`` (or any other input) falls through to torch's own implementation."""
+    running statistics as torch keeps them.  With more than one rank in ``process_group`` the training forward needs the cross-rank
+    exchange: by default that case stays on torch's own implementation (``MAS_SYNCBN=2``: one all_reduce of the fp64 sums each way
+    around the same kernels -- tested over gloo, not yet on RCCL hardware).  ``MAS_SYNCBN=0`` (or any other input) falls through to
+    torch's implementation everywhere."""
 
     def forward(self, x):
         if not (_MAS_SYNCBN and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.shape[1] <= 1024
                 and (self.training or self.track_running_stats)):
             return super().forward(x)
         training = self.training or not self.track_running_stats
+        group = None
+        if training and torch.distributed.is_available() and torch.distributed.is_initialized():
+            pg = self.process_group if self.process_group is not None else torch.distributed.group.WORLD
+            if torch.distributed.get_world_size(pg) > 1:
+                if _MAS_SYNCBN < 2:
+                    return super().forward(x)               # the exchanging case: torch's own module unless MAS_SYNCBN=2 (see above)
+                group = pg
+        if training and group is None and x.numel() // x.shape[1] == 1:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {x.shape}")      # (torch's own check)
         momentum = 0.0 if self.momentum is None else self.momentum
         if training and self.track_running_stats and self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)
             if self.momentum is None:                       # cumulative moving average (torch's convention; costs a host read)
                 momentum = 1.0 / float(self.num_batches_tracked)
-        group = None
-        if training and torch.distributed.is_available() and torch.distributed.is_initialized():
-            pg = self.process_group if self.process_group is not None else torch.distributed.group.WORLD
-            if torch.distributed.get_world_size(pg) > 1:
-                group = pg
-        if training and group is None and x.numel() // x.shape[1] == 1:
-            raise ValueError(f"Expected more than 1 value per channel when training, got input size {x.shape}")      # (torch's own check)
         rm = self.running_mean if self.track_running_stats else None
         rv = self.running_var if self.track_running_stats else None
         return ops.sync_batch_norm(x, self.weight, self.bias, rm, rv, self.eps, momentum, training, group)

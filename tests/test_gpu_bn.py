@@ -98,9 +98,9 @@ def test_bitwise_run_to_run():
         assert all(torch.equal(a, b) for a, b in zip(outs[0], o))
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, mode):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "make-a-scene_amd"))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MAS_SYNCBN=mode)      # (read when models.modules is imported)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ours, _ = _pair(64)
     g = torch.Generator().manual_seed(11)
@@ -118,15 +118,17 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_exchange_equals_the_full_batch(tmp_path):
-    """SyncBatchNorm's exchange (one all_reduce of the fp64 {sum, sum of squares, count} forward and of {sum dy, sum dy xhat} backward)
-    over gloo, two ranks with 2 and 4 images on the one GPU, against torch.nn.BatchNorm2d on all 6 images in this process"""
+@pytest.mark.parametrize("mode", ["2", "1"])
+def test_two_ranks_exchange_equals_the_full_batch(tmp_path, mode):
+    """SyncBatchNorm's exchange over gloo, two ranks with 2 and 4 images on the one GPU, against torch.nn.BatchNorm2d on all 6 images in
+    this process.  MAS_SYNCBN=2: batchnorm.hip with ONE all_reduce of the fp64 {sum, sum of squares, count} forward and of {sum dy,
+    sum dy xhat} backward; MAS_SYNCBN=1 (the default): the exchanging case is handed to torch's own module."""
     _dev()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "bn_rank")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, mode), nprocs=2, join=True)
     r0, r1 = np.load(out + "0.npz"), np.load(out + "1.npz")
     sys.path.insert(0, os.path.join(ROOT, "make-a-scene_amd"))
     _, ref = _pair(64)
