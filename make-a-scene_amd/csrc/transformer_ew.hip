@@ -395,7 +395,10 @@ extern "C" int mas_layernorm_fwd(const void* x, const float* gamma, const float*
     if (!x || !gamma || !beta || !y) MAS_FAIL(MAS_EINVAL, "layernorm_fwd: null argument");
     if (int rc = ln_check(in_dtype, out_dtype, rows, D, "layernorm_fwd")) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid(ln_blocks(rows)), block(NT);
+    // (64 VGPRs: eight work-groups per CU are resident, and at rows / 2048 = 1.5 rows per wave nearly every row is in flight at once:
+    //  the sandwich forward 22-23 -> 20.4 us at 12288 x 1024, the fp32 -> bf16 forward unchanged at 17.8; tools/probes/ln_probe.py)
+    static const int per_cu = mas_env_int("MAS_LN_FWD_BLOCKS_PER_CU", 8);
+    const dim3 grid(ln_blocks(rows, per_cu)), block(NT);
 #define MAS_LN_FWD(TI, TO) hipLaunchKernelGGL((layernorm_fwd_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, gamma, beta, (const TO*)residual, (TO*)y, mean_rstd, rows, D, eps)
     if (in_dtype == MAS_BF16 && out_dtype == MAS_BF16) MAS_LN_FWD(bf16_t, bf16_t);
     else if (in_dtype == MAS_BF16) MAS_LN_FWD(bf16_t, float);
