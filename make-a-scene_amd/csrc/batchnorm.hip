@@ -15,18 +15,21 @@ constexpr int NT = 256;
 constexpr int BN_ROWS_PER_BLOCK = 128;
 constexpr int BN_MAX_BLOCKS = 1024;
 
-// per-work-group partial sums over a slice of rows: partial[blk][2][C]
+// per-work-group partial sums over a slice of rows: partial[blk][2][C], fp64 from the first addition on (the products x * x are exact
+// in fp64): the variance is formed as E[x^2] - mean^2, which cancels catastrophically in fp32 as soon as |mean| >> std (mean / std = 100
+// already cost 1e-3 of the variance with fp32 partial sums); in fp64 the same ratio costs 1e-12.  8 MB tensor: the extra
+// fp64 issue slots do not show (the launches are latency-bound).
 //   dy == nullptr: (sum x, sum x^2);  else (sum dy, sum dy * xhat) with xhat = (x - mean) * rstd
 // A thread owns a column quad q = tid % quads and walks rows rl, rl + R, ... of the slice (R = NT / quads row lanes); LDS folds the row
 // lanes in a fixed order.  C % 4 == 0, C <= 4 * NT.
 __global__ __launch_bounds__(NT) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                         const float* __restrict__ mean_rstd, int M, int C, int rows_per_block,
-                                                        float* __restrict__ partial) {
-    extern __shared__ float red[];                   // [R][2][C]
+                                                        double* __restrict__ partial) {
+    extern __shared__ double red[];                  // [R][2][C]
     const int quads = C / 4, R = NT / quads > 0 ? NT / quads : 1;
     const int tid = threadIdx.x, q = tid % quads, rl = tid / quads;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    f32x4 s1 = {0.0f, 0.0f, 0.0f, 0.0f}, s2 = {0.0f, 0.0f, 0.0f, 0.0f};
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
     if (rl < R && q < quads) {
         f32x4 mu = {0.0f, 0.0f, 0.0f, 0.0f}, rs = {1.0f, 1.0f, 1.0f, 1.0f};
         if (dy) {
@@ -38,10 +41,10 @@ __global__ __launch_bounds__(NT) void bn_partial_kernel(const float* __restrict_
             if (dy) {
                 const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + (size_t)r * C + 4 * q);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * ((xv[e] - mu[e]) * rs[e]); }
+                for (int e = 0; e < 4; ++e) { s1[e] += (double)dv[e]; s2[e] += (double)dv[e] * (double)((xv[e] - mu[e]) * rs[e]); }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
+                for (int e = 0; e < 4; ++e) { s1[e] += (double)xv[e]; s2[e] += (double)xv[e] * (double)xv[e]; }
             }
         }
 #pragma unroll
@@ -49,26 +52,26 @@ __global__ __launch_bounds__(NT) void bn_partial_kernel(const float* __restrict_
     }
     __syncthreads();
     for (int i = tid; i < 2 * C; i += NT) {
-        float a = 0.0f;
+        double a = 0.0;
         for (int k = 0; k < R; ++k) a += red[k * 2 * C + i];
         partial[(size_t)blockIdx.x * 2 * C + i] = a;
     }
 }
 
 // sums[j] = sum over blocks of partial[blk][j] in fp64, block order; sums[2 C] = the element count of this rank
-__global__ __launch_bounds__(64) void bn_fold_kernel(const float* __restrict__ partial, int nblk, int C, double count, double* __restrict__ sums) {
+__global__ __launch_bounds__(64) void bn_fold_kernel(const double* __restrict__ partial, int nblk, int C, double count, double* __restrict__ sums) {
     const int j = blockIdx.x * 64 + threadIdx.x;
     if (j < 2 * C) {
         double a = 0.0;
         int b = 0;
         for (; b + 8 <= nblk; b += 8) {              // eight loads in flight, additions in block order
-            float v[8];
+            double v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = partial[(size_t)(b + k) * 2 * C + j];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) a += (double)v[k];
+            for (int k = 0; k < 8; ++k) a += v[k];
         }
-        for (; b < nblk; ++b) a += (double)partial[(size_t)b * 2 * C + j];
+        for (; b < nblk; ++b) a += partial[(size_t)b * 2 * C + j];
         sums[j] = a;
     }
     if (j == 0) sums[2 * C] = count;
@@ -156,7 +159,7 @@ int bn_grid(long long n4) {
 
 extern "C" size_t mas_bn_workspace(int M, int C) {
     if (M <= 0 || C <= 0) return 0;
-    return (size_t)bn_blocks(M) * 2 * (size_t)C * sizeof(float);
+    return (size_t)bn_blocks(M) * 2 * (size_t)C * sizeof(double);
 }
 
 extern "C" int mas_bn_partial_sums(const float* x, const float* dy, const float* mean_rstd, int M, int C, double* sums, void* workspace,
@@ -169,8 +172,8 @@ extern "C" int mas_bn_partial_sums(const float* x, const float* dy, const float*
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nblk = bn_blocks(M), rows_per_block = mas_cdiv(M, nblk);
     const int quads = C / 4, R = NT / quads > 0 ? NT / quads : 1;
-    float* partial = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(nblk), dim3(NT), (size_t)R * 2 * C * sizeof(float), s, x, dy, mean_rstd, M, C, rows_per_block, partial);
+    double* partial = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(nblk), dim3(NT), (size_t)R * 2 * C * sizeof(double), s, x, dy, mean_rstd, M, C, rows_per_block, partial);
     MAS_CHECK_LAUNCH("bn_partial");
     hipLaunchKernelGGL(bn_fold_kernel, dim3(mas_cdiv(2 * C, 64)), dim3(64), 0, s, partial, nblk, C, (double)M, sums);
     MAS_CHECK_LAUNCH("bn_fold");

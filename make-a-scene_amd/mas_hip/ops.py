@@ -1006,22 +1006,55 @@ class _SyncBatchNorm(torch.autograd.Function):
         return dx, dg, db, None, None, None, None
 
 
+class _BatchNormEval(torch.autograd.Function):
+    """``nn.SyncBatchNorm`` in evaluation mode: y = x * scale + shift with the pair from the RUNNING statistics (``mas_bn_finalize`` with no
+    sums) + ``mas_bn_apply``.  Differentiable like ``F.batch_norm(training=False)`` (fine-tuning with frozen statistics, input
+    gradients in eval()): dx = dy * gamma * rstd (``mas_bn_apply`` again, with a zero shift), dgamma = sum dy * xhat and dbeta = sum dy
+    (``mas_bn_partial_sums`` against the running mean / rstd, fixed order)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running, eps):
+        running_mean, running_var = running
+        n, c, h, w = x.shape
+        x = nhwc(x, torch.float32)
+        ss = torch.empty((c, 2), dtype=torch.float32, device=x.device)
+        mean_rstd = torch.empty((c, 2), dtype=torch.float32, device=x.device)
+        w32 = weight.detach().float().contiguous() if weight is not None else None
+        b32 = bias.detach().float().contiguous() if bias is not None else None
+        check(lib().mas_bn_finalize(None, _ptr(w32), _ptr(b32), float(eps), 0.0, _ptr(running_mean), _ptr(running_var), _ptr(mean_rstd), _ptr(ss),
+                                    c, _stream()), "bn_finalize")
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        check(lib().mas_bn_apply(_ptr(x), _ptr(ss), _ptr(y), n * h * w, c, _stream()), "bn_apply")
+        ctx.save_for_backward(x, ss, mean_rstd)
+        ctx.has_w, ctx.has_b = weight is not None, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ss, mean_rstd = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dy = nhwc(dy, torch.float32)
+        dx = dg = db = None
+        if ctx.needs_input_grad[0]:
+            ss_dx = ss.clone()
+            ss_dx[:, 1] = 0.0
+            dx = torch.empty_like(x, memory_format=torch.channels_last)
+            check(lib().mas_bn_apply(_ptr(dy), _ptr(ss_dx), _ptr(dx), n * h * w, c, _stream()), "bn_apply")
+        if (ctx.has_w and ctx.needs_input_grad[1]) or (ctx.has_b and ctx.needs_input_grad[2]):
+            sums = _bn_sums(x.permute(0, 2, 3, 1).reshape(-1, c), dy.permute(0, 2, 3, 1).reshape(-1, c), mean_rstd)
+            db = sums[:c].float() if ctx.has_b else None
+            dg = sums[c:2 * c].float() if ctx.has_w else None
+        return dx, dg, db, None, None
+
+
 def sync_batch_norm(x, weight, bias, running_mean, running_var, eps, momentum, training, group=None):
     """``nn.SyncBatchNorm.forward`` on a 4-D fp32 CUDA activation.  ``group``: a process group with more than one rank, or None (no
-    exchange).  Evaluation: the affine pair from the running statistics (``mas_bn_finalize`` with no sums) + ``mas_bn_apply``."""
+    exchange).  Evaluation: the affine pair from the running statistics (``mas_bn_finalize`` with no sums) + ``mas_bn_apply``, as an
+    autograd node (``_BatchNormEval``): eval() with frozen statistics stays differentiable w.r.t. x, weight and bias as torch's does."""
     _require_cuda(x, "sync_batch_norm")
-    n, c, h, w = x.shape
     if training:
         return _SyncBatchNorm.apply(x, weight, bias, (running_mean, running_var), eps, momentum, group)
-    x = nhwc(x, torch.float32)
-    ss = torch.empty((c, 2), dtype=torch.float32, device=x.device)
-    w32 = weight.detach().float().contiguous() if weight is not None else None
-    b32 = bias.detach().float().contiguous() if bias is not None else None
-    check(lib().mas_bn_finalize(None, _ptr(w32), _ptr(b32), float(eps), 0.0, _ptr(running_mean), _ptr(running_var), None, _ptr(ss), c, _stream()),
-          "bn_finalize")
-    y = torch.empty_like(x, memory_format=torch.channels_last)
-    check(lib().mas_bn_apply(_ptr(x), _ptr(ss), _ptr(y), n * h * w, c, _stream()), "bn_apply")
-    return y
+    return _BatchNormEval.apply(x, weight, bias, (running_mean, running_var), eps)
 
 
 # --------------------------------------------------------------------------- #
