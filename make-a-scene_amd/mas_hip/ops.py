@@ -423,8 +423,12 @@ _stat_rows_memo = {}
 _up2_memo = {}
 
 
+def _dev_key():
+    return torch.cuda.current_device()               # eligibility depends on the device's CU count (mas_num_cus)
+
+
 def _up2_wgrad_splits(d: ConvDesc) -> int:
-    key = ("w",) + tuple(getattr(d, f) for f, _ in ConvDesc._fields_[:-1])
+    key = ("w", _dev_key()) + tuple(getattr(d, f) for f, _ in ConvDesc._fields_[:-1])
     k = _up2_memo.get(key)
     if k is None:
         k = _up2_memo[key] = int(lib().mas_conv_up2_wgrad_splits(C.byref(d)))
@@ -432,7 +436,7 @@ def _up2_wgrad_splits(d: ConvDesc) -> int:
 
 
 def _up2_supported(d: ConvDesc, dgrad: bool = False) -> bool:
-    key = (dgrad,) + tuple(getattr(d, f) for f, _ in ConvDesc._fields_[:-1])
+    key = (dgrad, _dev_key()) + tuple(getattr(d, f) for f, _ in ConvDesc._fields_[:-1])
     ok = _up2_memo.get(key)
     if ok is None:
         fn = lib().mas_conv_up2_dgrad_supported if dgrad else lib().mas_conv_up2_supported
@@ -473,8 +477,13 @@ def conv_fwd_raw(x, ss, wp, bias, residual, n, h, w, cin, ho, wo, cout, ks, stri
     d = _desc(ns, h, w, cin, ho, wo, cout, ks, stride, pt, pl, x.dtype, out_dtype, act, upsample)
     if isinstance(wp, ConvWeight):
         d.w_layout = _preferred_layout(d)
-        if upsample and residual is None and act == ACT_NONE and _up2_supported(d):
-            d.w_layout = WLAYOUT_UP2                   # Upsample + conv in its sub-pixel form (conv_up2.hip): 2.25x fewer FLOPs
+        # Upsample + conv in its sub-pixel form (conv_up2.hip): 2.25x fewer FLOPs.  Eligibility depends on N (tile count against the
+        # CU count): EVERY batch slice has to take the kernel, or the whole launch keeps the 3x3 image (a smaller last slice must not
+        # turn into "w_layout UP2 but ... does not take the sub-pixel kernel")
+        if upsample and residual is None and act == ACT_NONE and all(
+                _up2_supported(d if n1 - n0 == ns else _desc(n1 - n0, h, w, cin, ho, wo, cout, ks, stride, pt, pl, x.dtype, out_dtype, act, upsample))
+                for n0, n1 in slices):
+            d.w_layout = WLAYOUT_UP2
         wp = _pack_cache.get(wp.w, wp.transpose, x.dtype, d.w_layout, wp.sources)
     partial, rows = None, 0
     if want_stats and _stats_state["on"] and act == ACT_NONE:
@@ -1245,20 +1254,38 @@ class _ColsumHint:
 
     A LayerNorm whose input is the output of a Linear layer (``LayerNorm.forward(..., producer_bias_grad=True)``: the sandwich
     LayerNorms behind ``out_proj`` / ``lin2``) accumulates the column sums of its dx inside its backward kernel
-    (``mas_layernorm_bwd_colsum``); ``_LinearBf16.backward`` asks here before it launches ``mas_colsum`` on that same tensor.  One slot:
-    the entry holds a STRONG reference to dx, so the allocator cannot hand the same address to another tensor while the entry exists,
-    and a hit requires the same storage address, element count, column count and version counter (no in-place write since) -- anything
-    else (a Dropout in between, an accumulation, a hook that replaced the gradient) misses and the Linear computes its own sums."""
+    (``mas_layernorm_bwd_colsum``); ``_LinearBf16.backward`` asks here before it launches ``mas_colsum`` on that same tensor.  One slot
+    per (device, stream) -- the sums are produced on the LayerNorm's stream and may only be consumed on the same one: the entry holds a
+    STRONG reference to dx, so the allocator cannot hand the same address to another tensor while the entry exists, and a hit requires
+    the same storage address, element count, column count and version counter (no in-place write since) -- anything else (a Dropout in
+    between, an accumulation, a hook that replaced the gradient) misses and the Linear computes its own sums.  Entries never outlive the
+    backward pass that made them: ``put`` queues an end-of-backward callback on the autograd engine that empties the table (a pruned
+    graph, ``autograd.grad`` on an intermediate or an exception would otherwise keep the last dx -- 25 MB at 12288 x 1024 -- alive)."""
 
     def __init__(self):
-        self.slot = None
+        self.slots = {}
         self.hits = 0                                # (tests / probes read this)
+        self._cb_pending = False
+
+    @staticmethod
+    def _key(t):
+        return (t.device.index, torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else (None, 0)
+
+    def _end_of_backward(self):
+        self.slots.clear()
+        self._cb_pending = False
 
     def put(self, dx, sums):
-        self.slot = (dx, dx.data_ptr(), dx.numel(), dx.shape[-1], dx._version, sums)
+        self.slots[self._key(dx)] = (dx, dx.data_ptr(), dx.numel(), dx.shape[-1], dx._version, sums)
+        if not self._cb_pending:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+                self._cb_pending = True
+            except RuntimeError:                     # not inside a backward pass (direct call of the raw function): the slot is taken or
+                pass                                 # overwritten by the next put
 
     def take(self, dy2):
-        ent, self.slot = self.slot, None
+        ent = self.slots.pop(self._key(dy2), None)
         if ent is None:
             return None
         dx, ptr, numel, cols, version, sums = ent
@@ -1269,7 +1296,7 @@ class _ColsumHint:
         return None
 
     def clear(self):
-        self.slot = None
+        self.slots.clear()
 
 
 _colsum_hint = _ColsumHint()

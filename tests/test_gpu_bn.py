@@ -80,6 +80,50 @@ def test_cumulative_momentum_no_affine_and_fallbacks():
     assert _rel(o6(x), r6(x)) < 1e-5
 
 
+def test_eval_mode_is_differentiable_like_batchnorm2d():
+    """eval() with frozen statistics must keep x, weight and bias on the autograd graph, as F.batch_norm does."""
+    _dev()
+    ours, ref = _pair(256)
+    g = torch.Generator().manual_seed(3)
+    for m in (ours, ref):                                # non-trivial running statistics
+        with torch.no_grad():
+            m.running_mean.copy_(0.3 * torch.randn(256, generator=g)); m.running_var.copy_(0.5 + torch.rand(256, generator=g))
+    ours.eval(); ref.eval()
+    x = (1.3 * torch.randn(4, 256, 16, 16, generator=g) + 0.2).cuda()
+    gy = torch.randn(4, 256, 16, 16, generator=g).cuda()
+    xo, xr = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    yo, yr = ours(xo), ref(xr)
+    assert yo.grad_fn is not None
+    (yo * gy).sum().backward(); (yr * gy).sum().backward()
+    assert _rel(yo, yr) < 2e-5 and _rel(xo.grad, xr.grad) < 2e-5
+    assert _rel(ours.weight.grad, ref.weight.grad) < 2e-5 and _rel(ours.bias.grad, ref.bias.grad) < 2e-5
+    # frozen parameters, input gradient only; and no grad at all
+    for prm in (ours.weight, ours.bias):
+        prm.requires_grad_(False); prm.grad = None
+    xo2 = x.clone().requires_grad_(True)
+    (ours(xo2) * gy).sum().backward()
+    assert torch.equal(xo2.grad, xo.grad) and ours.weight.grad is None
+    with torch.no_grad():
+        assert ours(x).grad_fn is None
+
+
+def test_large_channel_mean_keeps_the_variance():
+    """|mean| >> std must not cancel in E[x^2] - mean^2 (fp64 sums from the first addition on)."""
+    _dev()
+    ours, ref = _pair(64)
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(8, 64, 16, 16, generator=g) + 300.0).cuda()
+    y = ours(x)
+    xd = x.double()
+    var = xd.var(dim=(0, 2, 3), unbiased=False)
+    mean = xd.mean(dim=(0, 2, 3))
+    want = (xd - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + ours.eps) * ours.weight.double()[None, :, None, None] \
+        + ours.bias.double()[None, :, None, None]
+    assert _rel(y, want) < 2e-4, _rel(y, want)           # (the fp32 input itself carries 300 * 6e-8 = 2e-5 of a standard deviation)
+    rv_want = 0.9 + 0.1 * xd.var(dim=(0, 2, 3), unbiased=True)
+    assert _rel(ours.running_var, rv_want) < 1e-5, _rel(ours.running_var, rv_want)
+
+
 def test_bitwise_run_to_run():
     _dev()
     ours, _ = _pair(256)

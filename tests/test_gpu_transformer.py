@@ -345,7 +345,8 @@ def test_layer_norm_bwd_colsum_of_dx(rows, d, tin, tout):
     dx0, dg0, db0 = ops._layer_norm_bwd(x, w, mr, go, tout, None, False)
     ops._colsum_hint.clear()
     dx1, dg1, db1 = ops._layer_norm_bwd(x, w, mr, go, tout, None, True)
-    dc = ops._colsum_hint.slot[5]
+    (ent,) = ops._colsum_hint.slots.values()          # one entry, keyed by (device, stream)
+    dc = ent[5]
     assert torch.equal(dx0, dx1)
     rel = lambda a, c: float((a.double() - c.double()).norm() / c.double().norm())
     assert rel(dg1, dg0) < 1e-6 and rel(db1, db0) < 1e-6                    # (4 vs 3 work-groups per CU: another summation order)
@@ -354,7 +355,7 @@ def test_layer_norm_bwd_colsum_of_dx(rows, d, tin, tout):
     assert dc.dtype == torch.float32 and dc.shape == (d,)
     assert float(((dc.double() - ref).abs() / scale).max()) < 1e-6
     ops._layer_norm_bwd(x, w, mr, go, tout, None, True)
-    assert torch.equal(dc, ops._colsum_hint.slot[5])
+    assert torch.equal(dc, next(iter(ops._colsum_hint.slots.values()))[5])
     ops._colsum_hint.clear()
 
 
@@ -387,20 +388,20 @@ def test_linear_bias_gradient_from_the_layer_norm_backward():
     gx0, g0 = run(False)
     assert ops._colsum_hint.hits == h0
     gx1, g1 = run(True)
-    assert ops._colsum_hint.hits == h0 + 1 and ops._colsum_hint.slot is None
+    assert ops._colsum_hint.hits == h0 + 1 and not ops._colsum_hint.slots
     assert torch.equal(gx0, gx1) and torch.equal(g0[0], g1[0])              # dx, dW: the same tensors went through the same GEMMs
     rel = lambda a, c: float((a.double() - c.double()).norm() / c.double().norm())
     assert rel(g1[1], g0[1]) < 1e-6                                          # the bias gradient: another (fixed) summation order
     assert rel(g1[2], g0[2]) < 1e-6 and rel(g1[3], g0[3]) < 1e-6
     torch.manual_seed(1)
     gx2, g2 = run(True, torch.nn.Dropout(0.1))                               # the Linear receives dropout's gradient, not the LayerNorm's
-    assert ops._colsum_hint.hits == h0 + 1 and ops._colsum_hint.slot is None
+    assert ops._colsum_hint.hits == h0 + 1 and not ops._colsum_hint.slots
     assert torch.isfinite(g2[1]).all()
     # the hand-off itself: sums are given out for the very tensor they were computed from, once, and for nothing else
     a, b = torch.randn(8, 16, device="cuda").bfloat16(), torch.randn(8, 16, device="cuda").bfloat16()
     sums = torch.zeros(16, device="cuda")
     ops._colsum_hint.put(a, sums)
-    assert ops._colsum_hint.take(b) is None and ops._colsum_hint.slot is None          # another tensor: miss, slot dropped
+    assert ops._colsum_hint.take(b) is None and not ops._colsum_hint.slots       # another tensor: miss, slot dropped
     ops._colsum_hint.put(a, sums)
     a.add_(1)                                                                          # written since: the version counter moved
     assert ops._colsum_hint.take(a) is None
