@@ -1096,6 +1096,17 @@ class _SpatialAttention(torch.autograd.Function):
         return dx, None
 
 
+_spatial_attn_force = {"on": False}
+
+
+def force_bf16_spatial_attention(on: bool) -> bool:
+    """Tests: route fp32-mode AttnBlock cores through the bf16 kernels of ``spatial_attn.hip`` (inputs rounded to bf16, output cast
+    back).  Returns the previous setting."""
+    old = _spatial_attn_force["on"]
+    _spatial_attn_force["on"] = bool(on)
+    return old
+
+
 def spatial_attention(qkv: torch.Tensor, c: int) -> torch.Tensor:
     """qkv: [N,3C,H,W] channels_last (q|k|v stacked on channels).  softmax over keys of q.k^T * C^-1/2, then . v
     (reference models/modules.py:174-187).  bf16 (the compute dtype of the benched path): the hand-written HIP kernels, for the
@@ -1104,6 +1115,10 @@ def spatial_attention(qkv: torch.Tensor, c: int) -> torch.Tensor:
     n, c3, h, w = qkv.shape
     if qkv.is_cuda and qkv.dtype == torch.bfloat16 and h * w <= 256 and c <= 512 and c % 32 == 0:
         return _SpatialAttention.apply(qkv, c)
+    if _spatial_attn_force["on"] and qkv.is_cuda and qkv.dtype == torch.float32 and h * w <= 256 and c <= 512 and c % 32 == 0:
+        # parity knob (tests only): the fp32 MODE with its attention cores on the bf16 HIP kernel, so that the kernel is held against
+        # the reference's fp32 golden inside an otherwise exact-fp32 model (VERDICT r5 next #3d)
+        return _SpatialAttention.apply(qkv.to(torch.bfloat16), c).float()
     t = qkv.permute(0, 2, 3, 1).reshape(n, h * w, c3)          # a view of the NHWC buffer
     q, k, v = t[..., :c], t[..., c:2 * c], t[..., 2 * c:]
     s = torch.bmm(q, k.transpose(1, 2)) * (int(c) ** (-0.5))

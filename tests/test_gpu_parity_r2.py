@@ -98,7 +98,7 @@ def test_img256_bf16_vs_reference_golden(golden_dir):
     # (the REFERENCE run in bf16 agrees with its own fp32 run on 0.904 of the indices); decoder fed the
     # reference z_q max-rel 3.1e-2, rel-L2 2.6e-2.  52 bf16-storage layers deep, these are ~1.5x the 4-level tiny net's.
     assert e_h < 3e-2 and e_z < 5e-2 and l2_z < 4e-2
-    assert agree > 0.90
+    assert agree >= 0.93                                # tightened in round 6 to the measured floor (0.945 = 242 / 256) minus margin
     assert e_dec < 5e-2 and l2_dec < 4e-2
     assert abs(float(loss) - float(g["loss"])) < 3e-2 * abs(float(g["loss"]))
     assert e_gd < 1e-1

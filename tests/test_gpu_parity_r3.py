@@ -141,15 +141,15 @@ def test_dominant_conv_wide_real_shape_vs_cpu_fp32(monkeypatch):
 # --------------------------------------------------------------------------------------------------------------
 # 2. the model at a batch where the benched kernels walk several tiles, vs the oracle on the same batch
 # --------------------------------------------------------------------------------------------------------------
-def test_img256_bf16_multi_tile_batch_vs_oracle():
+@pytest.mark.parametrize("nb", [16, 32])
+def test_img256_bf16_multi_tile_batch_vs_oracle(nb):
     """reference models/vqvae.py:36-39 through oracle/vq_oracle.py (pinned to the reference by tests/test_oracle_golden.py) on a
-    16-image batch; ours in the production precision.  Same split as the B=1 golden test: latents, index agreement, decoder fed
+    16-image batch and (round 6, VERDICT r5 next #3b) on the 32-image batch bench.py runs; ours in the production precision.  Same split as the B=1 golden test: latents, index agreement, decoder fed
     the oracle's z_q.  The launch hook proves the 256x256 / 128x128 layers ran with more tiles than work-groups."""
     from mas_hip import ops
     from oracle import vq_oracle as O
     dev = _dev()
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
-    nb = 16
     x = O.synth_image_batch(nb, 3, 256, seed=6)
     sd = O.synth_state_dict(IMG["ddconfig"], IMG["n_embed"], IMG["embed_dim"], seed=1)
     taps = {}
@@ -178,10 +178,10 @@ def test_img256_bf16_multi_tile_batch_vs_oracle():
     e_z, l2_z = relerr(got["z"], ref_z), rel_l2(got["z"], ref_z)
     agree = float((got["q"][2].cpu() == ref_idx).float().mean())
     e_dec, l2_dec = relerr(rec_ref_zq, ref), rel_l2(rec_ref_zq, ref)
-    print("img256 bf16 B=16 vs oracle: z max-rel %.3e rel-L2 %.3e | index agreement %.4f | decoder(oracle z_q) max-rel %.3e rel-L2 %.3e"
+    print(f"img256 bf16 B={nb} vs oracle: " "z max-rel %.3e rel-L2 %.3e | index agreement %.4f | decoder(oracle z_q) max-rel %.3e rel-L2 %.3e"
           " | q_loss %.5f vs %.5f" % (e_z, l2_z, agree, e_dec, l2_dec, float(q), float(ref_q)))
     assert e_z < 5e-2 and l2_z < 4e-2                  # the B=1 golden test's tolerances (52 bf16-storage layers)
-    assert agree > 0.90
+    assert agree >= 0.93                               # measured 0.952 at B=16 (round 3); tightened from 0.90 in round 6
     assert e_dec < 5e-2 and l2_dec < 4e-2
     assert torch.isfinite(rec).all()
 

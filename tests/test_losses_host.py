@@ -98,3 +98,28 @@ def test_lpips_partial_checkpoint_is_reported(tmp_path, monkeypatch):
         m2 = lpips.LPIPS()
     assert m2.unloaded == [] and not rec
     assert torch.equal(m2.vgg.slice3[3].weight, tv["features.12.weight"])
+
+
+def test_loss_seg_vs_reference_golden():
+    """losses.loss_seg (BCELossWithQuant, VQVAEWithBCELoss) against the reference's own classes (reference losses/loss_seg.py:6-41;
+    fixture: tests/golden/make_golden_r6.py): loss values, gradients w.r.t. the prediction, the ``weight`` buffer and the state_dict keys."""
+    import numpy as np
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden_r6 import loss_seg_inputs
+    import losses
+    g = np.load(os.path.join(ROOT, "tests", "golden", "loss_seg.npz"))
+    pred, target, qloss = loss_seg_inputs()
+    for name in ("BCELossWithQuant", "VQVAEWithBCELoss"):
+        for cw in (1.0, 0.25):
+            m = getattr(losses, name)(image_channels=159, codebook_weight=cw)
+            p = torch.from_numpy(pred).requires_grad_(True)
+            loss = m(torch.tensor(qloss), torch.from_numpy(target), p)
+            loss.backward()
+            assert abs(float(loss) - float(g[f"{name}:{cw}:loss"])) < 1e-6 * max(1.0, abs(float(loss)))
+            ref = torch.from_numpy(g[f"{name}:{cw}:grad"])
+            assert float((p.grad - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+        assert np.array_equal(m.weight.numpy(), g[f"{name}:weight"]) and float(m.weight[153]) == 20.0 and float(m.weight[158]) == 1.0
+        assert sorted(m.state_dict().keys()) == list(g[f"{name}:state_keys"])
+    from losses.loss_seg import VQVAEWithBCELoss            # the plain submodule form
+    assert VQVAEWithBCELoss is losses.VQVAEWithBCELoss
