@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAS_ABI_VERSION 8
+#define MAS_ABI_VERSION 9
 
 enum { MAS_OK = 0, MAS_EINVAL = -1, MAS_EUNSUPPORTED = -2, MAS_ELAUNCH = -3, MAS_EWORKSPACE = -4 };
 enum { MAS_F32 = 0, MAS_BF16 = 1 };
@@ -353,6 +353,18 @@ int mas_bn_finalize(const double* sums, const float* gamma, const float* beta, f
 int mas_bn_apply(const float* x, const float* scale_shift, float* y, int M, int C, void* stream);
 int mas_bn_bwd_apply(const float* x, const float* dy, const float* mean_rstd, const float* gamma, const double* sums, float* dx, int M,
                      int C, void* stream);
+/* ABI v9: the same three passes on bf16 or fp32 storage (dtype = MAS_BF16 / MAS_F32 for x, dy, y, dx alike) with the LeakyReLU(slope) that
+ * follows the normalisation fused in -- the nn.BatchNorm2d + nn.LeakyReLU(0.2) pairs of the PatchGAN discriminator, reference
+ * losses/discriminator.py:26-33 (per-rank batch statistics there: no exchange).  slope == 1: no activation (the v8 entry points above
+ * are these with MAS_F32 and slope 1).
+ *   mas_bn_apply_act        : y = lrelu(x * scale + shift).
+ *   mas_bn_partial_sums_act : backward sums of g = dy * lrelu'(u), u = x * scale + shift recomputed (scale_shift required when slope != 1).
+ *   mas_bn_bwd_apply_act    : dx = gamma * rstd * (g - S1 / n - xhat * S2 / n) with the same g.                                      */
+int mas_bn_partial_sums_act(const void* x, const void* dy, const float* mean_rstd, const float* scale_shift, float slope, int dtype, int M, int C,
+                            double* sums, void* workspace, size_t workspace_bytes, void* stream);
+int mas_bn_apply_act(const void* x, const float* scale_shift, void* y, float slope, int dtype, int M, int C, void* stream);
+int mas_bn_bwd_apply_act(const void* x, const void* dy, const float* mean_rstd, const float* gamma, const float* scale_shift, float slope,
+                         const double* sums, void* dx, int dtype, int M, int C, void* stream);
 
 #ifdef __cplusplus
 }

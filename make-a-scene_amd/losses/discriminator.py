@@ -4,11 +4,15 @@ Same constructor, same ``nn.Sequential`` layout and therefore the same ``state_d
 ``model.11.bias``), same ``weights_init``.  The five 4x4 convolutions (stride 2, 2, 2, 1, 1; pad 1) run on libmas_hip's
 implicit-GEMM kernels in bf16 with fp32 accumulation: forward and data gradient on ``conv_fwd_kernel<4x4>`` (the stride-2 data
 gradient as a zero-stuffed stride-1 convolution), the weight gradient on the transpose-read kernel (stride 2 through a
-space-to-depth image, ``mas_space_to_depth2x``).  ``BatchNorm2d`` and ``LeakyReLU`` are the reference's own torch modules (one
-elementwise pass each on maps of at most 128x128x64: < 0.3 % of a VQ-IMG step; SURVEY K9 treats SyncBatchNorm the same way)."""
+space-to-depth image, ``mas_space_to_depth2x``).  Each ``BatchNorm2d`` + ``LeakyReLU(0.2)`` pair is one pass of ``batchnorm.hip`` on the
+bf16 map (round 6: ``ops.batch_norm_leaky_relu`` -- fp64 fixed-order batch statistics, running statistics as torch keeps them, the
+activation fused into the apply pass and its derivative into the backward sums; until round 5 torch's module on an fp32 round trip);
+the modules stay in the ``nn.Sequential`` (parameters, buffers, ``state_dict`` keys).  Channel counts the kernels do not take
+(C % 4 != 0, C > 1024) and CPU tensors keep the torch modules.  The first layer's bare ``LeakyReLU`` is torch's."""
 import torch
 import torch.nn as nn
 
+from mas_hip import ops
 from models.modules import Conv2d
 
 
@@ -47,9 +51,19 @@ class Discriminator(nn.Module):
 
     def forward(self, x):
         h = x
-        for m in self.model:
+        mods = list(self.model)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
             if isinstance(m, nn.BatchNorm2d):
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                fused = isinstance(nxt, nn.LeakyReLU)
+                if h.is_cuda and h.dim() == 4 and h.shape[1] % 4 == 0 and h.shape[1] <= 1024 and h.dtype in (torch.bfloat16, torch.float32):
+                    h = ops.batch_norm_leaky_relu(h, m, nxt.negative_slope if fused else 1.0)
+                    i += 2 if fused else 1
+                    continue
                 h = m(h.float()).to(torch.bfloat16)   # statistics and affine in fp32 on the bf16 map (channels_last preserved)
             else:
                 h = m(h)
+            i += 1
         return h

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MAS_HIP_LIB") or os.path.join(_HERE, "libmas_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_AFFINE, ACT_AFFINE_SILU = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 WLAYOUT_K64, WLAYOUT_K32, WLAYOUT_UP2 = 0, 1, 2
 
 
@@ -110,6 +110,9 @@ _SIGNATURES = {
     "mas_bn_finalize": (_i, [_p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p]),
     "mas_bn_apply": (_i, [_p, _p, _p, _i, _i, _p]),
     "mas_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "mas_bn_partial_sums_act": (_i, [_p, _p, _p, _p, _f, _i, _i, _i, _p, _p, _sz, _p]),
+    "mas_bn_apply_act": (_i, [_p, _p, _p, _f, _i, _i, _i, _p]),
+    "mas_bn_bwd_apply_act": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _p]),
     "mas_layernorm_bwd_colsum": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "mas_colsum_workspace": (_sz, [_i, _i]),
     "mas_colsum": (_i, [_p, _i, _i, _i, _p, _p, _sz, _p]),

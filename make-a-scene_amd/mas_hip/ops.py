@@ -1096,6 +1096,82 @@ class _SpatialAttention(torch.autograd.Function):
         return dx, None
 
 
+class _BatchNormLeaky(torch.autograd.Function):
+    """``nn.BatchNorm2d`` (per-rank batch statistics in training, running statistics in evaluation) + the ``nn.LeakyReLU(slope)`` that
+    follows it, on a bf16 or fp32 NHWC map in its own storage type: the normalisation pairs of the PatchGAN discriminator (reference
+    losses/discriminator.py:26-33).  Forward: fixed-order fp64 sums (``mas_bn_partial_sums_act``), ``mas_bn_finalize`` (mean / rstd, the
+    affine pair, running statistics), ``mas_bn_apply_act`` (one read, one write, the activation fused).  Backward: the sums of
+    g = dy * lrelu'(u) -- u recomputed from x, nothing but x is saved -- are this layer's dbeta / dgamma; ``mas_bn_bwd_apply_act`` writes dx.
+    Evaluation: dx = g * gamma * rstd (the same kernel with zero sums)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running, eps, momentum, slope, training):
+        running_mean, running_var = running
+        n, c, h, w = x.shape
+        x = nhwc(x)
+        dt = _DT[x.dtype]
+        m = n * h * w
+        x2 = x.permute(0, 2, 3, 1).reshape(-1, c)
+        sums = None
+        if training:
+            sums = torch.empty(2 * c + 1, dtype=torch.float64, device=x.device)
+            wsb = lib().mas_bn_workspace(m, c)
+            ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=x.device)
+            check(lib().mas_bn_partial_sums_act(_ptr(x2), None, None, None, 1.0, dt, m, c, _ptr(sums), _ptr(ws), wsb, _stream()), "bn_partial_sums")
+        mean_rstd = torch.empty((c, 2), dtype=torch.float32, device=x.device)
+        ss = torch.empty((c, 2), dtype=torch.float32, device=x.device)
+        w32 = weight.detach().float().contiguous() if weight is not None else None
+        b32 = bias.detach().float().contiguous() if bias is not None else None
+        check(lib().mas_bn_finalize(_ptr(sums), _ptr(w32), _ptr(b32), float(eps), float(momentum), _ptr(running_mean), _ptr(running_var),
+                                    _ptr(mean_rstd), _ptr(ss), c, _stream()), "bn_finalize")
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        check(lib().mas_bn_apply_act(_ptr(x), _ptr(ss), _ptr(y), float(slope), dt, m, c, _stream()), "bn_apply")
+        ctx.save_for_backward(x, w32 if w32 is not None else torch.empty(0, device=x.device), mean_rstd, ss)
+        ctx.has_w, ctx.has_b, ctx.slope, ctx.training = weight is not None, bias is not None, float(slope), bool(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w32, mean_rstd, ss = ctx.saved_tensors
+        n, c, h, w = x.shape
+        m = n * h * w
+        dt = _DT[x.dtype]
+        dy = nhwc(dy, x.dtype)
+        sums = torch.empty(2 * c + 1, dtype=torch.float64, device=x.device)
+        wsb = lib().mas_bn_workspace(m, c)
+        ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=x.device)
+        check(lib().mas_bn_partial_sums_act(_ptr(x), _ptr(dy), _ptr(mean_rstd), _ptr(ss), ctx.slope, dt, m, c, _ptr(sums), _ptr(ws), wsb, _stream()),
+              "bn_partial_sums")
+        db = sums[:c].float() if ctx.has_b else None
+        dg = sums[c:2 * c].float() if ctx.has_w else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if not ctx.training:                                # frozen statistics: no mean terms
+                sums = torch.zeros_like(sums)
+                sums[2 * c] = 1.0
+            dx = torch.empty_like(x, memory_format=torch.channels_last)
+            check(lib().mas_bn_bwd_apply_act(_ptr(x), _ptr(dy), _ptr(mean_rstd), _ptr(w32) if ctx.has_w else None, _ptr(ss), ctx.slope, _ptr(sums),
+                                             _ptr(dx), dt, m, c, _stream()), "bn_bwd_apply")
+        return dx, dg, db, None, None, None, None, None
+
+
+def batch_norm_leaky_relu(x, bn: torch.nn.BatchNorm2d, slope: float):
+    """``LeakyReLU(slope)(bn(x))`` for a 4-D bf16 / fp32 CUDA map on ``batchnorm.hip`` (``slope`` 1.0: the normalisation alone), with
+    ``nn.BatchNorm2d``'s bookkeeping: ``num_batches_tracked``, cumulative momentum, running statistics, evaluation mode."""
+    _require_cuda(x, "batch_norm_leaky_relu")
+    training = bn.training or not bn.track_running_stats
+    if training and x.numel() // x.shape[1] == 1:
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size {x.shape}")
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BatchNormLeaky.apply(x, bn.weight, bn.bias, (rm, rv), bn.eps, momentum, slope, training)
+
+
 _spatial_attn_force = {"on": False}
 
 

@@ -47,7 +47,7 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     """the ABI v2 additions follow the same convention: negative code + message, nothing computed"""
     import mas_hip
     L = mas_hip.lib()
-    assert L.mas_abi_version() == mas_hip.ABI_VERSION == 8
+    assert L.mas_abi_version() == mas_hip.ABI_VERSION == 9
     assert L.mas_conv_weight_layout(None) == mas_hip.WLAYOUT_K64
     d = mas_hip.ConvDesc(32, 256, 256, 128, 256, 256, 128, 3, 1, 1, 1, mas_hip.BF16, mas_hip.BF16, 0, 0, 0)
     assert L.mas_conv_weight_layout(ctypes.byref(d)) in (mas_hip.WLAYOUT_K64, mas_hip.WLAYOUT_K32)

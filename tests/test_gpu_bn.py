@@ -124,6 +124,41 @@ def test_large_channel_mean_keeps_the_variance():
     assert _rel(ours.running_var, rv_want) < 1e-5, _rel(ours.running_var, rv_want)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("slope", [0.2, 1.0])
+def test_batch_norm_leaky_relu_vs_torch(dtype, slope):
+    """ops.batch_norm_leaky_relu (the BatchNorm2d + LeakyReLU(0.2) pairs of the PatchGAN discriminator, reference
+    losses/discriminator.py:26-33) on bf16 / fp32 storage against torch's modules in fp32: training (outputs, all gradients, running
+    statistics over two steps) and evaluation (differentiable)."""
+    from mas_hip import ops
+    _dev()
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    for shape in ((4, 128, 15, 15), (2, 512, 7, 7), (3, 12, 5, 6)):
+        n, c, h, w = shape
+        torch.manual_seed(c)
+        ours, ref = torch.nn.BatchNorm2d(c).cuda(), torch.nn.BatchNorm2d(c).cuda()
+        with torch.no_grad():
+            ours.weight.copy_(1.0 + 0.2 * torch.randn(c)); ours.bias.copy_(0.1 * torch.randn(c))
+        ref.load_state_dict(ours.state_dict())
+        act = torch.nn.LeakyReLU(slope) if slope != 1.0 else torch.nn.Identity()
+        g = torch.Generator().manual_seed(n + c)
+        for step in range(3):
+            if step == 2:
+                ours.eval(); ref.eval()
+            x = (1.5 * torch.randn(n, c, h, w, generator=g) + 0.4).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+            gy = torch.randn(n, c, h, w, generator=g).to(dtype).cuda()
+            xo, xr = x.clone().requires_grad_(True), x.float().clone().requires_grad_(True)
+            yo = ops.batch_norm_leaky_relu(xo, ours, slope)
+            yr = act(ref(xr))
+            assert yo.dtype == dtype and yo.is_contiguous(memory_format=torch.channels_last)
+            (yo.float() * gy.float()).sum().backward(); (yr * gy.float()).sum().backward()
+            assert _rel(yo, yr) < tol and _rel(xo.grad, xr.grad) < 5 * tol, (shape, step, _rel(yo, yr), _rel(xo.grad, xr.grad))
+            assert _rel(ours.weight.grad, ref.weight.grad) < tol and _rel(ours.bias.grad, ref.bias.grad) < tol
+            ours.weight.grad = ours.bias.grad = ref.weight.grad = ref.bias.grad = None
+        assert _rel(ours.running_mean, ref.running_mean) < 1e-5 and _rel(ours.running_var, ref.running_var) < 1e-5
+        assert int(ours.num_batches_tracked) == int(ref.num_batches_tracked) == 2
+
+
 def test_bitwise_run_to_run():
     _dev()
     ours, _ = _pair(256)
