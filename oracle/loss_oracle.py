@@ -83,10 +83,12 @@ def disc_forward(sd: SD, x: Tensor, training: bool = True, in_channels=3, nf=64,
             if i != last:
                 h = r(h)
         elif kind == "bn":       # nn.BatchNorm2d, eps 1e-5; training: batch statistics (running buffers are not touched here)
-            h = r(F.batch_norm(h, None if training else sd[f"model.{i}.running_mean"], None if training else sd[f"model.{i}.running_var"],
-                               sd[f"model.{i}.weight"], sd[f"model.{i}.bias"], training, 0.1, 1e-5))
+            # (bf16_storage: no rounding here -- since round 6 the MI355X path normalises and activates in ONE pass, fp32 inside, and
+            #  rounds the activated map once: the rounding sits behind the LeakyReLU below)
+            h = F.batch_norm(h, None if training else sd[f"model.{i}.running_mean"], None if training else sd[f"model.{i}.running_var"],
+                             sd[f"model.{i}.weight"], sd[f"model.{i}.bias"], training, 0.1, 1e-5)
         else:
-            h = F.leaky_relu(h, 0.2)
+            h = r(F.leaky_relu(h, 0.2))
     return h
 
 

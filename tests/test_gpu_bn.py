@@ -52,7 +52,10 @@ def test_training_forward_backward_running_stats_vs_batchnorm2d(shape):
         yo, yr = ours(xo), ref(xr)
         assert yo.is_contiguous(memory_format=torch.channels_last) and yo.dtype == torch.float32
         (yo * gy).sum().backward(); (yr * gy).sum().backward()
-        assert _rel(yo, yr) < 2e-5 and _rel(xo.grad, xr.grad) < 1e-4, (step, _rel(yo, yr), _rel(xo.grad, xr.grad))
+        # dx against the scale of what it is made of (dy * gamma * rstd): with two values per channel (the 1x32x1x2 case) dx is pure
+        # cancellation, ~1e-5 of that scale, and torch's fp32 sums and the fp64 sums here round it differently
+        e_dx = float((xo.grad - xr.grad).abs().max() / max(float(xr.grad.abs().max()), 1e-3 * float(gy.abs().max())))
+        assert _rel(yo, yr) < 2e-5 and e_dx < 1e-4, (step, _rel(yo, yr), e_dx)
         assert _rel(ours.weight.grad, ref.weight.grad) < 2e-5 and _rel(ours.bias.grad, ref.bias.grad) < 2e-5
         ours.weight.grad = ours.bias.grad = ref.weight.grad = ref.bias.grad = None
     assert _rel(ours.running_mean, ref.running_mean) < 1e-5 and _rel(ours.running_var, ref.running_var) < 1e-5
@@ -85,9 +88,10 @@ def test_eval_mode_is_differentiable_like_batchnorm2d():
     _dev()
     ours, ref = _pair(256)
     g = torch.Generator().manual_seed(3)
-    for m in (ours, ref):                                # non-trivial running statistics
+    rm, rv = 0.3 * torch.randn(256, generator=g), 0.5 + torch.rand(256, generator=g)      # non-trivial running statistics
+    for m in (ours, ref):
         with torch.no_grad():
-            m.running_mean.copy_(0.3 * torch.randn(256, generator=g)); m.running_var.copy_(0.5 + torch.rand(256, generator=g))
+            m.running_mean.copy_(rm); m.running_var.copy_(rv)
     ours.eval(); ref.eval()
     x = (1.3 * torch.randn(4, 256, 16, 16, generator=g) + 0.2).cuda()
     gy = torch.randn(4, 256, 16, 16, generator=g).cuda()
