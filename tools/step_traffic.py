@@ -80,10 +80,12 @@ def main():
     launches = collections.Counter()
     meta = {}
     counters_seen = set()
+    windows = []
     for f in sorted(os.listdir(d)):
         if not (f.startswith("pass_") and f.endswith(".csv")):
             continue
         disp = window(load(os.path.join(d, f)), K, W)
+        windows.append(disp)
         first = not launches
         for _, name, c in disp:
             fam, fac, cal = family(name)
@@ -118,13 +120,49 @@ def main():
           f"(bounds {tot['lo'] / alg:.2f} .. {tot['hi'] / alg:.2f})")
     gn = sum(r["read_bytes"] + r["write_bytes"] for r in rows if r["family"].startswith("GroupNorm"))
     print(f"GroupNorm passes: {gn / 1e9:.2f} GB per step = {gn / total:.2f} of the step's traffic (algorithmic bytes by SURVEY's rule: 0)")
-    for extra in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"):
+    for extra in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_WRREQ_sum",
+                  "TCC_EA0_WRREQ_64B_sum"):
         if extra in counters_seen:
             print(f"{extra}: {sum(per[f][extra] for f in per) / K:.4g} per step")
+    exact = None
+    if {"TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"} <= counters_seen:
+        # request-size counters: the cross-check of the per-family factors (and the exact figure if the three sizes partition RDREQ)
+        print("# read requests by size, per step and family: n(all) n32 n64 n128 | 32 n32 + 64 n64 + 128 n128 (GB) | same with n64 := all - n32 - n128 (GB)"
+              " | factor-model read (GB)")
+        exact = 0.0
+        for r in rows:
+            c = per[r["family"]]
+            n, n32, n64, n128 = (c[k] / K for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"))
+            b1 = 32 * n32 + 64 * n64 + 128 * n128
+            b2 = 32 * n32 + 64 * max(n - n32 - n128, 0.0) + 128 * n128
+            r["read_bytes_by_request_size"] = b2
+            exact += b2
+            print(f"{r['family']:58s} {n:10.4g} {n32:10.4g} {n64:10.4g} {n128:10.4g} | {b1 / 1e9:8.2f} | {b2 / 1e9:8.2f} | {r['read_bytes'] / 1e9:8.2f}")
+        print(f"read bytes by request size: {exact / 1e9:.2f} GB per step (factor model: {tot['read'] / 1e9:.2f}); with the writes: {(exact + tot['write']) / 1e9:.2f} GB"
+              f" = {(exact + tot['write']) / alg:.2f} x algorithmic")
+    # the dominant launch IN the step (3x3 s1 128->128 @256^2, B = 32: 536.9 MB in, 536.9 MB out): the wide-kernel dispatches whose WRITE_SIZE
+    # is that output (+ the 4 MB statistics table of the forward variants), matched across passes by position in the step window
+    dom = None
+    names = [[n for _, n, _ in w] for w in windows]
+    if all(nm == names[0] for nm in names):
+        merged = [collections.defaultdict(float) for _ in names[0]]
+        for w in windows:
+            for i, (_, _, c) in enumerate(w):
+                for cn, v in c.items():
+                    merged[i][cn] += v
+        sel = [m for n, m in zip(names[0], merged) if "conv3x3_wide" in n and 520000 <= m["WRITE_SIZE"] <= 545000]
+        if sel:
+            fe = sum(m["FETCH_SIZE"] for m in sel) / len(sel) * 1024
+            wr = sum(m["WRITE_SIZE"] for m in sel) / len(sel) * 1024
+            dom = dict(launches=len(sel) / K, fetch_size_bytes=fe, write_bytes=wr, hbm_bytes_per_launch=fe + wr, algorithmic_bytes=2 * 32 * 256 * 256 * 128 * 2)
+            print(f"dominant launch in the step (wide kernel, 128->128 @256^2, B=32): {len(sel) / K:.0f} launches per step, FETCH_SIZE {fe / 1e6:.1f} MB (x1: 64-byte "
+                  f"requests) + WRITE_SIZE {wr / 1e6:.1f} MB = {(fe + wr) / 1e6:.1f} MB per launch; algorithmic 1073.7 MB (residual launches +536.9 MB)")
+    else:
+        print("(dispatch sequences differ between passes: no per-launch figure)")
     if out_json:
         json.dump(dict(steps=K, warmup=W, per_gpu_batch=batch, step_traffic_bytes=total, read_bytes=tot["read"], write_bytes=tot["write"],
                        lower_bound_bytes=tot["lo"], upper_bound_bytes=tot["hi"], algorithmic_bytes=alg,
-                       step_traffic_over_algorithmic=total / alg, groupnorm_bytes=gn, families=rows,
+                       step_traffic_over_algorithmic=total / alg, groupnorm_bytes=gn, families=rows, read_bytes_by_request_size=exact, dominant_launch=dom,
                        source="tools/step_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (own passes) over bench.py's timed steps"),
                   open(out_json, "w"), indent=1)
 

@@ -9,7 +9,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -oE "\b(TCC_EA0_[A-Z0-9_]*(RDREQ|WRREQ|RD_|WR_)[A-Z0-9_]*|FETCH_SIZE|WRITE_SIZE|TCC_EA0_[A-Z0-9_]*DRAM[A-Z0-9_]*|TCC_[A-Z0-9_]*MALL[A-Z0-9_]*)\b" | sort -u > $R/$O/counters_available.txt
 i=0
-for CNT in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+for CNT in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   i=$((i+1)); rm -rf /tmp/st_$i
   timeout 600 rocprofv3 --pmc $CNT --kernel-trace -d /tmp/st_$i -o st --output-format csv -- python $R/bench.py --steps $K --warmup $W --no-cpu-baseline --no-also --no-encoder-stack > /tmp/st_$i.log 2>&1 || { echo "pass $i ($CNT) failed"; tail -5 /tmp/st_$i.log; continue; }
   f=$(find /tmp/st_$i -name "*counter_collection.csv" | head -1)
