@@ -36,6 +36,7 @@ struct WideParams {
     int Hl, Wl, pad_top, pad_left, upsample, act;
     int n_chunks, Cout_pad, tiles_h, tiles_w, n_ct;
     unsigned m_ct, m_tw, m_th;                 // ceil(2^32 / d) for d = n_ct, tiles_w, tiles_h: t / d == umulhi(t, m) (host checks t * d < 2^32)
+    int xcd_bands;                             // 1: every XCD walks its own contiguous eighth of the tile list (see the prologue)
 };
 
 constexpr int W_PWL = 34;                      // patch pitch in pixels (32 + 2)
@@ -229,7 +230,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
     auto b_addr = [&](int P) { return P * 64 + (((g ^ (P >> 2)) & 3) << 4); };   // kk = 0; kk = 1 is ^ 32
 
     // ---- prologue ----------------------------------------------------------------------------------------------------------------
+    // Tile walk.  Work-group b runs on XCD b % 8 (observed dispatch order; speed only, never correctness).  With the plain static stride
+    // (b, b + G, ...) the 32 CUs of an XCD work on tiles 8 apart: no two of them share a halo, and every 18x34 patch (1.195x its tile)
+    // comes over the fabric.  xcd_bands: XCD x owns the contiguous eighth [T x / 8, T (x + 1) / 8) of the tile list and its work-groups
+    // walk it in order, so the tiles in flight on one XCD are spatial neighbours (a whole image of a 256^2 map) and their halos meet in
+    // that XCD's L2 (profiles/r06_xcd_bands.txt).  Same registers as before: `step` replaces gridDim.x, `tile_end` replaces total_tiles.
     int tile = blockIdx.x;                      // grid <= total_tiles
+    int step = (int)gridDim.x, tile_end = total_tiles;
+    if (p.xcd_bands && (gridDim.x & 7) == 0) {
+        const int x = blockIdx.x & 7;
+        step = (int)(gridDim.x >> 3);
+        tile = (int)(((long long)total_tiles * x) >> 3) + (int)(blockIdx.x >> 3);
+        tile_end = (int)(((long long)total_tiles * (x + 1)) >> 3);
+    }
     int c0_cur, c0_nxt, ob_cur[4];
     // ONE plan / image descriptor: the current tile's until its last chunk-B patch has been issued (stage 1 of the last pair),
     // the next tile's from stage 2 of the last pair on (only the in-bounds masks of both tiles are live at the same time)
@@ -278,8 +291,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(WideParams p) {
 #endif
 
     for (;;) {
-        const int next_tile = tile + (int)gridDim.x;
-        const bool has_next = next_tile < total_tiles;
+        const int next_tile = tile + step;
+        const bool has_next = next_tile < tile_end;
         WTS(0);
 
         f32x16 acc[4][2];
@@ -583,6 +596,14 @@ int mas_conv3x3_wide_launch(const MasConvDesc* d, const void* x, const float* sc
     p.tiles_h = mas_cdiv(d->Ho, 16); p.tiles_w = mas_cdiv(d->Wo, 32); p.n_ct = d->Cout / 128;
     auto magic = [](int dv) { return (unsigned)((0x100000000ULL + (unsigned)dv - 1) / (unsigned)dv); };   // (d = 1 handled in the kernel)
     p.m_ct = magic(p.n_ct); p.m_tw = magic(p.tiles_w); p.m_th = magic(p.tiles_h);
+    static const int xcd_bands = mas_env_int("MAS_CONV_XCD_BANDS", 1);
+    {   // the banded walk needs every band at least as long as the number of work-groups that walk it
+        const long long tiles = (long long)p.N * p.tiles_h * p.tiles_w * p.n_ct;
+        static const int wgs_per_cu = mas_env_int("MAS_CONV_WGS_PER_CU", 0);
+        const long long resident = (long long)(wgs_per_cu > 0 ? wgs_per_cu : 4) * mas_num_cus();
+        const long long blocks = tiles < resident ? tiles : resident;
+        p.xcd_bands = (xcd_bands && blocks % 8 == 0 && tiles / 8 >= blocks / 8) ? 1 : 0;
+    }
     if (stats) {
         if (d->act != MAS_ACT_NONE) return residual ? launch_wide<true, true, true>(p, s) : launch_wide<true, false, true>(p, s);
         return residual ? launch_wide<false, true, true>(p, s) : launch_wide<false, false, true>(p, s);
