@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dp", default="mas", choices=["mas", "ddp"],
                     help="N>1 gradient averaging: mas_hip.dp.GradReducer (default) or torch DistributedDataParallel")
+    ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="N>1 with --dp mas: the type the gradient buckets cross the links in (bf16: 190 MB instead of 381 MB per VQ-IMG step; "
+                         "A/B knob for the first multi-GPU run, off by default)")
     ap.add_argument("--optimizer", default="mas", choices=["mas", "torch", "torch-default"],
                     help="mas: mas_hip.optim.Adam (the same update as torch.optim.Adam, every parameter in one launch; tests/test_gpu_adam.py); "
                          "torch: torch.optim.Adam(fused=True); torch-default: torch.optim.Adam(params, lr, betas) exactly as the reference's "
@@ -321,7 +324,7 @@ def _wrap_dp(model, args, ddp, local_rank):
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True)
     elif ddp:                                               # same semantics, a few flat buckets instead of per-parameter copies
         from mas_hip.dp import GradReducer
-        reducer = GradReducer(model.parameters())
+        reducer = GradReducer(model.parameters(), grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else None)
     return net, reducer
 
 
@@ -431,7 +434,7 @@ def _emit(out):
 
 
 def _par(world, args, ddp):
-    return f"dp{world}" + ((" (DistributedDataParallel" if args.dp == "ddp" else " (mas_hip.dp.GradReducer: 128 MiB flat buckets,")
+    return f"dp{world}" + ((" (DistributedDataParallel" if args.dp == "ddp" else " (mas_hip.dp.GradReducer: 128 MiB flat buckets" + (" crossing the links as bf16," if args.grad_dtype == "bf16" else ","))
                            + " RCCL all-reduce overlapped with backward)" if ddp else "")
 
 
