@@ -248,15 +248,25 @@ def _adam(args, params, **kw):
     return torch.optim.Adam(params, fused=True, **kw)
 
 
-def _pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC summary (a separate profiled run of the
-    same kernel and shape, tools/pmc_kernel.sh), not measured by this run."""
-    p = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
+def _step_traffic():
+    """The COMMITTED rocprofv3 PMC summary of whole training steps of THIS command (tools/step_traffic.sh: FETCH_SIZE / WRITE_SIZE / request-size
+    counters in their own passes over `bench.py --steps 3 --warmup 2`; profiles/r06_step_traffic.{txt,json}) -- a profiled run cannot also
+    be the timed one, so the bench line carries the committed figures and says so."""
     try:
-        with open(p) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+        with open(os.path.join(ROOT, "profiles", "r06_step_traffic.json")) as f:
+            return json.load(f)
     except Exception:
         return None
+
+
+def _pmc_traffic():
+    """Fabric-side bytes (L2 <-> Infinity Cache / HBM) per launch of the dominant kernel, measured INSIDE the step (round 6; until round 5 a
+    kbench back-to-back loop whose inputs partly sat in the Infinity Cache): 2 x FETCH_SIZE (every read request is a 128-byte line fill)
+    + WRITE_SIZE, averaged over the 20 launches of the shape per step."""
+    st = _step_traffic()
+    if st and st.get("dominant_launch"):
+        return int(st["dominant_launch"]["hbm_bytes_per_launch"])
+    return None
 
 
 def _encoder_stack(model, x, batch, dtype):
@@ -547,7 +557,8 @@ def run_vq(args):
                                          "MAS_GN_MATERIALIZE=0; the forward launches also carry the next GroupNorm's statistics in their epilogue)",
                                "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": _pmc_traffic(),
-                               "traffic_source": "committed rocprofv3 PMC pass on the same kernel and shape (profiles/pmc_dominant_kernel.json), not measured by this run",
+                               "traffic_source": "committed rocprofv3 PMC passes over whole steps of this command (profiles/r06_step_traffic.json, tools/"
+                                                 "step_traffic.sh): per-launch average of the shape INSIDE the step, 2 x FETCH_SIZE + WRITE_SIZE; not measured by this run",
                                "avg_launch_ms": round(avg_ms, 4), "launches_timed": n_ev, "populations": pops,
                                "algorithmic_gflop_per_launch": round(flops / 1e9, 1),
                                "algorithmic_hbm_gbs": round(bytes_ / (avg_ms * 1e-3) / 1e9, 1),
@@ -555,6 +566,18 @@ def run_vq(args):
         if not args.no_encoder_stack:
             out["encoder_stack"] = _encoder_stack(model, x, batch, args.dtype)
         if "roofline" in out:
+            st = _step_traffic()
+            if st and st.get("per_gpu_batch") == batch:
+                # the step's real traffic next to its algorithmic bytes: GroupNorm's passes count zero bytes by SURVEY 8(d)'s
+                # rule and move a third of what crosses the fabric; the convolutions fetch ~1.85x their algorithmic bytes (32-channel chunks
+                # touch every 128-byte line twice, ~8 us apart, and the second touch misses the XCD's L2 one time in three; split-K slabs)
+                out["roofline"]["step_traffic_bytes"] = int(st["step_traffic_bytes"])
+                out["roofline"]["step_algorithmic_bytes"] = int(st["algorithmic_bytes"])
+                out["roofline"]["step_traffic_over_algorithmic"] = round(st["step_traffic_over_algorithmic"], 2)
+                out["roofline"]["step_traffic_groupnorm_share"] = round(st["groupnorm_bytes"] / st["step_traffic_bytes"], 2)
+                out["roofline"]["step_traffic_gbs"] = round(st["step_traffic_bytes"] / (dt / args.steps) / 1e9, 1)   # at THIS run's step time
+                if out["roofline"].get("traffic") and st.get("dominant_launch"):
+                    out["roofline"]["traffic_over_algorithmic"] = round(st["dominant_launch"]["hbm_bytes_per_launch"] / st["dominant_launch"]["algorithmic_bytes"], 2)
             # what this tile design can reach on this silicon: the shipped kernel with everything but its MFMAs and LDS fragment reads
             # compiled out (profiles/r02_wide_store_ablation.txt / DESIGN R2.2: 0.466 ms at the ~1.6 GHz the chip sustains under this
             # load = 1.33 PFLOP/s): the vendor peak `frac` is priced against assumes 2.4 GHz

@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
-"""Per-step HBM-side traffic from the per-dispatch counter files tools/step_traffic.sh writes.
+"""Per-step fabric-side traffic (L2 <-> Infinity Cache / HBM) from the per-dispatch counter files tools/step_traffic.sh writes
+(VERDICT r5 next #2).
 
     python tools/step_traffic.py <dir with pass_*.csv> K W [--json out.json]
 
 The K timed steps are cut out of the dispatch stream by the one kernel that runs exactly once per step (`adam_multi_kernel`): the window
-is (dispatch of Adam #W, dispatch of Adam #(W+K)].  Per kernel family: launches per step, FETCH_SIZE / WRITE_SIZE per step, and the read
-bytes after the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts REQUESTS at 64 B each, so
-a stream of full 128-byte lines reports half its bytes (x2: calibrated here on `gn_act`, whose read is exactly its tensor -- profiles/
-r05_gn_tuning.txt -- and on tools/probes/fetch_calib.hip, profiles/r02_fetch_calibration.txt) while a stream of 64-byte requests (the
-32-channel-chunk LDS-DMA pieces of the wide / sub-pixel / LDS-DMA weight-gradient kernels: 4 lanes x 16 B per pixel) reports all of
-them (x1: same calibration file, profiles/r05_up2_pmc.txt).  Families without a calibration of their own are priced at x2 and flagged;
-the totals are also given with x1 and x2 everywhere (lower / upper bound).  WRITE_SIZE is taken as is (equals the output tensor of the
-convolution and of gn_act exactly).  Infinity-Cache hits are INCLUDED in both counters (they sit at the L2's fabric side), so this is
-"bytes that left the XCDs' L2s", the quantity SURVEY 8(d)'s algorithmic bytes are compared with."""
+is (dispatch of Adam #W, dispatch of Adam #(W+K)].  Per kernel family: launches per step, read and write bytes per step.
+
+READ bytes.  FETCH_SIZE counts the L2's fabric-side read REQUESTS at 64 B each (/opt/skills/guides/MI355X_MICROARCH.md, HBM section:
+"double it"), and this rocprofv3 also exposes the request-size counters: over whole steps TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ (32-B: 0,
+64-B: < 0.1 %) for EVERY family -- the L2 fills whole 128-byte lines whatever part of the line was asked for.  So read bytes =
+128 x RDREQ = 2 x FETCH_SIZE everywhere.  Rounds 2-5 priced the wide / sub-pixel / LDS-DMA weight-gradient kernels at x1 because
+tools/probes/fetch_calib.hip's half-line stream (64 B of every 128-B line) reports exactly the bytes it ASKED for; what that calibration
+shows is one 128-byte fill per line touched, i.e. twice the useful bytes crossed the fabric (their 32-channel-chunk patch pieces are
+64 B per pixel: every line is touched by two chunk passes ~8 us apart, and the second touch misses the XCD's 4 MiB L2 about one time in
+three -- 32 CUs stream ~3.5 MB through it in that time).  The x1 column is kept for comparison with the older profiles.
+WRITE bytes: WRITE_SIZE as is (all write requests are 64 B: TCC_EA0_WRREQ_64B == TCC_EA0_WRREQ; equals the output tensors exactly).
+Infinity-Cache hits are INCLUDED in both (the counters sit at the L2's fabric side): this is "bytes that left the XCDs' L2s", an upper
+bound of the HBM bytes and the quantity SURVEY 8(d)'s algorithmic bytes are compared with."""
 import collections
 import csv
 import json
@@ -113,12 +118,22 @@ def main():
                          write_bytes=write))
         print(f"{fam:58s} {launches[fam] / K:8.1f} {fetch / 1e6:10.1f} {fac:4d} {read / 1e9:8.2f} {write / 1e9:9.2f} {(read + write) / 1e9:9.2f}"
               f"  {'' if cal else 'factor uncalibrated'}")
-    total = tot["read"] + tot["write"]
-    print(f"{'TOTAL per step':58s} {sum(launches.values()) / K:8.1f} {'':10s} {'':4s} {tot['read'] / 1e9:8.2f} {tot['write'] / 1e9:9.2f} {total / 1e9:9.2f}")
-    print(f"bounds: every read at x1 {tot['lo'] / 1e9:.2f} GB, every read at x2 {tot['hi'] / 1e9:.2f} GB per step")
+    lines128 = {"TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum"} <= counters_seen and \
+        abs(sum(per[f]["TCC_EA0_RDREQ_128B_sum"] for f in per) / max(sum(per[f]["TCC_EA0_RDREQ_sum"] for f in per), 1.0) - 1.0) < 0.01
+    for r in rows:                       # every fabric read request is a 128-byte line fill (checked above): read = 2 x FETCH_SIZE
+        r["read_bytes_x1_model"] = r["read_bytes"]
+        r["read_bytes"] = 2 * r["fetch_size_bytes"]
+    total = tot["hi"]
+    tot["read_model"], tot["read"] = tot["read"], tot["hi"] - tot["write"]
+    print(f"{'TOTAL per step (old per-family factors)':58s} {sum(launches.values()) / K:8.1f} {'':10s} {'':4s} {tot['read_model'] / 1e9:8.2f} {tot['write'] / 1e9:9.2f} "
+          f"{(tot['read_model'] + tot['write']) / 1e9:9.2f}")
+    print(f"TOTAL per step, every read request a 128-byte line fill ({'confirmed by TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ' if lines128 else 'request-size pass missing: the guide rule'}): "
+          f"read {tot['read'] / 1e9:.2f} GB + write {tot['write'] / 1e9:.2f} GB = {total / 1e9:.2f} GB")
     print(f"algorithmic (SURVEY 8(d): 1.79 GB per image x {batch}): {alg / 1e9:.2f} GB per step -> traffic / algorithmic = {total / alg:.2f} "
-          f"(bounds {tot['lo'] / alg:.2f} .. {tot['hi'] / alg:.2f})")
+          f"(with the old x1 factors: {(tot['read_model'] + tot['write']) / alg:.2f})")
     gn = sum(r["read_bytes"] + r["write_bytes"] for r in rows if r["family"].startswith("GroupNorm"))
+    conv = sum(r["read_bytes"] + r["write_bytes"] for r in rows if "conv" in r["family"] or "gradient" in r["family"] or "reduce" in r["family"])
+    print(f"convolution kernels (all families, split-K reduce included): {conv / 1e9:.2f} GB per step = {conv / alg:.2f} x the step's algorithmic bytes")
     print(f"GroupNorm passes: {gn / 1e9:.2f} GB per step = {gn / total:.2f} of the step's traffic (algorithmic bytes by SURVEY's rule: 0)")
     for extra in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_WRREQ_sum",
                   "TCC_EA0_WRREQ_64B_sum"):
@@ -154,14 +169,18 @@ def main():
         if sel:
             fe = sum(m["FETCH_SIZE"] for m in sel) / len(sel) * 1024
             wr = sum(m["WRITE_SIZE"] for m in sel) / len(sel) * 1024
-            dom = dict(launches=len(sel) / K, fetch_size_bytes=fe, write_bytes=wr, hbm_bytes_per_launch=fe + wr, algorithmic_bytes=2 * 32 * 256 * 256 * 128 * 2)
-            print(f"dominant launch in the step (wide kernel, 128->128 @256^2, B=32): {len(sel) / K:.0f} launches per step, FETCH_SIZE {fe / 1e6:.1f} MB (x1: 64-byte "
-                  f"requests) + WRITE_SIZE {wr / 1e6:.1f} MB = {(fe + wr) / 1e6:.1f} MB per launch; algorithmic 1073.7 MB (residual launches +536.9 MB)")
+            n_res = sum(1 for m in sel if m["WRITE_SIZE"] > 535000)          # (the residual variants also write their statistics table)
+            alg_l = (2 * 32 * 256 * 256 * 128 * 2 * len(sel) + 32 * 256 * 256 * 128 * 2 * n_res) / len(sel)
+            dom = dict(launches=len(sel) / K, fetch_size_bytes=fe, read_bytes=2 * fe, write_bytes=wr, hbm_bytes_per_launch=2 * fe + wr,
+                       algorithmic_bytes=alg_l, residual_launches=n_res / K)
+            print(f"dominant launch in the step (wide kernel, 128->128 @256^2, B=32): {len(sel) / K:.0f} launches per step ({n_res / K:.0f} with a residual), "
+                  f"FETCH_SIZE {fe / 1e6:.1f} MB -> read {2 * fe / 1e6:.1f} MB (128-byte line fills) + WRITE_SIZE {wr / 1e6:.1f} MB = {(2 * fe + wr) / 1e6:.1f} MB "
+                  f"per launch; algorithmic {alg_l / 1e6:.1f} MB (1073.7, +536.9 for a residual) -> {(2 * fe + wr) / alg_l:.2f} x")
     else:
         print("(dispatch sequences differ between passes: no per-launch figure)")
     if out_json:
         json.dump(dict(steps=K, warmup=W, per_gpu_batch=batch, step_traffic_bytes=total, read_bytes=tot["read"], write_bytes=tot["write"],
-                       lower_bound_bytes=tot["lo"], upper_bound_bytes=tot["hi"], algorithmic_bytes=alg,
+                       all_read_requests_are_128B_lines=bool(lines128), with_old_x1_factors_bytes=tot["read_model"] + tot["write"], algorithmic_bytes=alg,
                        step_traffic_over_algorithmic=total / alg, groupnorm_bytes=gn, families=rows, read_bytes_by_request_size=exact, dominant_launch=dom,
                        source="tools/step_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (own passes) over bench.py's timed steps"),
                   open(out_json, "w"), indent=1)
