@@ -52,19 +52,20 @@ def test_training_forward_backward_running_stats_vs_batchnorm2d(shape):
         yo, yr = ours(xo), ref(xr)
         assert yo.is_contiguous(memory_format=torch.channels_last) and yo.dtype == torch.float32
         (yo * gy).sum().backward(); (yr * gy).sum().backward()
-        e_y, e_dx = _rel(yo, yr), _rel(xo.grad, xr.grad)
-        if e_y >= 2e-5 or e_dx >= 1e-4:
-            # ill-conditioned channels (the 1x32x1x2 case: two values per channel -- rstd amplifies the rounding of the variance, and dx is
-            # O(eps / var) of its terms, pure cancellation): torch's fp32 statistics and the fp64 sums here round differently; the arbiter
-            # is the same module in fp64
+        pairs = [("y", yo, yr, 2e-5), ("dx", xo.grad, xr.grad, 1e-4), ("dgamma", ours.weight.grad, ref.weight.grad, 2e-5),
+                 ("dbeta", ours.bias.grad, ref.bias.grad, 2e-5)]
+        if any(_rel(a, b) >= tol for _, a, b, tol in pairs):
+            # ill-conditioned channels (the 1x32x1x2 case: two values per channel -- rstd amplifies the rounding of the variance, xhat is +-1
+            # up to that rounding and dx is O(eps / var) of its terms): torch's fp32 statistics and the fp64 sums here round differently;
+            # the arbiter is the same module in fp64: ours must be as close to it as torch's fp32 result is (x 1.5), or within the tolerance
             r64 = torch.nn.BatchNorm2d(c, momentum=ref.momentum).double()
             r64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in ours.state_dict().items()})
             x64 = x.detach().cpu().double().requires_grad_(True)
             y64 = r64(x64)
             (y64 * gy.cpu().double()).sum().backward()
-            assert _rel(yo, y64) <= max(2e-5, 1.5 * _rel(yr, y64)), (step, _rel(yo, y64), _rel(yr, y64))
-            assert _rel(xo.grad, x64.grad) <= max(1e-4, 1.5 * _rel(xr.grad, x64.grad)), (step, _rel(xo.grad, x64.grad), _rel(xr.grad, x64.grad))
-        assert _rel(ours.weight.grad, ref.weight.grad) < 2e-5 and _rel(ours.bias.grad, ref.bias.grad) < 2e-5
+            truth = dict(y=y64, dx=x64.grad, dgamma=r64.weight.grad, dbeta=r64.bias.grad)
+            for name, a, b, tol in pairs:
+                assert _rel(a, truth[name]) <= max(tol, 1.5 * _rel(b, truth[name])), (step, name, _rel(a, truth[name]), _rel(b, truth[name]))
         ours.weight.grad = ours.bias.grad = ref.weight.grad = ref.bias.grad = None
     assert _rel(ours.running_mean, ref.running_mean) < 1e-5 and _rel(ours.running_var, ref.running_var) < 1e-5
     assert int(ours.num_batches_tracked) == int(ref.num_batches_tracked) == 2
