@@ -1443,6 +1443,80 @@ class _LayerNormFork(torch.autograd.Function):
         return dx, dg, db, None, None
 
 
+class _LayerNormPair(torch.autograd.Function):
+    """(LN2(xnew), xnew) with xnew = residual + LN1(h): the sandwich LayerNorm + residual of one sub-block and the pre-LayerNorm of the
+    next as ONE node and ONE pass each way (``mas_layernorm_pair_fwd / _bwd``; reference models/transformer.py:201-203 + :205, and
+    :207-209 + the next layer's :197 / the final LayerNorm).  ``xnew`` is also the skip connection of the next sub-block, so the node has
+    the two outputs ``_LayerNormFork`` has; the gradient that comes back along the skip is added inside the backward kernel, which hands
+    the gradient of xnew on as the gradient of ``residual`` and runs LN1's backward on it without a trip through memory.  Values: bit
+    for bit those of ``_LayerNorm`` followed by ``_LayerNormFork``."""
+
+    @staticmethod
+    def forward(ctx, h, residual, w1, b1, eps1, w2, b2, eps2, y_dtype, want_colsum):
+        _require_cuda(h, "layer_norm_pair")
+        d = h.shape[-1]
+        rows = h.numel() // d
+        h = h.contiguous()
+        residual = residual.contiguous()
+        xnew = torch.empty(h.shape, dtype=residual.dtype, device=h.device)
+        y2 = torch.empty(h.shape, dtype=y_dtype, device=h.device)
+        mr1 = torch.empty((rows, 2), dtype=torch.float32, device=h.device)
+        mr2 = torch.empty((rows, 2), dtype=torch.float32, device=h.device)
+        w1f, b1f = w1.detach().float().contiguous(), b1.detach().float().contiguous()
+        w2f, b2f = w2.detach().float().contiguous(), b2.detach().float().contiguous()
+        check(lib().mas_layernorm_pair_fwd(_ptr(h), _ptr(w1f), _ptr(b1f), _ptr(residual), _ptr(w2f), _ptr(b2f), _ptr(xnew), _ptr(y2), _ptr(mr1),
+                                           _ptr(mr2), _DT[h.dtype], _DT[residual.dtype], _DT[y_dtype], rows, d, float(eps1), float(eps2), _stream()),
+              "layernorm_pair_fwd")
+        ctx.save_for_backward(h, xnew, w1, w2, mr1, mr2)
+        ctx.y_dtype, ctx.want_colsum = y_dtype, bool(want_colsum)
+        return y2, xnew
+
+    @staticmethod
+    def backward(ctx, dy2, dskip):
+        h, xnew, w1, w2, mr1, mr2 = ctx.saved_tensors
+        d = h.shape[-1]
+        rows = h.numel() // d
+        if dskip is not None:
+            dskip = dskip.to(xnew.dtype).contiguous()
+        if dy2 is None:                                    # the second LayerNorm's output was not used: LN1's backward alone
+            if dskip is None:
+                return (None,) * 10
+            dh, dg1, db1 = _layer_norm_bwd(h, w1, mr1, dskip, xnew.dtype, None, ctx.want_colsum)
+            return dh, dskip, dg1, db1, None, None, None, None, None, None
+        dy2 = dy2.to(ctx.y_dtype).contiguous()
+        dh = torch.empty_like(h)
+        dres = torch.empty_like(xnew)
+        dg1, db1, dg2, db2 = (torch.empty(d, dtype=torch.float32, device=h.device) for _ in range(4))
+        dc = torch.empty(d, dtype=torch.float32, device=h.device) if ctx.want_colsum else None
+        wsb = lib().mas_layernorm_pair_bwd_workspace(rows, d)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=h.device)
+        w1f, w2f = w1.detach().float().contiguous(), w2.detach().float().contiguous()
+        check(lib().mas_layernorm_pair_bwd(_ptr(h), _ptr(xnew), _ptr(dy2), _ptr(dskip), _ptr(w1f), _ptr(w2f), _ptr(mr1), _ptr(mr2), _ptr(dh), _ptr(dres),
+                                           _ptr(dg1), _ptr(db1), _ptr(dg2), _ptr(db2), _ptr(dc), _DT[h.dtype], _DT[xnew.dtype], _DT[ctx.y_dtype], rows, d,
+                                           _ptr(ws), wsb, _stream()), "layernorm_pair_bwd")
+        if ctx.want_colsum:
+            _colsum_hint.put(dh, dc)
+        return dh, dres, dg1.to(w1.dtype), db1.to(w1.dtype), None, dg2.to(w2.dtype), db2.to(w2.dtype), None, None, None
+
+
+_LN_PAIR = os.environ.get("MAS_LN_PAIR", "1") == "1"
+
+
+def layer_norm_pair(h, residual, ln1, ln2, producer_bias_grad=False):
+    """-> (ln2(xnew), xnew) with xnew = residual + ln1(h), for two ``nn.LayerNorm``-like modules over the last dimension.  One fused
+    launch each way where the kernels apply -- the autocast transformer (h bf16, fp32 residual stream, bf16 consumer) or everything fp32,
+    D % 4 == 0, D <= 1024, equal shapes -- else (and with ``MAS_LN_PAIR=0``) the two separate nodes: the same values either way."""
+    y_dtype = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else residual.dtype
+    d = h.shape[-1]
+    ok = (_LN_PAIR and h.is_cuda and residual.shape == h.shape and residual.dtype == torch.float32 and d % 4 == 0 and d <= 1024
+          and ((h.dtype == torch.bfloat16 and y_dtype == torch.bfloat16) or (h.dtype == torch.float32 and y_dtype == torch.float32)))
+    if not ok:
+        xnew = layer_norm(h, ln1.weight, ln1.bias, ln1.eps, residual, producer_bias_grad=producer_bias_grad)
+        return layer_norm_fork(xnew, ln2.weight, ln2.bias, ln2.eps)
+    want = bool(producer_bias_grad) and h.grad_fn is not None and type(h.grad_fn).__name__.startswith("_LinearBf16")
+    return _LayerNormPair.apply(h, residual, ln1.weight, ln1.bias, ln1.eps, ln2.weight, ln2.bias, ln2.eps, y_dtype, want)
+
+
 def layer_norm(x, weight, bias, eps=1e-5, residual=None, out_dtype=None, producer_bias_grad=False):
     """``out_dtype`` None: the residual's dtype if one is given, else the autocast dtype when autocast is on (the
     consumer is a Linear that would cast anyway), else the input's dtype.  ``producer_bias_grad``: x is the output of a Linear layer --

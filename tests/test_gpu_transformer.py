@@ -1,6 +1,7 @@
 """Transformer rows of the hot path: the flash-style causal attention kernel vs the CPU oracle
 of ``SelfAttention.calculate_attention`` (mask*s - (1-mask)*1e4, PB-relax shift, softmax), and the drop-in
 ``MakeAScene`` vs the golden logits / gradients produced by the reference itself."""
+import contextlib
 import os
 
 import numpy as np
@@ -438,3 +439,66 @@ def test_linear_bf16_shadow_weights_follow_the_optimizer():
         a.weight.data.mul_(2.0)                      # a write through .data: invisible to the version check
     ops.invalidate_weight_cache()
     assert torch.equal(ops._bf16_shadows.get(a.weight), a.weight.detach().bfloat16())
+
+
+@pytest.mark.parametrize("mode", ["autocast", "fp32"])
+@pytest.mark.parametrize("rows,d", [(300, 1024), (37, 64), (1030, 256)])
+def test_layer_norm_pair_equals_the_two_separate_launches(mode, rows, d):
+    """ops.layer_norm_pair (round 6: sandwich LayerNorm + residual and the next pre-LayerNorm as one launch each way; reference
+    transformer.py:201-205, 207-209 + the next layer's :197) against the two nodes it replaces (``layer_norm`` with a residual, then
+    ``layer_norm_fork``): outputs, dh and dres bit for bit; the four parameter gradients and the Linear's bias gradient to summation
+    order; and against torch's fp32 LayerNorm arithmetic."""
+    import torch.nn.functional as F
+    from mas_hip import ops
+    from models.transformer import LayerNorm, Linear
+    torch.manual_seed(rows + d)
+    lin = Linear(64, d).cuda()
+    ln1, ln2 = LayerNorm(d, eps=1e-5).cuda(), LayerNorm(d, eps=1e-5).cuda()
+    with torch.no_grad():
+        for m in (ln1, ln2):
+            m.weight.copy_(1.0 + 0.2 * torch.randn(d)); m.bias.copy_(0.1 * torch.randn(d))
+    x = torch.randn(rows, 64, device="cuda")
+    res = torch.randn(rows, d, device="cuda")
+    gy, gs = torch.randn(rows, d, device="cuda"), torch.randn(rows, d, device="cuda")
+    params = list(lin.parameters()) + list(ln1.parameters()) + list(ln2.parameters())
+
+    def run(paired):
+        for p in params:
+            p.grad = None
+        xi, ri = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        ctx = torch.autocast("cuda", dtype=torch.bfloat16) if mode == "autocast" else contextlib.nullcontext()
+        with ctx:
+            h = lin(xi)
+            if paired:
+                y2, xnew = ops.layer_norm_pair(h, ri, ln1, ln2, producer_bias_grad=True)
+            else:
+                xn = ln1(h, residual=ri, producer_bias_grad=True)
+                y2, xnew = ln2.fork(xn)
+        ((y2.float() * gy).sum() + (xnew * gs).sum()).backward()
+        return y2.detach(), xnew.detach(), xi.grad.clone(), ri.grad.clone(), [p.grad.clone() for p in params]
+
+    old = ops._LN_PAIR
+    try:
+        ops._LN_PAIR = True
+        h0 = ops._colsum_hint.hits
+        y_p, x_p, gx_p, gr_p, gp_p = run(True)
+        hits_pair = ops._colsum_hint.hits - h0
+        y_s, x_s, gx_s, gr_s, gp_s = run(False)
+    finally:
+        ops._LN_PAIR = old
+    assert y_p.dtype == (torch.bfloat16 if mode == "autocast" else torch.float32) and x_p.dtype == torch.float32
+    assert torch.equal(y_p, y_s) and torch.equal(x_p, x_s)
+    assert torch.equal(gr_p, gr_s) and torch.equal(gx_p, gx_s)                   # dres; dx through the same GEMM from a bitwise-equal dh
+    assert torch.equal(gp_p[0], gp_s[0])                                         # the Linear's weight gradient: same dh
+    rel = lambda a, c: float((a.double() - c.double()).norm() / (c.double().norm() + 1e-30))
+    for a, c in zip(gp_p[1:], gp_s[1:]):                                         # bias gradient + the four LayerNorm parameter gradients
+        assert rel(a, c) < 2e-6, rel(a, c)
+    if mode == "autocast":
+        assert hits_pair == 1                                                    # the Linear took its bias gradient from the pair's backward
+    # and the arithmetic itself, against torch in fp32 on the same h
+    with torch.no_grad():
+        h = lin(x) if mode == "fp32" else F.linear(x.bfloat16(), lin.weight.bfloat16(), lin.bias.bfloat16()).float()
+        xr = res + F.layer_norm(h, (d,), ln1.weight, ln1.bias, 1e-5)
+        yr = F.layer_norm(xr, (d,), ln2.weight, ln2.bias, 1e-5)
+    tol = 2e-5 if mode == "fp32" else 2e-2
+    assert rel(x_p, xr) < tol and rel(y_p.float(), yr) < tol
