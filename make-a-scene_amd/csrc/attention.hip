@@ -1064,7 +1064,9 @@ __global__ __launch_bounds__(NT, FA_DKV_WGS) void attn_bwd_dkv_bf16_kernel(AttnB
     for (int it = 0; it < n_tiles; ++it) {
         const int q0 = q_start + it * QT2;
         const bool more = it + 1 < n_tiles;
+#ifndef FB_ABL_NODMA                                 // (ablation builds of the BACKWARD, round 6: profiles/r06_attn_bwd_ablation.txt; -DFB_ABL_* change results)
         if (more) issue(q0 + QT2, cur ^ 1);         // the other stage was last read before the barrier that ended the previous tile
+#endif
         const unsigned char* qt = fa_smem + cur * STAGE;
         const unsigned char* gt = qt + FaTile::BYTES;
         const float* lse_s = reinterpret_cast<const float*>(qt + 2 * FaTile::BYTES);
@@ -1084,8 +1086,12 @@ __global__ __launch_bounds__(NT, FA_DKV_WGS) void attn_bwd_dkv_bf16_kernel(AttnB
                     for (int r = 0; r < 16; ++r) z[r] = 0.0f;
                     s = z; dp = z;
                 }
+#ifndef FB_ABL_NOSDP
                 mma16(s, qa, kf[kk]);
                 mma16(dp, ga, vf[kk]);
+#else
+                s[kk] += (float)qa[0]; dp[kk] += (float)ga[0];
+#endif
             }
             f32x4 l4[4], d4[4];                     // rows r = 4j..4j+3 are queries 8j + 4g + 0..3 of the block
 #pragma unroll
@@ -1096,8 +1102,13 @@ __global__ __launch_bounds__(NT, FA_DKV_WGS) void attn_bwd_dkv_bf16_kernel(AttnB
             const bool needs_mask = (qs < kw + 31) || (qs + 32 > p.S) || (kw + 32 > p.S);
             // (the mask as ONE wave-uniform branch around 16 selects, not a branch per element: with the test inside the element loop the
             //  compiler cut this block into 33 basic blocks per 32 MFMAs and nothing could be scheduled across them)
+#ifndef FB_ABL_NOSOFTMAX
 #pragma unroll
+#ifndef FB_ABL_NOEXP
             for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -l4[r >> 2][r & 3]));      // P[query][key]
+#else
+            for (int r = 0; r < 16; ++r) s[r] = __builtin_fmaf(s[r], c2, -l4[r >> 2][r & 3]);
+#endif
             if (needs_mask) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1107,6 +1118,10 @@ __global__ __launch_bounds__(NT, FA_DKV_WGS) void attn_bwd_dkv_bf16_kernel(AttnB
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) dp[r] = s[r] * (dp[r] - d4[r >> 2][r & 3]) * p.scale;                            // dS[query][key]
+#else
+            if (needs_mask && c2 == 12345.0f) s[0] = l4[0][0] + d4[0][0];
+#endif
+#ifndef FB_ABL_NOOUT
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 bf16x8 pf, sf;
@@ -1118,6 +1133,10 @@ __global__ __launch_bounds__(NT, FA_DKV_WGS) void attn_bwd_dkv_bf16_kernel(AttnB
                     mma16(dk[i], fa_tr_tile_frag(qt, sub * 32 + 16 * t, i, g, G16, sl), sf);    // dK^T += Q^T dS
                 }
             }
+#else
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dv[0][r] += s[r]; dk[0][r] += dp[r]; }
+#endif
         }
         if (more) commit(fa_smem + (cur ^ 1) * STAGE);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of the next tile have landed
@@ -1140,7 +1159,10 @@ __global__ __launch_bounds__(NT, FA_DKV_WGS) void attn_bwd_dkv_bf16_kernel(AttnB
     }
 }
 
-__global__ __launch_bounds__(NT, 3) void attn_bwd_dq_bf16_kernel(AttnBwdParams p) {       // (round 3: DMA staging -> <= 168 VGPRs, 3 waves per SIMD)
+#ifndef FA_DQ_WGS
+#define FA_DQ_WGS 3
+#endif
+__global__ __launch_bounds__(NT, FA_DQ_WGS) void attn_bwd_dq_bf16_kernel(AttnBwdParams p) {       // (round 3: DMA staging -> <= 168 VGPRs, 3 waves per SIMD)
     using T = bf16_t;
     constexpr int HD = 64, NKK = 4, NMI = 2, KT2 = 64;
     constexpr int STAGE = 2 * FaTile::BYTES;
@@ -1194,10 +1216,12 @@ __global__ __launch_bounds__(NT, 3) void attn_bwd_dq_bf16_kernel(AttnBwdParams p
     for (int it = 0; it < n_tiles; ++it) {
         const int k0 = it * KT2;
         const bool more = it + 1 < n_tiles;
+#ifndef FB_ABL_NODMA
         if (more) {                                 // the other stage was last read before the barrier that ended the previous tile
             fa_dma_tile(rs_k, lds0 + (cur ^ 1) * STAGE, k0 + KT2, p.S, p.ld, wave, lane, vo);
             fa_dma_tile(rs_v, lds0 + (cur ^ 1) * STAGE + FaTile::BYTES, k0 + KT2, p.S, p.ld, wave, lane, vo);
         }
+#endif
         const unsigned char* kt = fa_smem + cur * STAGE;
         const unsigned char* vt = kt + FaTile::BYTES;
 #pragma unroll
@@ -1215,12 +1239,21 @@ __global__ __launch_bounds__(NT, 3) void attn_bwd_dq_bf16_kernel(AttnBwdParams p
                     for (int r = 0; r < 16; ++r) z[r] = 0.0f;
                     s = z; dp = z;
                 }
+#ifndef FB_ABL_NOSDP
                 mma16(s, ka, qf[kk]);
                 mma16(dp, va, gf[kk]);
+#else
+                s[kk] += (float)ka[0]; dp[kk] += (float)va[0];
+#endif
             }
             const bool needs_mask = (ks + 31 > qw) || (ks + 32 > p.S);
+#ifndef FB_ABL_NOSOFTMAX
 #pragma unroll
+#ifndef FB_ABL_NOEXP
             for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -my_lse2));
+#else
+            for (int r = 0; r < 16; ++r) s[r] = __builtin_fmaf(s[r], c2, -my_lse2);
+#endif
             if (needs_mask) {                                        // (one wave-uniform branch around 16 selects: see attn_bwd_dkv)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1230,6 +1263,10 @@ __global__ __launch_bounds__(NT, 3) void attn_bwd_dq_bf16_kernel(AttnBwdParams p
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) dp[r] = s[r] * (dp[r] - my_delta) * p.scale;                                     // dS^T[key][query]
+#else
+            if (needs_mask && c2 == 12345.0f) s[0] = my_lse2 + my_delta;
+#endif
+#ifndef FB_ABL_NOOUT
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 bf16x8 sf;
@@ -1238,6 +1275,10 @@ __global__ __launch_bounds__(NT, 3) void attn_bwd_dq_bf16_kernel(AttnBwdParams p
 #pragma unroll
                 for (int i = 0; i < NMI; ++i) mma16(dq[i], fa_tr_tile_frag(kt, sub * 32 + 16 * t, i, g, G16, sl), sf);   // dQ^T += K^T dS^T
             }
+#else
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dq[0][r] += s[r]; dq[1][r] += dp[r]; }
+#endif
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of the next tile have landed
         __syncthreads();

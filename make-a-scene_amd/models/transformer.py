@@ -225,95 +225,6 @@ class TransformerLayer(nn.Module):
         return (y, new_cache) if next_ln is None else (y, new_cache, None)
 
     def _forward_cached(self, x, cache):
-        if torch.is_grad_enabled() and x.requires_grad:
-            raise RuntimeError("KV-cached attention is an inference path: call it under torch.no_grad()")
-        b, s_tot, d = x.shape
-        h = self.num_attn_heads
-        past = 0 if cache is None else cache[0].shape[-2]
-        nq = s_tot - past
-        if nq <= 0:
-            raise RuntimeError(f"SelfAttention: the cache already holds {past} positions, the input has {s_tot}")
-        qkv = self.qkv(x[:, past:, :])
-        dt = qkv.dtype
-        if cache is None:
-            cap = max(getattr(self, "cache_capacity", 0), s_tot)
-            kbuf = torch.empty((b, cap, d), dtype=dt, device=x.device)
-            vbuf = torch.empty_like(kbuf)
-            obuf = torch.empty_like(kbuf)
-        else:
-            # the [B, cap, D] buffers behind the views; an entry that is NOT such a view any more (cloned, made contiguous,
-            # index_select'ed for a beam / batch reorder) is rebuilt from its [B, H, L, hd] / [B, L, D] contents
-            kbuf, vbuf = (_kv_backing(t, b, d) for t in cache[:2])
-            obuf = _row_backing(cache[2], b, d)
-            if kbuf.shape[1] < s_tot or obuf.shape[1] < s_tot or vbuf.shape[1] != kbuf.shape[1]:                                                  # grow geometrically, copy once
-                cap = max(2 * kbuf.shape[1], s_tot)
-                grow = lambda t: torch.cat([t[:, :past], torch.empty((b, cap - past, d), dtype=t.dtype, device=t.device)], dim=1)
-                kbuf, vbuf, obuf = grow(kbuf), grow(vbuf), grow(obuf)
-        kbuf[:, past:s_tot] = qkv[..., d:2 * d]
-        vbuf[:, past:s_tot] = qkv[..., 2 * d:]
-        q = qkv[..., :d]
-        if cache is None and nq > 1:
-            context = ops.causal_attention(qkv, h)                  # prefill: the training kernel on the whole prompt
-        else:
-            context = ops.attention_decode(q, kbuf, vbuf, past, h)  # decode: one pass over the cached rows
-        obuf[:, past:s_tot] = self.out_proj(context)
-        hd = d // h
-        view = lambda t: t[:, :s_tot].view(b, s_tot, h, hd).permute(0, 2, 1, 3)
-        return self.out_drop(obuf[:, :s_tot]), (view(kbuf), view(vbuf), obuf[:, :s_tot])
-
-
-class MLP(nn.Module):
-    def __init__(self, hidden_dim, dropout_prob, rudalle_relax=False):
-        super(MLP, self).__init__()
-        self.lin1 = Linear(hidden_dim, 4 * hidden_dim)
-        self.lin2 = Linear(4 * hidden_dim, hidden_dim)
-        self.dropout = nn.Dropout(dropout_prob)
-        self.rudalle_relax = rudalle_relax
-
-    def forward(self, x):
-        if self.rudalle_relax:
-            raise NotImplementedError("rudalle_relax is off the measured path")
-        return self.dropout(self.lin2(gelu(self.lin1(x))))
-
-
-class TransformerLayer(nn.Module):
-    def __init__(self, hidden_dim, num_attn_heads, attn_dropout_prop, out_dropout_prob, cogview_pb_relax=True,
-                 cogview_sandwich_layernorm=True, cogview_layernorm_prescale=False, rudalle_relax=False):
-        super().__init__()
-        self.cogview_pb_relax = cogview_pb_relax
-        self.cogview_sandwich_layernorm = cogview_sandwich_layernorm
-        self.cogview_layernorm_prescale = cogview_layernorm_prescale
-        self.rudalle_relax = rudalle_relax
-        self.ln_in = LayerNorm(hidden_dim, eps=1e-5)
-        self.ln_out = LayerNorm(hidden_dim, eps=1e-5)
-        if cogview_sandwich_layernorm:
-            self.first_ln_sandwich = LayerNorm(hidden_dim, eps=1e-5)
-            self.second_ln_sandwich = LayerNorm(hidden_dim, eps=1e-5)
-        self.attn = SelfAttention(hidden_dim=hidden_dim, num_attn_heads=num_attn_heads, attn_dropout_prob=attn_dropout_prop,
-                                  out_dropout_prob=out_dropout_prob, cogview_pb_relax=cogview_pb_relax, rudalle_relax=rudalle_relax)
-        self.mlp = MLP(hidden_dim=hidden_dim, dropout_prob=out_dropout_prob, rudalle_relax=rudalle_relax)
-
-    def _prescale(self, t):
-        return t / t.detach().max(dim=-1)[0].unsqueeze(-1) if self.cogview_layernorm_prescale else t
-
-    def forward(self, x, mask, cache=None, use_cache=False, mlp_cache=False):
-        if use_cache:
-            return self._forward_cached(x, cache)
-        fork = not self.cogview_layernorm_prescale      # (the prescale variant divides x before the LayerNorm: plain path)
-        ln, skip = self.ln_in.fork(x) if fork else (self.ln_in(self._prescale(x)), x)
-        attn_out, new_cache = self.attn(ln, mask, False, cache)
-        if self.cogview_sandwich_layernorm:
-            x = self.first_ln_sandwich(self._prescale(attn_out), residual=skip,     # x + LN(attn_out), one pass
-                                       producer_bias_grad=not self.cogview_layernorm_prescale)
-        else:
-            x = skip + attn_out
-        ln, skip = self.ln_out.fork(x) if fork else (self.ln_out(self._prescale(x)), x)
-        mlp_out = self.mlp(ln)
-        if self.cogview_sandwich_layernorm:
-            return self.second_ln_sandwich(mlp_out, residual=skip, producer_bias_grad=not self.cogview_layernorm_prescale), new_cache
-        return skip + mlp_out, new_cache
-
-    def _forward_cached(self, x, cache):
         """Full sequence in, full sequence out, only the positions past the cache computed (reference transformer.py:170-210
         with its two defects fixed, see the module docstring).  cache = (k, v, attn_out, layer_out): the attention's tuple plus
         this layer's own outputs so far (the reference keeps those for the last layer only, ``mlp_cache``)."""
