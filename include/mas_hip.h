@@ -330,16 +330,11 @@ int mas_layernorm_bwd_colsum(const void* x, const void* dy, const float* gamma, 
  *   or the final LayerNorm :264) -- the row stays in registers between the two: 12 B per element instead of 16, bit for bit the values
  *   of the two separate launches.  h / dh in h_dtype, residual / xnew / dres / dskip in x_dtype, y2 / dy2 in y_dtype:
  *   (bf16, fp32, bf16) -- the autocast transformer with its fp32 residual stream -- or all fp32.  D % 4 == 0, D <= 1024.
- *   backward: dres = LN2'(dy2) [+ dskip] (the gradient of xnew = of the residual), dh = LN1'(dres); dh_colsum (may be NULL) = the column
- *   sums of dh as stored: the bias gradient of the Linear that produced h.                                                           */
+ *   The backward is mas_layernorm_bwd_add on (xnew, dy2, dskip) followed by mas_layernorm_bwd_colsum on (h, its result): a fused form was
+ *   built and lost (two waves per SIMD at 190 VGPRs: 80 us against 34 + 25).                                                         */
 int mas_layernorm_pair_fwd(const void* h, const float* gamma1, const float* beta1, const void* residual, const float* gamma2,
                            const float* beta2, void* xnew, void* y2, float* mean_rstd1, float* mean_rstd2, int h_dtype, int x_dtype,
                            int y_dtype, int rows, int D, float eps1, float eps2, void* stream);
-size_t mas_layernorm_pair_bwd_workspace(int rows, int D);
-int mas_layernorm_pair_bwd(const void* h, const void* xnew, const void* dy2, const void* dskip, const float* gamma1, const float* gamma2,
-                           const float* mean_rstd1, const float* mean_rstd2, void* dh, void* dres, float* dgamma1, float* dbeta1,
-                           float* dgamma2, float* dbeta2, float* dh_colsum, int h_dtype, int x_dtype, int y_dtype, int rows, int D,
-                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* mas_colsum: out[c] = sum over rows of x[r][c] (fp32 accumulation, fixed summation order: bitwise run-to-run deterministic).
  *   The bias gradient of the transformer's Linear layers (torch.nn.Linear in reference models/transformer.py:31,34,125,126:

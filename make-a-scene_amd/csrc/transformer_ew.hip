@@ -264,7 +264,9 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const TI* __restrict_
 //   xnew = res + LN1(h)        (h: the attention / MLP output; reference models/transformer.py:201-203, 207-209)
 //   y2   = LN2(xnew)           (:197-198 of the next sub-block / layer, or the final LayerNorm)
 // The row stays in registers between the two normalisations: xnew is written once and never read back (the separate launches move
-// 16 B per element, this one 12).  Same arithmetic, same order and -- xnew being rounded to its storage type before the second
+// 16 B per element, this one 12).  The BACKWARD of the pair stays two launches: fused, its five accumulator arrays (dgamma / dbeta of both
+// LayerNorms + the producer's bias gradient) take the kernel to 190 VGPRs = two waves per SIMD, and a latency-bound stream at that occupancy
+// ran 80 us against 34 + 25 for the two launches (profiles/r06_ln_pair.txt; docs/history/experiments/r6_ln_pair_bwd.patch).  Same arithmetic, same order and -- xnew being rounded to its storage type before the second
 // statistics -- the same values as the two launches of layernorm_fwd_kernel, bit for bit.  VEC = 4 (one of the three types is fp32).
 template <typename TI, typename TO, typename TY>
 __global__ __launch_bounds__(NT) void layernorm_pair_fwd_kernel(const TI* __restrict__ h, const float* __restrict__ g1, const float* __restrict__ b1,
@@ -337,117 +339,6 @@ __global__ __launch_bounds__(NT) void layernorm_pair_fwd_kernel(const TI* __rest
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) o[e] = (v[k][e] - mean2) * rstd2 * ga[e] + be[e];
                 st_n<TY, VEC>(y2 + (size_t)row * D + c * VEC, o);
-            }
-        }
-    }
-}
-
-// backward of the pair: dxn = LN2'(dy2) + dskip (the gradient of xnew: also the gradient of `res`, written once as dres), then
-// dh = LN1'(dxn); partial[blk][NP][D] = {dgamma2, dbeta2, dgamma1, dbeta1[, column sum of dh as stored]}.  dxn never leaves the
-// registers between the two backward formulas (the separate launches write it and read it back: 22 B per element against 18).
-template <typename TI, typename TO, typename TY, bool CS>
-__global__ __launch_bounds__(NT) void layernorm_pair_bwd_kernel(const TI* __restrict__ h, const TO* __restrict__ xnew, const TY* __restrict__ dy2,
-                                                                const TO* __restrict__ dskip, const float* __restrict__ g1, const float* __restrict__ g2,
-                                                                const float* __restrict__ mr1, const float* __restrict__ mr2, TI* __restrict__ dh,
-                                                                TO* __restrict__ dres, float* __restrict__ partial, int rows, int D) {
-    constexpr int NP = CS ? 5 : 4;
-    constexpr int VEC = 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nvec = D / VEC;
-    float a_g2[LN_KMAX][VEC], a_b2[LN_KMAX][VEC], a_g1[LN_KMAX][VEC], a_b1[LN_KMAX][VEC], a_c[CS ? LN_KMAX : 1][VEC];
-#pragma unroll
-    for (int k = 0; k < LN_KMAX; ++k)
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) { a_g2[k][e] = 0.0f; a_b2[k][e] = 0.0f; a_g1[k][e] = 0.0f; a_b1[k][e] = 0.0f; if (CS) a_c[k][e] = 0.0f; }
-    for (int row = blockIdx.x * (NT / 64) + wave; row < rows; row += gridDim.x * (NT / 64)) {
-        const size_t ro = (size_t)row * D;
-        const float mean2 = mr2[2 * (size_t)row], rstd2 = mr2[2 * (size_t)row + 1];
-        const float mean1 = mr1[2 * (size_t)row], rstd1 = mr1[2 * (size_t)row + 1];
-        float xh[LN_KMAX][VEC], g[LN_KMAX][VEC];
-        float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-        for (int k = 0; k < LN_KMAX; ++k) {
-            const int c = k * 64 + lane;
-            if (c < nvec) {
-                float xv[VEC], dv[VEC], ga[VEC];
-                ld_n<TO, VEC>(xnew + ro + c * VEC, xv);
-                ld_n<TY, VEC>(dy2 + ro + c * VEC, dv);
-                ld_n<float, VEC>(g2 + c * VEC, ga);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const float d = dv[e];
-                    xh[k][e] = (xv[e] - mean2) * rstd2;
-                    g[k][e] = d * ga[e];
-                    s1 += g[k][e]; s2 += g[k][e] * xh[k][e];
-                    a_g2[k][e] += d * xh[k][e]; a_b2[k][e] += d;
-                }
-            }
-        }
-        float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
-        s1 = 0.0f; s2 = 0.0f;
-#pragma unroll
-        for (int k = 0; k < LN_KMAX; ++k) {
-            const int c = k * 64 + lane;
-            if (c < nvec) {
-                float o[VEC], hv[VEC], ga[VEC];
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) o[e] = rstd2 * (g[k][e] - m1 - xh[k][e] * m2);
-                if (dskip) {                                   // the gradient that reached xnew along its skip connection
-                    float sk[VEC];
-                    ld_n<TO, VEC>(dskip + ro + c * VEC, sk);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) o[e] += sk[e];
-                }
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) o[e] = (float)(TO)o[e];   // dxn as the separate launches store it
-                st_n<TO, VEC>(dres + ro + c * VEC, o);
-                ld_n<TI, VEC>(h + ro + c * VEC, hv);
-                ld_n<float, VEC>(g1 + c * VEC, ga);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const float d = o[e];
-                    xh[k][e] = (hv[e] - mean1) * rstd1;        // (the arrays of the first formula are dead: reused)
-                    g[k][e] = d * ga[e];
-                    s1 += g[k][e]; s2 += g[k][e] * xh[k][e];
-                    a_g1[k][e] += d * xh[k][e]; a_b1[k][e] += d;
-                }
-            }
-        }
-        m1 = wave_sum(s1) / (float)D; m2 = wave_sum(s2) / (float)D;
-#pragma unroll
-        for (int k = 0; k < LN_KMAX; ++k) {
-            const int c = k * 64 + lane;
-            if (c < nvec) {
-                float o[VEC];
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) o[e] = rstd1 * (g[k][e] - m1 - xh[k][e] * m2);
-                if (CS) {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) a_c[k][e] += (float)(TI)o[e];
-                }
-                st_n<TI, VEC>(dh + ro + c * VEC, o);
-            }
-        }
-    }
-    __shared__ float red[(NT / 64)][NP][64 * VEC + 1];
-#pragma unroll
-    for (int k = 0; k < LN_KMAX; ++k) {
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            red[wave][0][lane * VEC + e] = a_g2[k][e]; red[wave][1][lane * VEC + e] = a_b2[k][e];
-            red[wave][2][lane * VEC + e] = a_g1[k][e]; red[wave][3][lane * VEC + e] = a_b1[k][e];
-            if (CS) red[wave][NP - 1][lane * VEC + e] = a_c[k][e];
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < NP * 64 * VEC; i += NT) {
-            const int which = i / (64 * VEC), j = i % (64 * VEC);
-            const int col = k * 64 * VEC + j;
-            if (col < D) {
-                float a = 0.0f;
-#pragma unroll
-                for (int w = 0; w < NT / 64; ++w) a += red[w][which][j];
-                partial[((size_t)blockIdx.x * NP + which) * D + col] = a;
             }
         }
     }
@@ -679,44 +570,6 @@ extern "C" int mas_layernorm_pair_fwd(const void* h, const float* gamma1, const 
         hipLaunchKernelGGL((layernorm_pair_fwd_kernel<float, float, float>), grid, block, 0, s, (const float*)h, gamma1, beta1, (const float*)residual,
                            gamma2, beta2, (float*)xnew, (float*)y2, mean_rstd1, mean_rstd2, rows, D, eps1, eps2);
     MAS_CHECK_LAUNCH("layernorm_pair_fwd");
-    return MAS_OK;
-}
-
-extern "C" size_t mas_layernorm_pair_bwd_workspace(int rows, int D) {
-    if (rows <= 0 || D <= 0) return 0;
-    return (size_t)ln_blocks(rows) * 5 * (size_t)D * sizeof(float);
-}
-
-extern "C" int mas_layernorm_pair_bwd(const void* h, const void* xnew, const void* dy2, const void* dskip, const float* gamma1, const float* gamma2,
-                                      const float* mean_rstd1, const float* mean_rstd2, void* dh, void* dres, float* dgamma1, float* dbeta1,
-                                      float* dgamma2, float* dbeta2, float* dh_colsum, int h_dtype, int x_dtype, int y_dtype, int rows, int D,
-                                      void* workspace, size_t workspace_bytes, void* stream) {
-    MAS_ENTER();
-    if (!h || !xnew || !dy2 || !gamma1 || !gamma2 || !mean_rstd1 || !mean_rstd2 || !dh || !dres || !dgamma1 || !dbeta1 || !dgamma2 || !dbeta2 ||
-        !workspace)
-        MAS_FAIL(MAS_EINVAL, "layernorm_pair_bwd: null argument");
-    if (int rc = ln_pair_check(h_dtype, x_dtype, y_dtype, rows, D, "layernorm_pair_bwd")) return rc;
-    if (workspace_bytes < mas_layernorm_pair_bwd_workspace(rows, D)) MAS_FAIL(MAS_EINVAL, "layernorm_pair_bwd: workspace too small");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static const int per_cu = mas_env_int("MAS_LN_PAIR_BWD_BLOCKS_PER_CU", 3);
-    const int nblk = ln_blocks(rows, per_cu);
-    float* partial = reinterpret_cast<float*>(workspace);
-#define MAS_LN_PAIR_BWD(TI, TO, TY)                                                                                                                \
-    do {                                                                                                                                           \
-        if (dh_colsum) hipLaunchKernelGGL((layernorm_pair_bwd_kernel<TI, TO, TY, true>), dim3(nblk), dim3(NT), 0, s, (const TI*)h, (const TO*)xnew,   \
-                                          (const TY*)dy2, (const TO*)dskip, gamma1, gamma2, mean_rstd1, mean_rstd2, (TI*)dh, (TO*)dres, partial, rows, D); \
-        else hipLaunchKernelGGL((layernorm_pair_bwd_kernel<TI, TO, TY, false>), dim3(nblk), dim3(NT), 0, s, (const TI*)h, (const TO*)xnew,            \
-                                (const TY*)dy2, (const TO*)dskip, gamma1, gamma2, mean_rstd1, mean_rstd2, (TI*)dh, (TO*)dres, partial, rows, D);     \
-    } while (0)
-    if (h_dtype == MAS_BF16) MAS_LN_PAIR_BWD(bf16_t, float, bf16_t);
-    else MAS_LN_PAIR_BWD(float, float, float);
-#undef MAS_LN_PAIR_BWD
-    const int np = dh_colsum ? 5 : 4;
-    // the fold kernel writes three outputs per launch: {dgamma2, dbeta2, dgamma1} then {dbeta1[, column sum of dh]}
-    hipLaunchKernelGGL(fold_rows_kernel, dim3(mas_cdiv(D, 32), 3), dim3(NT), 0, s, partial, nblk, D, (long long)np * D, (long long)D, dgamma2, dbeta2, dgamma1);
-    hipLaunchKernelGGL(fold_rows_kernel, dim3(mas_cdiv(D, 32), np - 3), dim3(NT), 0, s, partial + 3 * (size_t)D, nblk, D, (long long)np * D, (long long)D, dbeta1,
-                       dh_colsum, dh_colsum);
-    MAS_CHECK_LAUNCH("layernorm_pair_bwd");
     return MAS_OK;
 }
 

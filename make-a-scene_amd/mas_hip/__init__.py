@@ -115,8 +115,6 @@ _SIGNATURES = {
     "mas_bn_bwd_apply_act": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _p]),
     "mas_layernorm_bwd_colsum": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "mas_layernorm_pair_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p]),
-    "mas_layernorm_pair_bwd_workspace": (_sz, [_i, _i]),
-    "mas_layernorm_pair_bwd": (_i, [_p] * 15 + [_i, _i, _i, _i, _i, _p, _sz, _p]),
     "mas_colsum_workspace": (_sz, [_i, _i]),
     "mas_colsum": (_i, [_p, _i, _i, _i, _p, _p, _sz, _p]),
 }

@@ -1445,11 +1445,11 @@ class _LayerNormFork(torch.autograd.Function):
 
 class _LayerNormPair(torch.autograd.Function):
     """(LN2(xnew), xnew) with xnew = residual + LN1(h): the sandwich LayerNorm + residual of one sub-block and the pre-LayerNorm of the
-    next as ONE node and ONE pass each way (``mas_layernorm_pair_fwd / _bwd``; reference models/transformer.py:201-203 + :205, and
+    next as ONE node (``mas_layernorm_pair_fwd``; reference models/transformer.py:201-203 + :205, and
     :207-209 + the next layer's :197 / the final LayerNorm).  ``xnew`` is also the skip connection of the next sub-block, so the node has
-    the two outputs ``_LayerNormFork`` has; the gradient that comes back along the skip is added inside the backward kernel, which hands
-    the gradient of xnew on as the gradient of ``residual`` and runs LN1's backward on it without a trip through memory.  Values: bit
-    for bit those of ``_LayerNorm`` followed by ``_LayerNormFork``."""
+    the two outputs ``_LayerNormFork`` has.  Forward: one launch (``mas_layernorm_pair_fwd``: the row stays in registers between the two
+    normalisations, 12 B per element instead of 16).  Backward: the two launches of the unfused form.  Values: bit for bit those of
+    ``_LayerNorm`` followed by ``_LayerNormFork``."""
 
     @staticmethod
     def forward(ctx, h, residual, w1, b1, eps1, w2, b2, eps2, y_dtype, want_colsum):
@@ -1483,20 +1483,11 @@ class _LayerNormPair(torch.autograd.Function):
                 return (None,) * 10
             dh, dg1, db1 = _layer_norm_bwd(h, w1, mr1, dskip, xnew.dtype, None, ctx.want_colsum)
             return dh, dskip, dg1, db1, None, None, None, None, None, None
-        dy2 = dy2.to(ctx.y_dtype).contiguous()
-        dh = torch.empty_like(h)
-        dres = torch.empty_like(xnew)
-        dg1, db1, dg2, db2 = (torch.empty(d, dtype=torch.float32, device=h.device) for _ in range(4))
-        dc = torch.empty(d, dtype=torch.float32, device=h.device) if ctx.want_colsum else None
-        wsb = lib().mas_layernorm_pair_bwd_workspace(rows, d)
-        ws = torch.empty(wsb // 4, dtype=torch.float32, device=h.device)
-        w1f, w2f = w1.detach().float().contiguous(), w2.detach().float().contiguous()
-        check(lib().mas_layernorm_pair_bwd(_ptr(h), _ptr(xnew), _ptr(dy2), _ptr(dskip), _ptr(w1f), _ptr(w2f), _ptr(mr1), _ptr(mr2), _ptr(dh), _ptr(dres),
-                                           _ptr(dg1), _ptr(db1), _ptr(dg2), _ptr(db2), _ptr(dc), _DT[h.dtype], _DT[xnew.dtype], _DT[ctx.y_dtype], rows, d,
-                                           _ptr(ws), wsb, _stream()), "layernorm_pair_bwd")
-        if ctx.want_colsum:
-            _colsum_hint.put(dh, dc)
-        return dh, dres, dg1.to(w1.dtype), db1.to(w1.dtype), None, dg2.to(w2.dtype), db2.to(w2.dtype), None, None, None
+        # LN2's backward with the skip gradient added in the kernel -> the gradient of xnew (= of the residual), then LN1's backward on it
+        # (with the producer's bias gradient): the two launches of the unfused form -- the fused backward kernel lost (transformer_ew.hip)
+        dxn, dg2, db2 = _layer_norm_bwd(xnew, w2, mr2, dy2.to(ctx.y_dtype).contiguous(), ctx.y_dtype, dskip)
+        dh, dg1, db1 = _layer_norm_bwd(h, w1, mr1, dxn, xnew.dtype, None, ctx.want_colsum)
+        return dh, dxn, dg1, db1, None, dg2, db2, None, None, None
 
 
 _LN_PAIR = os.environ.get("MAS_LN_PAIR", "1") == "1"
@@ -1504,7 +1495,7 @@ _LN_PAIR = os.environ.get("MAS_LN_PAIR", "1") == "1"
 
 def layer_norm_pair(h, residual, ln1, ln2, producer_bias_grad=False):
     """-> (ln2(xnew), xnew) with xnew = residual + ln1(h), for two ``nn.LayerNorm``-like modules over the last dimension.  One fused
-    launch each way where the kernels apply -- the autocast transformer (h bf16, fp32 residual stream, bf16 consumer) or everything fp32,
+    forward launch where the kernel applies -- the autocast transformer (h bf16, fp32 residual stream, bf16 consumer) or everything fp32,
     D % 4 == 0, D <= 1024, equal shapes -- else (and with ``MAS_LN_PAIR=0``) the two separate nodes: the same values either way."""
     y_dtype = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else residual.dtype
     d = h.shape[-1]
