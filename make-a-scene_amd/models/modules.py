@@ -29,10 +29,13 @@ import torch.distributed as dist
 from mas_hip import ACT_AFFINE, ACT_AFFINE_SILU, ACT_NONE
 from mas_hip import ops
 
-# SyncBatchNorm: 1 (default) = batchnorm.hip wherever no cross-rank exchange is needed (one rank, or evaluation) and torch's own module for
-# the exchanging case; 2 = batchnorm.hip also WITH the exchange (one fp64 all_reduce each way; tested over gloo at two ranks, never run on
-# RCCL hardware -- there is no multi-GPU node here -- hence not the default); 0 = torch's implementation everywhere
-_MAS_SYNCBN = int(os.environ.get("MAS_SYNCBN", "1"))
+# SyncBatchNorm: 2 (default since round 6) = batchnorm.hip everywhere, WITH the cross-rank exchange when the group has more than one rank (one
+# all_reduce of 2 C + 1 fp64 sums each way: tested at two ranks over gloo against the full batch, and over RCCL itself at world size 1 with the
+# exchange forced -- tests/test_gpu_bn.py; no multi-GPU node exists here, so RCCL has not carried it between two devices yet);
+# 1 = batchnorm.hip only where no exchange is needed, torch's own module for the exchanging case (the default of round 5);
+# 0 = torch's implementation everywhere.  MAS_SYNCBN_EXCHANGE_AT_WORLD_1=1 (tests): a one-rank group exchanges too.
+_MAS_SYNCBN = int(os.environ.get("MAS_SYNCBN", "2"))
+_EXCHANGE_AT_WORLD_1 = os.environ.get("MAS_SYNCBN_EXCHANGE_AT_WORLD_1", "0") == "1"
 
 
 def nonlinearity(x):
@@ -52,10 +55,10 @@ def Normalize(in_channels):
 class SyncBatchNorm(nn.SyncBatchNorm):
     """``nn.SyncBatchNorm`` parameters, buffers and ``state_dict`` keys (reference models/vqvae.py:16: the normalisation behind
     ``quant_conv``) on ``libmas_hip.so``'s BatchNorm kernels (``batchnorm.hip``) for a 4-D fp32 CUDA input: per-rank sums in a fixed order,
-    running statistics as torch keeps them.  With more than one rank in ``process_group`` the training forward needs the cross-rank
-    exchange: by default that case stays on torch's own implementation (``MAS_SYNCBN=2``: one all_reduce of the fp64 sums each way
-    around the same kernels -- tested over gloo, not yet on RCCL hardware).  ``MAS_SYNCBN=0`` (or any other input) falls through to
-    torch's implementation everywhere."""
+    running statistics as torch keeps them.  With more than one rank in ``process_group`` the training forward exchanges the per-rank
+    sums: ONE all_reduce of 2 C + 1 fp64 values each way around the same kernels (the default since round 6; ``MAS_SYNCBN=1`` hands that
+    case to torch's own implementation, as round 5 did).  ``MAS_SYNCBN=0`` (or any other input) falls through to torch's
+    implementation everywhere."""
 
     def forward(self, x):
         if not (_MAS_SYNCBN and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.shape[1] <= 1024
@@ -65,7 +68,7 @@ class SyncBatchNorm(nn.SyncBatchNorm):
         group = None
         if training and torch.distributed.is_available() and torch.distributed.is_initialized():
             pg = self.process_group if self.process_group is not None else torch.distributed.group.WORLD
-            if torch.distributed.get_world_size(pg) > 1:
+            if torch.distributed.get_world_size(pg) > 1 or _EXCHANGE_AT_WORLD_1:
                 if _MAS_SYNCBN < 2:
                     return super().forward(x)               # the exchanging case: torch's own module unless MAS_SYNCBN=2 (see above)
                 group = pg

@@ -235,3 +235,56 @@ def test_two_ranks_exchange_equals_the_full_batch(tmp_path, mode):
     assert rel(r0["gw"], ref.weight.grad.cpu().numpy()) < 2e-5 and rel(r0["gb"], ref.bias.grad.cpu().numpy()) < 2e-5
     for r in (r0, r1):
         assert rel(r["rm"], ref.running_mean.cpu().numpy()) < 1e-5 and rel(r["rv"], ref.running_var.cpu().numpy()) < 1e-5
+
+
+def _rccl_worker(out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "make-a-scene_amd"))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MAS_SYNCBN="2", MAS_SYNCBN_EXCHANGE_AT_WORLD_1="1")
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    except Exception as e:                                    # no RCCL in this environment: reported, not failed
+        open(out, "w").write("skip: " + repr(e))
+        return
+    torch.cuda.set_device(0)
+    from mas_hip import ops
+    calls = []
+    real = dist.all_reduce
+
+    def spy(t, *a, **k):
+        calls.append((t.dtype, tuple(t.shape), t.device.type))
+        return real(t, *a, **k)
+    dist.all_reduce = spy
+    ours, ref = _pair(256)
+    g = torch.Generator().manual_seed(4)
+    x = (1.2 * torch.randn(8, 256, 16, 16, generator=g) + 0.3).cuda()
+    gy = torch.randn(8, 256, 16, 16, generator=g).cuda()
+    xo, xr = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    yo, yr = ours(xo), ref(xr)
+    (yo * gy).sum().backward(); (yr * gy).sum().backward()
+    torch.cuda.synchronize()
+    res = dict(y=_rel(yo, yr), dx=_rel(xo.grad, xr.grad), dw=_rel(ours.weight.grad, ref.weight.grad), rv=_rel(ours.running_var, ref.running_var),
+               calls=calls)
+    dist.destroy_process_group()
+    open(out, "w").write(repr(res))
+
+
+def test_exchange_runs_over_rccl_at_world_size_one(tmp_path):
+    """The default since round 6 (MAS_SYNCBN=2) exchanges the fp64 sums with torch.distributed.all_reduce on whatever backend the group
+    has; two-rank arithmetic is pinned over gloo above.  Here the SAME code path runs on the NCCL (= RCCL) backend -- one rank, the
+    exchange forced (MAS_SYNCBN_EXCHANGE_AT_WORLD_1=1) -- so that the fp64 CUDA all_reduce of 2 C + 1 values, its stream ordering
+    against the kernels around it and the backward's second exchange have run on RCCL before a multi-GPU node sees them."""
+    _dev()
+    out = str(tmp_path / "rccl.txt")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_worker, args=(out,))
+    p.start(); p.join(300)
+    assert p.exitcode == 0, p.exitcode
+    txt = open(out).read()
+    if txt.startswith("skip"):
+        pytest.skip(txt)
+    res = eval(txt, {"torch": torch})
+    assert res["y"] < 2e-5 and res["dx"] < 1e-4 and res["dw"] < 2e-5 and res["rv"] < 1e-5, res
+    assert len(res["calls"]) == 2 and all(c == (torch.float64, (513,), "cuda") for c in res["calls"]), res["calls"]
