@@ -1139,7 +1139,9 @@ __global__ __launch_bounds__(NT, FA_DKV_WGS) void attn_bwd_dkv_bf16_kernel(AttnB
 #endif
         }
         if (more) commit(fa_smem + (cur ^ 1) * STAGE);
+#ifndef FB_ABL_NOWAIT                                // (timing only: is the DMA's LATENCY exposed, or only its issue?)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of the next tile have landed
+#endif
         __syncthreads();
         cur ^= 1;
     }
@@ -1280,7 +1282,9 @@ __global__ __launch_bounds__(NT, FA_DQ_WGS) void attn_bwd_dq_bf16_kernel(AttnBwd
             for (int r = 0; r < 16; ++r) { dq[0][r] += s[r]; dq[1][r] += dp[r]; }
 #endif
         }
+#ifndef FB_ABL_NOWAIT
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of the next tile have landed
+#endif
         __syncthreads();
         cur ^= 1;
     }
