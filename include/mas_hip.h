@@ -302,6 +302,13 @@ int mas_space_to_depth2x(const void* x, void* y, int dtype, int N, int H, int W,
  *   backward.  D must be a multiple of the 16-byte vector (8 for bf16->bf16, else 4) and at most 256 vectors.      */
 int mas_gelu_tanh_fwd(const void* x, void* y, int dtype, long long n, void* stream);
 int mas_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int dtype, long long n, void* stream);
+/* mas_gelu_tanh_bwd_colsum (ABI v9): mas_gelu_tanh_bwd over a [rows][cols] tensor that ALSO returns dx_colsum[cols] (fp32) = the column sums of
+ *   the dx it writes (as stored; fixed summation order): the bias gradient of the Linear layer that produced x (`lin1`, reference
+ *   models/transformer.py:125,129: grad_bias = grad_output.sum(0) with grad_output = this dx), otherwise a mas_colsum pass over dx.
+ *   cols % 8 == 0 (bf16) / % 4 (fp32); workspace: mas_gelu_tanh_bwd_colsum_workspace bytes (0 = shape not supported), caller-owned.                */
+size_t mas_gelu_tanh_bwd_colsum_workspace(int dtype, int cols);
+int mas_gelu_tanh_bwd_colsum(const void* x, const void* dy, void* dx, float* dx_colsum, int dtype, long long rows, int cols, void* workspace,
+                             size_t workspace_bytes, void* stream);
 int mas_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y,
                       float* mean_rstd, int in_dtype, int out_dtype, int rows, int D, float eps, void* stream);
 size_t mas_layernorm_bwd_workspace(int rows, int D);

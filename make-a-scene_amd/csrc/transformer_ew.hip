@@ -103,6 +103,37 @@ __global__ __launch_bounds__(NT) void gelu_bwd_kernel(const T* __restrict__ x, c
     }
 }
 
+// gelu_bwd that ALSO leaves the column sums of the dx it writes (round 6): dx is the grad_output of the Linear that produced x (`lin1`,
+// reference models/transformer.py:125,129), whose bias gradient is grad_output.sum(0) -- otherwise a mas_colsum pass over the 100 MB tensor.
+// The grid-stride step (gridDim * NT * N elements) is a multiple of the row length, so a thread meets the SAME N columns in every
+// iteration and keeps their sums in registers; partial[gridDim * NT * N] viewed as [gridDim * NT * N / cols][cols] holds one value per
+// (thread, column), folded by fold_rows_kernel in a fixed order.  Sums of dx AS STORED (rounded to T), like mas_colsum's.
+template <typename T>
+__global__ __launch_bounds__(NT) void gelu_bwd_colsum_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long long n,
+                                                             float* __restrict__ partial) {
+    constexpr int N = EwVec<T>::N;
+    constexpr bool EXACT = sizeof(T) == 4;
+    auto grad = [](float a, float g) {
+        const float a2 = a * a, t = tanh_f<EXACT>(GK * a * (1.0f + GC * a2));
+        return g * (0.5f * (1.0f + t) + 0.5f * a * (1.0f - t * t) * GK * (1.0f + 3.0f * GC * a2));
+    };
+    float acc[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[e] = 0.0f;
+    const long long nv = n / N, stride = (long long)gridDim.x * NT;
+    const long long first = (long long)blockIdx.x * NT + threadIdx.x;
+    for (long long i = first; i < nv; i += stride) {
+        float v[N], g[N];
+        ld_vec<T, N>(x + i * N, v);
+        ld_vec<T, N>(dy + i * N, g);
+#pragma unroll
+        for (int e = 0; e < N; ++e) { v[e] = grad(v[e], g[e]); acc[e] += (float)(T)v[e]; }
+        st_vec<T, N>(dx + i * N, v);
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) partial[first * N + e] = acc[e];
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // LayerNorm.  One wave per row; a lane owns the same columns of every row (column = (k*64 + lane)*VEC + e for
 // k < KMAX), the row lives in registers, statistics are exact two-pass (mean, then centred sum of squares) in
@@ -472,6 +503,48 @@ extern "C" int mas_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int dt
     if (dtype == MAS_BF16) return gelu_launch<bf16_t>(true, x, dy, dx, n, s);
     if (dtype == MAS_F32) return gelu_launch<float>(true, x, dy, dx, n, s);
     MAS_FAIL(MAS_EUNSUPPORTED, "gelu_tanh_bwd: dtype %d", dtype);
+}
+
+namespace {
+// grid of gelu_bwd_colsum: gridDim * NT * N must be a multiple of cols; ~4 work-groups per CU (the per-thread sums make the partial table
+// gridDim * NT * N floats: 8 MB at 1024 work-groups of bf16)
+int gelu_cs_grid(int cols, int vec) {
+    const long long per_block = (long long)NT * vec;
+    long long a = cols, b = per_block;
+    while (b) { const long long t = a % b; a = b; b = t; }
+    const long long unit = cols / a;                                   // smallest block count whose elements are whole rows
+    long long want = 4LL * mas_num_cus();
+    long long g = want / unit * unit;
+    if (g < unit) g = unit;
+    return g > 65535 ? 0 : (int)g;
+}
+}  // namespace
+
+extern "C" size_t mas_gelu_tanh_bwd_colsum_workspace(int dtype, int cols) {
+    const int vec = dtype == MAS_BF16 ? 8 : 4;
+    if (cols <= 0 || cols % vec) return 0;
+    const int g = gelu_cs_grid(cols, vec);
+    return g ? (size_t)g * NT * vec * sizeof(float) : 0;
+}
+
+extern "C" int mas_gelu_tanh_bwd_colsum(const void* x, const void* dy, void* dx, float* dx_colsum, int dtype, long long rows, int cols, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    MAS_ENTER();
+    if (!x || !dy || !dx || !dx_colsum || !workspace || rows <= 0 || cols <= 0) MAS_FAIL(MAS_EINVAL, "gelu_tanh_bwd_colsum: null argument or bad shape");
+    if (dtype != MAS_BF16 && dtype != MAS_F32) MAS_FAIL(MAS_EUNSUPPORTED, "gelu_tanh_bwd_colsum: dtype %d", dtype);
+    const int vec = dtype == MAS_BF16 ? 8 : 4;
+    if (cols % vec) MAS_FAIL(MAS_EUNSUPPORTED, "gelu_tanh_bwd_colsum: cols=%d must be a multiple of %d", cols, vec);
+    const int g = gelu_cs_grid(cols, vec);
+    if (!g || workspace_bytes < mas_gelu_tanh_bwd_colsum_workspace(dtype, cols)) MAS_FAIL(MAS_EINVAL, "gelu_tanh_bwd_colsum: workspace too small");
+    const long long n = rows * cols, slots = (long long)g * NT;       // (threads past the tensor's end write zero sums)
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* partial = reinterpret_cast<float*>(workspace);
+    if (dtype == MAS_BF16) hipLaunchKernelGGL(gelu_bwd_colsum_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n, partial);
+    else hipLaunchKernelGGL(gelu_bwd_colsum_kernel<float>, dim3(g), dim3(NT), 0, s, (const float*)x, (const float*)dy, (float*)dx, n, partial);
+    const int nrow = (int)(slots * vec / cols);                        // the partial table as [nrow][cols]
+    hipLaunchKernelGGL(fold_rows_kernel, dim3(mas_cdiv(cols, 32), 1), dim3(NT), 0, s, partial, nrow, cols, (long long)cols, 0LL, dx_colsum, dx_colsum, dx_colsum);
+    MAS_CHECK_LAUNCH("gelu_tanh_bwd_colsum");
+    return MAS_OK;
 }
 
 extern "C" int mas_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y,

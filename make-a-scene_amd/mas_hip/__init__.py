@@ -101,6 +101,8 @@ _SIGNATURES = {
     "mas_space_to_depth2x": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "mas_gelu_tanh_fwd": (_i, [_p, _p, _i, C.c_longlong, _p]),
     "mas_gelu_tanh_bwd": (_i, [_p, _p, _p, _i, C.c_longlong, _p]),
+    "mas_gelu_tanh_bwd_colsum_workspace": (_sz, [_i, _i]),
+    "mas_gelu_tanh_bwd_colsum": (_i, [_p, _p, _p, _p, _i, C.c_longlong, _i, _p, _sz, _p]),
     "mas_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "mas_layernorm_bwd_workspace": (_sz, [_i, _i]),
     "mas_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),

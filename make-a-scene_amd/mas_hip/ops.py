@@ -1283,17 +1283,23 @@ def _check_dtype(t: torch.Tensor, what: str):
         raise RuntimeError(f"{what}: dtype {t.dtype} not supported (float32 / bfloat16)")
 
 
+_GELU_COLSUM = os.environ.get("MAS_GELU_COLSUM", "1") == "1"
+
+
 class _GeluTanh(torch.autograd.Function):
-    """OpenAI tanh-GELU (reference models/transformer.py:11-14), one streaming pass each way."""
+    """OpenAI tanh-GELU (reference models/transformer.py:11-14), one streaming pass each way.  When x is what a ``_LinearBf16`` node
+    returned (``lin1`` of the MLP, :125,129) the backward pass also sums the dx it writes over the rows and leaves the result for that
+    layer's bias gradient (``mas_gelu_tanh_bwd_colsum`` + ``_ColsumHint``, as the sandwich LayerNorms do for ``out_proj`` / ``lin2``)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, want_colsum=False):
         _require_cuda(x, "gelu_tanh")
         _check_dtype(x, "gelu_tanh")
         x = x.contiguous()
         y = torch.empty_like(x)
         check(lib().mas_gelu_tanh_fwd(_ptr(x), _ptr(y), _DT[x.dtype], x.numel(), _stream()), "gelu_tanh_fwd")
         ctx.save_for_backward(x)
+        ctx.want_colsum = bool(want_colsum)
         return y
 
     @staticmethod
@@ -1301,12 +1307,23 @@ class _GeluTanh(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         dy = dy.to(x.dtype).contiguous()
         dx = torch.empty_like(x)
-        check(lib().mas_gelu_tanh_bwd(_ptr(x), _ptr(dy), _ptr(dx), _DT[x.dtype], x.numel(), _stream()), "gelu_tanh_bwd")
-        return dx
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        wsb = lib().mas_gelu_tanh_bwd_colsum_workspace(_DT[x.dtype], cols) if ctx.want_colsum else 0
+        if wsb:
+            dc = torch.empty(cols, dtype=torch.float32, device=x.device)
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
+            check(lib().mas_gelu_tanh_bwd_colsum(_ptr(x), _ptr(dy), _ptr(dx), _ptr(dc), _DT[x.dtype], rows, cols, _ptr(ws), wsb, _stream()),
+                  "gelu_tanh_bwd_colsum")
+            _colsum_hint.put(dx, dc)
+        else:
+            check(lib().mas_gelu_tanh_bwd(_ptr(x), _ptr(dy), _ptr(dx), _DT[x.dtype], x.numel(), _stream()), "gelu_tanh_bwd")
+        return dx, None
 
 
 def gelu_tanh(x: torch.Tensor) -> torch.Tensor:
-    return _GeluTanh.apply(x)
+    want = _GELU_COLSUM and x.dim() >= 2 and x.grad_fn is not None and type(x.grad_fn).__name__.startswith("_LinearBf16")
+    return _GeluTanh.apply(x, want)
 
 
 class _LayerNorm(torch.autograd.Function):

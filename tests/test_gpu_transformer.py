@@ -502,3 +502,53 @@ def test_layer_norm_pair_equals_the_two_separate_launches(mode, rows, d):
         yr = F.layer_norm(xr, (d,), ln2.weight, ln2.bias, 1e-5)
     tol = 2e-5 if mode == "fp32" else 2e-2
     assert rel(x_p, xr) < tol and rel(y_p.float(), yr) < tol
+
+
+@pytest.mark.parametrize("rows,cols", [(12288, 4096), (300, 4096), (96, 3072), (64, 640), (5, 64)])
+def test_gelu_backward_leaves_the_linear_bias_gradient(rows, cols):
+    """Linear -> tanh-GELU (the MLP's lin1, reference transformer.py:125,129): the GELU backward kernel also sums the dx it writes
+    (``mas_gelu_tanh_bwd_colsum``) and the Linear takes its bias gradient from there -- one hit of the hand-off, dx and every other gradient
+    bit for bit those of the plain kernel + ``mas_colsum``, the bias gradient equal to summation order; and the raw entry point against an
+    fp64 column sum of the dx it wrote."""
+    from mas_hip import ops
+    from models.transformer import Linear
+    torch.manual_seed(rows + cols)
+    lin = Linear(64, cols).cuda()
+    x = torch.randn(rows, 64, device="cuda")
+    gy = torch.randn(rows, cols, device="cuda")
+
+    def run(on):
+        old, ops._GELU_COLSUM = ops._GELU_COLSUM, on
+        try:
+            for p in lin.parameters():
+                p.grad = None
+            xi = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = ops.gelu_tanh(lin(xi))
+            h0 = ops._colsum_hint.hits
+            (y.float() * gy).sum().backward()
+            return y.detach(), xi.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone(), ops._colsum_hint.hits - h0
+        finally:
+            ops._GELU_COLSUM = old
+    y1, gx1, gw1, gb1, hits1 = run(True)
+    y0, gx0, gw0, gb0, hits0 = run(False)
+    assert hits1 == 1 and hits0 == 0
+    assert torch.equal(y1, y0) and torch.equal(gx1, gx0) and torch.equal(gw1, gw0)
+    rel = lambda a, c: float((a.double() - c.double()).norm() / (c.double().norm() + 1e-30))
+    assert rel(gb1, gb0) < 2e-6, rel(gb1, gb0)
+    # the raw entry point
+    L = ops.lib()
+    a = torch.randn(rows, cols, device="cuda").bfloat16()
+    g = torch.randn(rows, cols, device="cuda").bfloat16()
+    dx, dx_ref = torch.empty_like(a), torch.empty_like(a)
+    dc = torch.empty(cols, dtype=torch.float32, device="cuda")
+    wsb = L.mas_gelu_tanh_bwd_colsum_workspace(ops._DT[a.dtype], cols)
+    assert wsb > 0
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device="cuda")
+    ops.check(L.mas_gelu_tanh_bwd_colsum(a.data_ptr(), g.data_ptr(), dx.data_ptr(), dc.data_ptr(), ops._DT[a.dtype], rows, cols, ws.data_ptr(), wsb,
+                                         ops._stream()), "gelu bwd colsum")
+    ops.check(L.mas_gelu_tanh_bwd(a.data_ptr(), g.data_ptr(), dx_ref.data_ptr(), ops._DT[a.dtype], a.numel(), ops._stream()), "gelu bwd")
+    assert torch.equal(dx, dx_ref)
+    ref = dx.double().sum(0)
+    scale = dx.double().abs().sum(0) + 1e-30
+    assert float(((dc.double() - ref).abs() / scale).max()) < 1e-6
