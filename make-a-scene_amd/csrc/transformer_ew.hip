@@ -80,46 +80,23 @@ __global__ __launch_bounds__(NT) void gelu_fwd_kernel(const T* __restrict__ x, T
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(NT) void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long long n) {
+// CS: ALSO leave the column sums of the dx written (round 6): dx is the grad_output of the Linear that produced x (`lin1`, reference
+// models/transformer.py:125,129), whose bias gradient is grad_output.sum(0) -- otherwise a mas_colsum pass over the 100 MB tensor.  The
+// grid-stride step (gridDim * NT * N elements) is then a multiple of the row length, so a thread meets the SAME N columns in every iteration
+// and keeps their sums in registers; partial[gridDim * NT * N] viewed as [gridDim * NT * N / cols][cols] holds one value per (thread, column),
+// folded by fold_rows_kernel in a fixed order.  Sums of dx AS STORED (rounded to T), like mas_colsum's.  One template for both forms.
+template <typename T, bool CS>
+__global__ __launch_bounds__(NT) void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long long n,
+                                                      float* __restrict__ partial) {
     constexpr int N = EwVec<T>::N;
     constexpr bool EXACT = sizeof(T) == 4;
     auto grad = [](float a, float g) {
         const float a2 = a * a, t = tanh_f<EXACT>(GK * a * (1.0f + GC * a2));
         return g * (0.5f * (1.0f + t) + 0.5f * a * (1.0f - t * t) * GK * (1.0f + 3.0f * GC * a2));
     };
-    const long long nv = n / N, stride = (long long)gridDim.x * NT;
-    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < nv; i += stride) {
-        float v[N], g[N];
-        ld_vec<T, N>(x + i * N, v);
-        ld_vec<T, N>(dy + i * N, g);
+    float acc[CS ? N : 1];
 #pragma unroll
-        for (int e = 0; e < N; ++e) v[e] = grad(v[e], g[e]);
-        st_vec<T, N>(dx + i * N, v);
-    }
-    if (blockIdx.x == 0 && (int)threadIdx.x < (int)(n - nv * N)) {
-        const long long i = nv * N + threadIdx.x;
-        dx[i] = (T)grad((float)x[i], (float)dy[i]);
-    }
-}
-
-// gelu_bwd that ALSO leaves the column sums of the dx it writes (round 6): dx is the grad_output of the Linear that produced x (`lin1`,
-// reference models/transformer.py:125,129), whose bias gradient is grad_output.sum(0) -- otherwise a mas_colsum pass over the 100 MB tensor.
-// The grid-stride step (gridDim * NT * N elements) is a multiple of the row length, so a thread meets the SAME N columns in every
-// iteration and keeps their sums in registers; partial[gridDim * NT * N] viewed as [gridDim * NT * N / cols][cols] holds one value per
-// (thread, column), folded by fold_rows_kernel in a fixed order.  Sums of dx AS STORED (rounded to T), like mas_colsum's.
-template <typename T>
-__global__ __launch_bounds__(NT) void gelu_bwd_colsum_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long long n,
-                                                             float* __restrict__ partial) {
-    constexpr int N = EwVec<T>::N;
-    constexpr bool EXACT = sizeof(T) == 4;
-    auto grad = [](float a, float g) {
-        const float a2 = a * a, t = tanh_f<EXACT>(GK * a * (1.0f + GC * a2));
-        return g * (0.5f * (1.0f + t) + 0.5f * a * (1.0f - t * t) * GK * (1.0f + 3.0f * GC * a2));
-    };
-    float acc[N];
-#pragma unroll
-    for (int e = 0; e < N; ++e) acc[e] = 0.0f;
+    for (int e = 0; e < (CS ? N : 1); ++e) acc[e] = 0.0f;
     const long long nv = n / N, stride = (long long)gridDim.x * NT;
     const long long first = (long long)blockIdx.x * NT + threadIdx.x;
     for (long long i = first; i < nv; i += stride) {
@@ -127,11 +104,20 @@ __global__ __launch_bounds__(NT) void gelu_bwd_colsum_kernel(const T* __restrict
         ld_vec<T, N>(x + i * N, v);
         ld_vec<T, N>(dy + i * N, g);
 #pragma unroll
-        for (int e = 0; e < N; ++e) { v[e] = grad(v[e], g[e]); acc[e] += (float)(T)v[e]; }
+        for (int e = 0; e < N; ++e) v[e] = grad(v[e], g[e]);
+        if constexpr (CS) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) acc[e] += (float)(T)v[e];
+        }
         st_vec<T, N>(dx + i * N, v);
     }
+    if constexpr (CS) {
 #pragma unroll
-    for (int e = 0; e < N; ++e) partial[first * N + e] = acc[e];
+        for (int e = 0; e < N; ++e) partial[first * N + e] = acc[e];
+    } else if (blockIdx.x == 0 && (int)threadIdx.x < (int)(n - nv * N)) {
+        const long long i = nv * N + threadIdx.x;
+        dx[i] = (T)grad((float)x[i], (float)dy[i]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -469,7 +455,7 @@ int gelu_launch(bool bwd, const void* x, const void* dy, void* out, long long n,
     const long long cap = 16LL * mas_num_cus();
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
-    if (bwd) hipLaunchKernelGGL(gelu_bwd_kernel<T>, dim3((unsigned)nb), dim3(NT), 0, s, (const T*)x, (const T*)dy, (T*)out, n);
+    if (bwd) hipLaunchKernelGGL((gelu_bwd_kernel<T, false>), dim3((unsigned)nb), dim3(NT), 0, s, (const T*)x, (const T*)dy, (T*)out, n, (float*)nullptr);
     else hipLaunchKernelGGL(gelu_fwd_kernel<T>, dim3((unsigned)nb), dim3(NT), 0, s, (const T*)x, (T*)out, n);
     MAS_CHECK_LAUNCH(bwd ? "gelu_tanh_bwd" : "gelu_tanh_fwd");
     return MAS_OK;
@@ -539,8 +525,8 @@ extern "C" int mas_gelu_tanh_bwd_colsum(const void* x, const void* dy, void* dx,
     const long long n = rows * cols, slots = (long long)g * NT;       // (threads past the tensor's end write zero sums)
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* partial = reinterpret_cast<float*>(workspace);
-    if (dtype == MAS_BF16) hipLaunchKernelGGL(gelu_bwd_colsum_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n, partial);
-    else hipLaunchKernelGGL(gelu_bwd_colsum_kernel<float>, dim3(g), dim3(NT), 0, s, (const float*)x, (const float*)dy, (float*)dx, n, partial);
+    if (dtype == MAS_BF16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t, true>), dim3(g), dim3(NT), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n, partial);
+    else hipLaunchKernelGGL((gelu_bwd_kernel<float, true>), dim3(g), dim3(NT), 0, s, (const float*)x, (const float*)dy, (float*)dx, n, partial);
     const int nrow = (int)(slots * vec / cols);                        // the partial table as [nrow][cols]
     hipLaunchKernelGGL(fold_rows_kernel, dim3(mas_cdiv(cols, 32), 1), dim3(NT), 0, s, partial, nrow, cols, (long long)cols, 0LL, dx_colsum, dx_colsum, dx_colsum);
     MAS_CHECK_LAUNCH("gelu_tanh_bwd_colsum");
