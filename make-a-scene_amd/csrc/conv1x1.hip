@@ -35,6 +35,7 @@ struct PwParams {
     const unsigned char* a; const unsigned char* w; const float* bias; const unsigned char* res; unsigned char* y;
     int M, K, N;                               // pixels, input channels, output channels
     int rows_pad, n_chunks, n_nt;              // weight image: rows per chunk (Cout rounded up to 128), 64-channel chunks; cout tiles
+    int xcd_bands;                             // grid % 8 == 0 and more than one cout tile: the banded block -> tile map (see the kernel)
 };
 
 constexpr int PW_NT = 256;
@@ -49,8 +50,12 @@ __global__ __launch_bounds__(PW_NT, 2) void conv1x1_kernel(PwParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, l31 = lane & 31;
     const int wave_n = wave & 1, wave_m = wave >> 1;               // 2 x 64 couts, 2 x 64 pixels
-    // cout tile fastest: the work-groups that share a pixel tile are dispatched together (its rows come from HBM once, then L2)
-    const int nt = (int)blockIdx.x % p.n_nt, mt = (int)blockIdx.x / p.n_nt;
+    // cout tile fastest: the work-groups that share a pixel tile are adjacent in the tile list -- and, since round 6, on the SAME XCD: work-group b
+    // runs on XCD b % 8 (observed dispatch order; speed only), so with the plain b -> tile map the n_nt work-groups of a pixel tile sit on
+    // n_nt different XCDs and its rows cross the fabric once per XCD.  Banded map: XCD x takes the contiguous eighth [x G / 8, (x + 1) G / 8).
+    int tile = (int)blockIdx.x;
+    if (p.xcd_bands) tile = (tile & 7) * ((int)gridDim.x >> 3) + (tile >> 3);
+    const int nt = tile % p.n_nt, mt = tile / p.n_nt;
     const int m0 = mt * 128, n0 = nt * 128;
 
     const pw_i32x4 rs_a = pw_rsrc(p.a, (unsigned)((size_t)p.M * p.K * 2));
@@ -309,6 +314,8 @@ int mas_conv1x1_try(const MasConvDesc* d, const void* x, const void* w_packed, c
         mas_attr_done(attr, attr_bit);
     }
     const long long grid = (M + 127) / 128 * p.n_nt;
+    static const int bands = mas_env_int("MAS_CONV_XCD_BANDS", 1);
+    p.xcd_bands = (bands && p.n_nt > 1 && grid % 8 == 0) ? 1 : 0;
     hipLaunchKernelGGL(conv1x1_kernel, dim3((unsigned)grid), dim3(PW_NT), PW_LDS, s, p);
     MAS_CHECK_LAUNCH("conv1x1");
     return 1;
