@@ -32,6 +32,7 @@ struct StreamParams {
     int N, H, W, Cin, Ho, Wo, Cout;
     int Hl, Wl, pad_top, pad_left, upsample, act;
     int n_chunks, Cout_pad, tiles_h, tiles_w, n_ct;
+    int xcd_bands;                             // 1: every XCD walks its own contiguous eighth of the tile list (conv3x3_wide.hip has the reasoning)
 };
 
 constexpr int S_PWL = 18;                      // patch pitch in pixels ((16-1)+3)
@@ -254,6 +255,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
 
     // ---- prologue -----------------------------------------------------------------------------------------------------
     int tile = blockIdx.x;                      // grid <= total_tiles
+    int step = (int)gridDim.x, tile_end = total_tiles;
+    if (p.xcd_bands && (gridDim.x & 7) == 0) {  // work-group b runs on XCD b % 8: the cout tiles that share a patch (consecutive tile ids) on ONE XCD
+        const int xcd = blockIdx.x & 7;
+        step = (int)(gridDim.x >> 3);
+        tile = (int)(((long long)total_tiles * xcd) >> 3) + (int)(blockIdx.x >> 3);
+        tile_end = (int)(((long long)total_tiles * (xcd + 1)) >> 3);
+    }
     Tile cur = decode(tile);
     int vo_cur[G::NSLOT], vo_nxt[G::NSLOT];
     unsigned inb_cur, inb_nxt;
@@ -290,8 +298,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamParams p) 
     int tl_iter = 0;
 #endif
     for (;;) {
-        const int next_tile = tile + (int)gridDim.x;
-        const bool has_next = next_tile < total_tiles;
+        const int next_tile = tile + step;
+        const bool has_next = next_tile < tile_end;
         const Tile nxt = has_next ? decode(next_tile) : cur;
         STS(0);
 
@@ -514,7 +522,10 @@ int launch_stream(const StreamParams& p, hipStream_t s) {
     static const int wgs_per_cu = mas_env_int("MAS_CONV_WGS_PER_CU", 0);
     if (wgs_per_cu > 0) resident = (long long)wgs_per_cu * mas_num_cus();
     const unsigned blocks = (unsigned)(tiles < resident ? tiles : resident);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), S_LDS, s, p);
+    static const int bands = mas_env_int("MAS_CONV_XCD_BANDS", 1);
+    StreamParams pb = p;
+    pb.xcd_bands = (bands && blocks % 8 == 0 && tiles / 8 >= blocks / 8) ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), S_LDS, s, pb);
     MAS_CHECK_LAUNCH("conv3x3_stream");
     return MAS_OK;
 }
