@@ -389,10 +389,38 @@ def gn_stats_act(x: torch.Tensor, gamma, beta, groups: int, eps: float, act: int
     return mr, ss, a
 
 
+def _gn_bwd_aten(x, da, dres, groups, act, gamma, mr, ss):
+    """The same backward from ATen element-wise ops and reductions ON THE GPU, for channel counts the streaming kernels do not take (their
+    threads keep one 16-byte channel slot across the grid stride: C / 8 must divide 256 -- every width of the reference's configs does;
+    192, 320, ... do not).  Off the benched path; found by tests/test_gpu_conv_random.py (round 6).  u is rebuilt from the saved
+    scale / shift table, xhat from the saved (mean, rstd)."""
+    n, c, h, w = x.shape
+    cg = c // groups
+    xf, df = x.float(), da.float()
+    u = xf * ss[..., 0].view(n, c, 1, 1) + ss[..., 1].view(n, c, 1, 1)
+    if act == ACT_AFFINE_SILU:
+        sg = torch.sigmoid(u)
+        df = df * (sg * (1.0 + u * (1.0 - sg)))
+    mean, rstd = mr[..., 0].view(n, groups, 1, 1, 1), mr[..., 1].view(n, groups, 1, 1, 1)
+    xhat = (xf.reshape(n, groups, cg, h, w) - mean) * rstd
+    g = (df * gamma.float().view(1, c, 1, 1)).reshape(n, groups, cg, h, w)
+    m = float(cg * h * w)
+    s1, s2 = g.sum((2, 3, 4), keepdim=True) / m, (g * xhat).sum((2, 3, 4), keepdim=True) / m
+    dx = (rstd * (g - s1 - xhat * s2)).reshape(n, c, h, w)
+    if dres is not None:
+        dx = dx + dres.float()
+    dgamma = (df.reshape(n, groups, cg, h, w) * xhat).reshape(n, c, h, w).sum((0, 2, 3))
+    dbeta = df.sum((0, 2, 3))
+    return dx.to(x.dtype).contiguous(memory_format=torch.channels_last), dgamma, dbeta
+
+
 def gn_bwd(x, da, dres, groups, act, gamma, mr, ss, path=None):
     """GroupNorm(+SiLU) backward: (dx [+ dres], dgamma, dbeta).  ``path`` None: ``mas_gn_bwd`` (the small-map kernel up to 512 pixels,
-    bf16; else the three launches); "three": reduce / finalize / apply launches on any shape (``mas_gn_bwd_3pass``)."""
+    bf16; else the three launches); "three": reduce / finalize / apply launches on any shape (``mas_gn_bwd_3pass``).  Channel counts
+    outside the kernels' envelope (``_gn_act_ok``) take ``_gn_bwd_aten``."""
     n, c, h, w = x.shape
+    if not _gn_act_ok(c, x.dtype):
+        return _gn_bwd_aten(x, da, dres, groups, act, gamma, mr, ss)
     dx = torch.empty_like(x, memory_format=torch.channels_last)
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
