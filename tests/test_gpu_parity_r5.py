@@ -53,7 +53,9 @@ def _torch_resblock(x, sd):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-4), (torch.bfloat16, 4e-2)])
-@pytest.mark.parametrize("shape", [(3, 128, 256, 24, 40), (2, 256, 512, 16, 16), (4, 512, 256, 32, 32)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("shape", [(3, 128, 256, 24, 40), (2, 256, 512, 16, 16), (4, 512, 256, 32, 32),
+                                   (2, 96, 192, 20, 28), (2, 320, 160, 12, 36), (3, 64, 32, 17, 9)],    # round 6: widths outside the reference's configs
+                         ids=lambda s: "x".join(map(str, s)))
 def test_resnet_block_with_shortcut_vs_torch_fp32(shape, dtype, tol):
     from mas_hip import ops
     from models.modules import ResnetBlock
