@@ -103,11 +103,14 @@ def test_resnet_block_with_shortcut_vs_torch_fp32(shape, dtype, tol):
         if in_envelope:
             assert torch.equal(xd.grad, dx_trainable)
         else:                     # widths the streaming GroupNorm kernels do not take run that backward on ATen (ops._gn_bwd_aten): same values to rounding
-            assert _rel(xd.grad, dx_trainable) < 1e-5
+            assert _rel(xd.grad, dx_trainable) < (1e-5 if dtype == torch.float32 else 1e-3)
         # no_grad: nothing saved, same output
         with torch.no_grad():
             y2 = blk(xd)
-        assert torch.equal(y2, y.detach())
+        if in_envelope:
+            assert torch.equal(y2, y.detach())
+        else:                     # (the statistics of such widths come from a different pass under no_grad: same values to rounding)
+            assert _rel(y2, y.detach()) < (1e-5 if dtype == torch.float32 else 1e-2)
     finally:
         ops.set_compute_dtype(old)
 
