@@ -300,3 +300,50 @@ def test_codebook_warmup_schedule():
     finally:
         if own_group:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("channels,zc,ed,ne", [([32, 96, 160, 192], 48, 24, 50), ([64, 64, 320], 64, 36, 100)],
+                         ids=["32-96-160-192", "64-64-320"])
+def test_widths_outside_the_reference_configs_vs_oracle(channels, zc, ed, ne):
+    """The drop-in keeps the reference's constructor: ANY ``channels`` list GroupNorm(32, C) accepts must train, not only the 128 / 256 / 512
+    of conf/*.yaml (round 6: tests/test_gpu_conv_random.py found the GroupNorm backward rejecting C = 192 / 320).  Tiny VQBASE with widths,
+    latent and codebook sizes nobody tuned a kernel for, forward + backward, fp32 mode vs the oracle (reference models/vqvae.py:36-39)."""
+    from models import VQBASE
+    from mas_hip import ops
+    from oracle import vq_oracle as O
+    dev = _dev()
+    cfg = dict(ddconfig=dict(z_channels=zc, in_channels=3, out_channels=3, channels=channels, num_res_blocks=1, resolution=32,
+                             attn_resolutions=[8], dropout=0.0), n_embed=ne, embed_dim=ed, init_steps=3000, reservoir_size=12500)
+    sd = O.synth_state_dict(cfg["ddconfig"], ne, ed, seed=3)
+    x = O.synth_image_batch(2, 3, 32, seed=3)
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    ref, ref_q, ref_idx, ref_z = O.vqbase_forward(sdr, x, cfg["ddconfig"], training=True)
+    ((x - ref).abs().mean() + ref_q).backward()
+    old = ops.compute_dtype()
+    ops.set_compute_dtype(torch.float32)
+    try:
+        m = VQBASE(**cfg)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dev).train()
+        m.quantize.q_counter = m.quantize.q_re_end
+        got = {}
+        m.quant_conv.register_forward_hook(lambda mod, i, o: got.__setitem__("z", o.detach()))
+        m.quantize.register_forward_hook(lambda mod, i, o: got.__setitem__("q", o))
+        rec, q = m(x.to(dev))
+        ((x.to(dev) - rec).abs().mean() + q).backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_compute_dtype(old)
+    assert relerr(got["z"], ref_z.detach()) < 2e-3
+    flips = float((got["q"][2].cpu() != ref_idx).float().mean())
+    assert flips <= 0.02, flips
+    if flips == 0.0:
+        assert relerr(rec, ref.detach()) < 5e-3
+        params = dict(m.named_parameters())
+        checked = 0
+        for k, v in sdr.items():
+            if v.is_floating_point() and v.grad is not None and k in params and float(v.grad.abs().max()) > 1e-7:
+                e = float((params[k].grad.cpu() - v.grad).norm() / (v.grad.norm() + 1e-30))
+                assert e < 2e-2, (k, e)
+                checked += 1
+        assert checked > 30
