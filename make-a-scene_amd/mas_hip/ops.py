@@ -982,8 +982,22 @@ class _VQ(torch.autograd.Function):
         return dz, dcb, None
 
 
+_VQ_DIMS = (32, 64, 128, 256)
+
+
 def vq_lookup(z, codebook, beta):
-    return _VQ.apply(z, codebook, beta)
+    """``Codebook.forward``'s lookup (reference models/modules.py:501-517).  The kernel takes codebook_dim in {32, 64, 128, 256}; any other
+    width up to 256 is zero-padded to the next of those with differentiable torch ops (zero dimensions add nothing to any distance, to the
+    loss's sum of squares or to a gradient; the loss is re-normalised to the true width), so every ``embed_dim`` the reference's constructor
+    accepts up to 256 works -- found by tests/test_gpu_model.py's off-config case (round 6)."""
+    d = codebook.shape[1]
+    if d in _VQ_DIMS or d > _VQ_DIMS[-1]:
+        return _VQ.apply(z, codebook, beta)                 # (d > 256: the library's own error)
+    dp = next(v for v in _VQ_DIMS if v >= d)
+    zp = torch.nn.functional.pad(nhwc(z, torch.float32), (0, 0, 0, 0, 0, dp - d))
+    cp = torch.nn.functional.pad(codebook.float(), (0, dp - d))
+    zq, loss, idx = _VQ.apply(zp, cp, beta)
+    return zq[:, :d], loss * (dp / d), idx
 
 
 # --------------------------------------------------------------------------- #
