@@ -347,3 +347,47 @@ def test_widths_outside_the_reference_configs_vs_oracle(channels, zc, ed, ne):
                 assert e < 2e-2, (k, e)
                 checked += 1
         assert checked > 30
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-3), ("bf16", 4e-2)])
+def test_odd_input_size_batch_and_attention_placement_vs_oracle(mode, tol):
+    """Off-config geometry: a 40 x 56 input (ragged tiles at every level, 5 x 7 latent), batch 3, two ResnetBlocks per level, attention at two
+    levels -- one of them on a 20 x 28 map (560 tokens: beyond the spatial-attention kernel's 256, so the GEMM path) --, a codebook of 48
+    codes in 40 dimensions.  Forward (+ backward in fp32 mode) vs the oracle."""
+    from models import VQBASE
+    from mas_hip import ops
+    from oracle import vq_oracle as O
+    dev = _dev()
+    cfg = dict(ddconfig=dict(z_channels=40, in_channels=3, out_channels=3, channels=[32, 64, 64, 96], num_res_blocks=2, resolution=32,
+                             attn_resolutions=[16, 8], dropout=0.0), n_embed=48, embed_dim=40, init_steps=3000, reservoir_size=12500)
+    sd = O.synth_state_dict(cfg["ddconfig"], 48, 40, seed=8)
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(3, 3, 40, 56, generator=g)
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    taps = {}
+    ref, ref_q, ref_idx, ref_z = O.vqbase_forward(sdr, x, cfg["ddconfig"], training=True, taps=taps)
+    ((x - ref).abs().mean() + ref_q).backward()
+    old = ops.compute_dtype()
+    ops.set_compute_dtype(torch.float32 if mode == "fp32" else torch.bfloat16)
+    try:
+        m = VQBASE(**cfg)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dev).train()
+        m.quantize.q_counter = m.quantize.q_re_end
+        got = {}
+        m.quant_conv.register_forward_hook(lambda mod, i, o: got.__setitem__("z", o.detach()))
+        rec, q = m(x.to(dev))
+        ((x.to(dev) - rec).abs().mean() + q).backward()
+        with torch.no_grad():
+            dec = m.decode(taps["z_q"].detach().to(dev))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_compute_dtype(old)
+    assert rec.shape == ref.shape and relerr(got["z"], ref_z.detach()) < tol
+    assert relerr(dec, ref.detach()) < tol                       # decoder fed the oracle's z_q: no index flips in the way
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    if mode == "fp32":
+        params = dict(m.named_parameters())
+        k = "decoder.model.%d.weight" % (len(m.decoder.model) - 1)
+        e = float((params[k].grad.cpu() - sdr[k].grad).norm() / (sdr[k].grad.norm() + 1e-30))
+        assert e < 2e-2, e
