@@ -554,3 +554,40 @@ def test_gelu_backward_leaves_the_linear_bias_gradient(rows, cols):
     ref = dx.double().sum(0)
     scale = dx.double().abs().sum(0) + 1e-30
     assert float(((dc.double() - ref).abs() / scale).max()) < 1e-6
+
+
+@pytest.mark.parametrize("hidden,heads", [(96, 4), (192, 2), (80, 5), (100, 5)], ids=["hd24", "hd96", "hd16x5", "hd20"])
+@pytest.mark.parametrize("mode", ["fp32", "autocast"])
+def test_make_a_scene_off_config_widths_vs_oracle(hidden, heads, mode):
+    """Head dimensions / hidden sizes nobody tuned a kernel for (the reference's constructor accepts any hidden_dim divisible by the head
+    count, models/transformer.py:17-35): forward + backward of a small MakeAScene against the oracle.  Whatever the attention / LayerNorm /
+    GELU dispatch does with such widths (HIP kernel, padded kernel, ATen on the GPU), the numbers must be the reference's."""
+    from mas_hip import ops
+    from models.transformer import MakeAScene
+    from oracle import transformer_oracle as TO
+    dev = _dev()
+    cfg = dict(num_layers=2, hidden_dim=hidden, num_attn_heads=heads, image_vocab_size=70, seg_vocab_size=30, text_vocab_size=45,
+               image_tokens_per_dim=4, seg_tokens_per_dim=2, text_length=7)
+    sd = TO.synth_transformer_state_dict(cfg, seed=9)
+    text, seg, img = TO.synth_tokens(cfg, batch=3, seed=9)
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    ref = TO.make_a_scene_forward(sdr, cfg, text, seg, img)
+    ref_loss = torch.nn.functional.cross_entropy(ref.reshape(-1, ref.shape[-1]), img.reshape(-1))
+    ref_loss.backward()
+    ops.set_compute_dtype(torch.float32)
+    m = MakeAScene(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev)
+    ctx = torch.autocast("cuda", dtype=torch.bfloat16) if mode == "autocast" else contextlib.nullcontext()
+    with ctx:
+        logits = m(text.to(dev), seg.to(dev), img.to(dev))
+    loss = torch.nn.functional.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), img.to(dev).reshape(-1))
+    loss.backward()
+    torch.cuda.synchronize()
+    tol = 1e-3 if mode == "fp32" else 4e-2
+    assert relerr(logits.float(), ref.detach()) < tol
+    assert abs(float(loss) - float(ref_loss)) < (1e-4 if mode == "fp32" else 2e-2) * abs(float(ref_loss))
+    params = dict(m.named_parameters())
+    for k in ("transformer.layers.0.attn.qkv.weight", "transformer.layers.1.mlp.lin1.bias", "transformer.layers.1.first_ln_sandwich.weight",
+              "to_logits.1.weight"):
+        assert relerr(params[k].grad, sdr[k].grad) < (5e-3 if mode == "fp32" else 8e-2), k
