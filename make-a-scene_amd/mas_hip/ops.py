@@ -1248,26 +1248,31 @@ def spatial_attention(qkv: torch.Tensor, c: int) -> torch.Tensor:
 # --------------------------------------------------------------------------- #
 # causal multi-head attention (transformer path, reference models/transformer.py:44-115)
 # --------------------------------------------------------------------------- #
+_ATTN_HEAD_DIMS = (16, 32, 64, 128)
+
+
 class _CausalAttention(torch.autograd.Function):
     """context = softmax_causal((q/sqrt(hd)) k^T) v on the fused qkv projection [B,S,3*H*hd].
     Forward and backward are the flash-style HIP kernels (the [S,S] scores are never written; the backward
     recomputes them tile by tile from the saved log-sum-exp and writes d(qkv) in place, no atomics)."""
 
     @staticmethod
-    def forward(ctx, qkv, n_heads, cd):
+    def forward(ctx, qkv, n_heads, cd, scale=None):
         _require_cuda(qkv, "causal_attention")
         x = qkv.to(cd).contiguous()
         b, s, d3 = x.shape
         d = d3 // 3
         hd = d // n_heads
+        scale = float(hd) ** -0.5 if scale is None else float(scale)      # (a zero-padded head keeps the scale of its true width)
         o = torch.empty((b, s, d), dtype=cd, device=x.device)
         lse = torch.empty((b, n_heads, s), dtype=torch.float32, device=x.device)
         esz = x.element_size()
         base = x.data_ptr()
         check(lib().mas_attn_causal_fwd(C.c_void_p(base), C.c_void_p(base + d * esz), C.c_void_p(base + 2 * d * esz), _ptr(o), _ptr(lse),
-                                        _DT[cd], b, n_heads, s, hd, d3, d3, d3, s * d3, s * d3, s * d3, float(hd) ** -0.5, _stream()),
+                                        _DT[cd], b, n_heads, s, hd, d3, d3, d3, s * d3, s * d3, s * d3, scale, _stream()),
               "attn_causal_fwd")
         ctx.n_heads = n_heads
+        ctx.scale = scale
         ctx.in_dtype = qkv.dtype
         ctx.save_for_backward(x, o, lse)
         return o.to(qkv.dtype)
@@ -1282,8 +1287,8 @@ class _CausalAttention(torch.autograd.Function):
         dx = torch.empty_like(x)
         delta = torch.empty_like(lse)
         check(lib().mas_attn_causal_bwd(_ptr(x), _ptr(o), _ptr(g), _ptr(lse), _ptr(delta), _ptr(dx), _DT[x.dtype], b, h, s, hd,
-                                        float(hd) ** -0.5, _stream()), "attn_causal_bwd")
-        return dx.to(ctx.in_dtype), None, None
+                                        ctx.scale, _stream()), "attn_causal_bwd")
+        return dx.to(ctx.in_dtype), None, None, None
 
 
 def causal_attention(qkv: torch.Tensor, n_heads: int, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
@@ -1294,7 +1299,17 @@ def causal_attention(qkv: torch.Tensor, n_heads: int, dtype: Optional[torch.dtyp
         dtype = qkv.dtype
     if dtype not in _DT:
         raise RuntimeError(f"causal_attention: dtype {dtype} not supported (float32 / bfloat16)")
-    return _CausalAttention.apply(qkv, n_heads, dtype)
+    b, s, d3 = qkv.shape
+    hd = d3 // 3 // n_heads
+    if hd in _ATTN_HEAD_DIMS or hd > _ATTN_HEAD_DIMS[-1]:
+        return _CausalAttention.apply(qkv, n_heads, dtype)          # (head_dim > 128: the library's own error)
+    # any other head width (the reference's constructor takes every hidden_dim divisible by the head count, models/transformer.py:17-35): the
+    # heads are zero-padded to the next width the kernels have -- zero dimensions add nothing to a score, produce zero context columns and
+    # receive zero gradients -- with the softmax scale of the TRUE width.  Differentiable torch ops around the same node; off the benched path.
+    hp = next(v for v in _ATTN_HEAD_DIMS if v >= hd)
+    x = torch.nn.functional.pad(qkv.reshape(b, s, 3, n_heads, hd), (0, hp - hd)).reshape(b, s, 3 * n_heads * hp)
+    o = _CausalAttention.apply(x, n_heads, dtype, float(hd) ** -0.5)
+    return o.reshape(b, s, n_heads, hp)[..., :hd].reshape(b, s, n_heads * hd)
 
 
 def attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, past: int, n_heads: int) -> torch.Tensor:
@@ -1310,6 +1325,16 @@ def attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
         raise RuntimeError(f"attention_decode: cache {tuple(k_cache.shape)} does not hold past={past} + nq={nq} rows of width {d}")
     if q.stride(2) != 1 or k_cache.stride(2) != 1 or v_cache.stride(2) != 1:
         raise RuntimeError("attention_decode: the last dimension must be contiguous")
+    if hd not in _ATTN_HEAD_DIMS:
+        # head widths the decode kernel does not have (see ``causal_attention``): the same arithmetic from ATen ops on the GPU (inference only)
+        L = past + nq
+        qh = q.reshape(b, nq, n_heads, hd).transpose(1, 2).float()
+        kh = k_cache[:, :L].reshape(b, L, n_heads, hd).transpose(1, 2).float()
+        vh = v_cache[:, :L].reshape(b, L, n_heads, hd).transpose(1, 2).float()
+        sc = torch.matmul(qh, kh.transpose(-1, -2)) * (float(hd) ** -0.5)
+        allowed = torch.arange(L, device=q.device)[None, :] <= (past + torch.arange(nq, device=q.device))[:, None]
+        pr = torch.softmax(sc.masked_fill(~allowed, float("-inf")), dim=-1)
+        return torch.matmul(pr, vh).transpose(1, 2).reshape(b, nq, d).to(q.dtype)
     o = torch.empty((b, nq, d), dtype=q.dtype, device=q.device)
     check(lib().mas_attn_decode(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(o), _DT[q.dtype], b, n_heads, nq, int(past), hd,
                                 q.stride(1), k_cache.stride(1), v_cache.stride(1), o.stride(1), q.stride(0), k_cache.stride(0),

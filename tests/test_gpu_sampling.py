@@ -165,3 +165,21 @@ def test_frozen_vq_tokenisation_roundtrip(tmp_path):
         assert torch.equal(img_t, tok[2].cpu()) and torch.equal(seg_t, tok[2].cpu()) and int(text_t.sum()) == 0
     finally:
         ops.set_compute_dtype(old)
+
+
+@pytest.mark.parametrize("hidden,heads", [(96, 4), (100, 5)], ids=["hd24", "hd20"])
+def test_generate_with_off_config_head_widths(hidden, heads):
+    """round 6: head widths the attention kernels do not have (zero-padded in training / prefill, ATen in cached decoding) -- greedy tokens are
+    the argmax of the uncached forward fed with them, and cached logits equal uncached logits."""
+    from models.transformer import MakeAScene
+    dev = _dev()
+    torch.manual_seed(2)
+    m = MakeAScene(num_layers=2, hidden_dim=hidden, num_attn_heads=heads, image_vocab_size=64, seg_vocab_size=11, text_vocab_size=48,
+                   image_tokens_per_dim=4, seg_tokens_per_dim=2, text_length=8).to(dev).eval()
+    g = torch.Generator().manual_seed(3)
+    text = torch.randint(1, 40, (2, 8), generator=g).to(dev)
+    seg = torch.randint(0, 11, (2, 4), generator=g).to(dev)
+    with torch.no_grad():
+        tok = m.generate(text, seg, temperature=0)
+        assert tok.shape == (2, 16) and int(tok.max()) < 64
+        assert (m(text, seg, tok).argmax(-1) == tok).float().mean() > 0.95
