@@ -1583,13 +1583,22 @@ def layer_norm_pair(h, residual, ln1, ln2, producer_bias_grad=False):
     D % 4 == 0, D <= 1024, equal shapes -- else (and with ``MAS_LN_PAIR=0``) the two separate nodes: the same values either way."""
     y_dtype = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else residual.dtype
     d = h.shape[-1]
-    ok = (_LN_PAIR and h.is_cuda and residual.shape == h.shape and residual.dtype == torch.float32 and d % 4 == 0 and d <= 1024
+    ok = (_LN_PAIR and h.is_cuda and residual.shape == h.shape and residual.dtype == torch.float32 and d % 4 == 0 and d <= 1024 and _ln_ok(d, h.dtype, residual.dtype)
           and ((h.dtype == torch.bfloat16 and y_dtype == torch.bfloat16) or (h.dtype == torch.float32 and y_dtype == torch.float32)))
     if not ok:
         xnew = layer_norm(h, ln1.weight, ln1.bias, ln1.eps, residual, producer_bias_grad=producer_bias_grad)
         return layer_norm_fork(xnew, ln2.weight, ln2.bias, ln2.eps)
     want = bool(producer_bias_grad) and h.grad_fn is not None and type(h.grad_fn).__name__.startswith("_LinearBf16")
     return _LayerNormPair.apply(h, residual, ln1.weight, ln1.bias, ln1.eps, ln2.weight, ln2.bias, ln2.eps, y_dtype, want)
+
+
+def _ln_ok(d: int, in_dtype, out_dtype) -> bool:
+    """the LayerNorm kernels' envelope (transformer_ew.hip ln_check): a whole number of 16-byte vectors per row, at most 256 of them; other
+    widths (hidden_dim 100, say: the reference's constructor takes any) run ATen's layer_norm on the GPU -- off the benched path"""
+    if in_dtype not in _DT or out_dtype not in _DT:
+        return False
+    vec = 8 if (in_dtype == torch.bfloat16 and out_dtype == torch.bfloat16) else 4
+    return d % vec == 0 and d <= 64 * vec * 4
 
 
 def layer_norm(x, weight, bias, eps=1e-5, residual=None, out_dtype=None, producer_bias_grad=False):
@@ -1605,6 +1614,9 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None, out_dtype=None, produce
             out_dtype = x.dtype
     if out_dtype not in _DT:
         raise RuntimeError(f"layer_norm: output dtype {out_dtype} not supported")
+    if not _ln_ok(x.shape[-1], x.dtype, out_dtype):
+        y = torch.nn.functional.layer_norm(x.float(), (x.shape[-1],), weight.float(), bias.float(), eps)      # widths outside the kernels' envelope
+        return (y + residual.float() if residual is not None else y).to(out_dtype)
     # (only when x really is what a ``_LinearBf16`` node returned: any other producer -- nn.Linear outside autocast, a Dropout with
     # p > 0, a prescale -- would never take the sums, and the slot would keep dx alive for nothing)
     want = bool(producer_bias_grad) and x.grad_fn is not None and type(x.grad_fn).__name__.startswith("_LinearBf16")
@@ -1617,6 +1629,8 @@ def layer_norm_fork(x, weight, bias, eps=1e-5, out_dtype=None):
         out_dtype = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else x.dtype
     if out_dtype not in _DT:
         raise RuntimeError(f"layer_norm: output dtype {out_dtype} not supported")
+    if not _ln_ok(x.shape[-1], x.dtype, out_dtype):
+        return torch.nn.functional.layer_norm(x.float(), (x.shape[-1],), weight.float(), bias.float(), eps).to(out_dtype), x
     return _LayerNormFork.apply(x, weight, bias, eps, out_dtype)
 
 
