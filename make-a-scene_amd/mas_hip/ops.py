@@ -991,8 +991,18 @@ def vq_lookup(z, codebook, beta):
     loss's sum of squares or to a gradient; the loss is re-normalised to the true width), so every ``embed_dim`` the reference's constructor
     accepts up to 256 works -- found by tests/test_gpu_model.py's off-config case (round 6)."""
     d = codebook.shape[1]
-    if d in _VQ_DIMS or d > _VQ_DIMS[-1]:
-        return _VQ.apply(z, codebook, beta)                 # (d > 256: the library's own error)
+    if d in _VQ_DIMS:
+        return _VQ.apply(z, codebook, beta)
+    if d > _VQ_DIMS[-1]:
+        # wider than any kernel instantiation: the reference's own formula (models/modules.py:501-517) from ATen ops on the GPU
+        zp = nhwc(z, torch.float32).permute(0, 2, 3, 1)
+        zf = zp.reshape(-1, d)
+        cb = codebook.float()
+        dist = (zf * zf).sum(1, keepdim=True) + (cb * cb).sum(1) - 2.0 * zf @ cb.t()
+        idx = torch.argmin(dist, dim=1)
+        zq = torch.nn.functional.embedding(idx, cb).view(zp.shape)
+        loss = torch.mean((zq.detach() - zp) ** 2) + beta * torch.mean((zq - zp.detach()) ** 2)
+        return (zp + (zq - zp).detach()).permute(0, 3, 1, 2), loss, idx
     dp = next(v for v in _VQ_DIMS if v >= d)
     zp = torch.nn.functional.pad(nhwc(z, torch.float32), (0, 0, 0, 0, 0, dp - d))
     cp = torch.nn.functional.pad(codebook.float(), (0, dp - d))
@@ -1301,8 +1311,12 @@ def causal_attention(qkv: torch.Tensor, n_heads: int, dtype: Optional[torch.dtyp
         raise RuntimeError(f"causal_attention: dtype {dtype} not supported (float32 / bfloat16)")
     b, s, d3 = qkv.shape
     hd = d3 // 3 // n_heads
-    if hd in _ATTN_HEAD_DIMS or hd > _ATTN_HEAD_DIMS[-1]:
-        return _CausalAttention.apply(qkv, n_heads, dtype)          # (head_dim > 128: the library's own error)
+    if hd in _ATTN_HEAD_DIMS:
+        return _CausalAttention.apply(qkv, n_heads, dtype)
+    if hd > _ATTN_HEAD_DIMS[-1]:                                    # wider than any kernel instantiation: ATen's fused attention on the GPU
+        q, k, v = (t.reshape(b, s, n_heads, hd).transpose(1, 2).to(dtype) for t in qkv.split(n_heads * hd, dim=-1))
+        o = torch.nn.functional.scaled_dot_product_attention(q, k, v, is_causal=True)
+        return o.transpose(1, 2).reshape(b, s, n_heads * hd).to(qkv.dtype)
     # any other head width (the reference's constructor takes every hidden_dim divisible by the head count, models/transformer.py:17-35): the
     # heads are zero-padded to the next width the kernels have -- zero dimensions add nothing to a score, produce zero context columns and
     # receive zero gradients -- with the softmax scale of the TRUE width.  Differentiable torch ops around the same node; off the benched path.

@@ -191,6 +191,27 @@ def test_vq_lookup_at_the_benched_size_vs_reference_golden(golden_dir):
     assert relerr(zq[::8, ::16], torch.from_numpy(g["zq_sub"])) < 1e-6
 
 
+@pytest.mark.parametrize("k,d", [(50, 24), (100, 36), (129, 200), (64, 320)], ids=["d24", "d36", "d200", "d320"])
+def test_vq_lookup_off_config_widths_vs_oracle(k, d):
+    """codebook widths without a kernel instantiation (round 6): zero-padded to the next of {32, 64, 128, 256}, ATen beyond 256 -- indices,
+    z_q, loss and both gradients against the oracle's Codebook.forward (reference models/modules.py:501-517)."""
+    from mas_hip import ops
+    from oracle import vq_oracle as O
+    dev = _dev()
+    rs = np.random.RandomState(k + d)
+    z, cb = _rand(rs, 3, d, 5, 4), _rand(rs, k, d)
+    zr, cr = z.clone().requires_grad_(True), cb.clone().requires_grad_(True)
+    zq_r, loss_r, idx_r = O.codebook_forward(cr, zr)
+    gz = _rand(rs, *zq_r.shape)
+    (zq_r * gz).sum().add(2.0 * loss_r).backward()
+    zg, cg = z.clone().to(dev).requires_grad_(True), cb.clone().to(dev).requires_grad_(True)
+    zq, loss, idx = ops.vq_lookup(zg, cg, 0.25)
+    ((zq * gz.to(dev)).sum() + 2.0 * loss).backward()
+    assert np.array_equal(idx.cpu().numpy(), idx_r.numpy())
+    assert zq.shape == zq_r.shape and relerr(zq, zq_r) < 1e-6 and abs(float(loss) - float(loss_r)) < 1e-5 * abs(float(loss_r))
+    assert relerr(zg.grad, zr.grad) < 1e-5 and relerr(cg.grad, cr.grad) < 1e-5
+
+
 def test_vq_backward_matches_oracle():
     from mas_hip import ops
     from oracle import vq_oracle as O

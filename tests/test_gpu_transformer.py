@@ -556,7 +556,7 @@ def test_gelu_backward_leaves_the_linear_bias_gradient(rows, cols):
     assert float(((dc.double() - ref).abs() / scale).max()) < 1e-6
 
 
-@pytest.mark.parametrize("hidden,heads", [(96, 4), (192, 2), (80, 5), (100, 5)], ids=["hd24", "hd96", "hd16x5", "hd20"])
+@pytest.mark.parametrize("hidden,heads", [(96, 4), (192, 2), (80, 5), (100, 5), (320, 2)], ids=["hd24", "hd96", "hd16x5", "hd20", "hd160"])
 @pytest.mark.parametrize("mode", ["fp32", "autocast"])
 def test_make_a_scene_off_config_widths_vs_oracle(hidden, heads, mode):
     """Head dimensions / hidden sizes nobody tuned a kernel for (the reference's constructor accepts any hidden_dim divisible by the head
