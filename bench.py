@@ -21,6 +21,10 @@ Rank 0 prints ONE JSON line; besides the driver's contract it carries
                   MFMA peak (vq: the 3x3 128->128 conv at 256^2, fwd + dgrad launches, per loader population and launch-weighted
                   -- in training every launch is prologue-free since round 3; transformer / e2e: the causal-attention forward
                   kernel); "mfma_only_floor_ms": the same kernel with everything but MFMAs and LDS reads compiled out (committed);
+                  "traffic" / "traffic_over_algorithmic": fabric-side bytes per launch of that kernel INSIDE the step, and
+                  "step_traffic_bytes" / "step_traffic_over_algorithmic" / "step_traffic_groupnorm_share": what a whole step moves -- both from the
+                  committed rocprofv3 --pmc passes over this very command (tools/step_traffic.sh -> profiles/r06_step_traffic.json; a
+                  profiled run cannot also be the timed one);
   "cpu_baseline": the reference itself where a checkout exists (MAS_REFERENCE_ROOT or /root/reference: kind "reference"), else the CPU
                   oracle (oracle/vq_oracle.py, a port of the reference's arithmetic: kind "port" -- the GPU box has no checkout), timed
                   on this host's cores on a bounded sample (rank 0, N=1, vq workload only);

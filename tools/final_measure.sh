@@ -50,3 +50,5 @@ python tools/rocprof_summary.py $(find /tmp/pf_vq -name "*.db" | head -1) $O/ker
 python tools/rocprof_summary.py $(find /tmp/pf_tr -name "*.db" | head -1) $O/kernel_trace_transformer.txt > /dev/null
 python tools/rocprof_summary.py $(find /tmp/pf_enc -name "*.db" | head -1) $O/kernel_trace_encoder_fwd.txt > /dev/null
 tail -2 $O/pytest_gpu.txt; tail -1 $O/smoke.txt; cut -c1-300 $O/bench.json; cut -c1-300 $O/bench_transformer.json; head -12 $O/kbench.txt
+# what whole steps move across the fabric (rocprofv3 --pmc, own passes): copy traffic/.. summary + json to profiles/ if the tree changed the kernels
+bash tools/step_traffic.sh gpurun_out/final/traffic 3 2 > $O/step_traffic_run.txt 2>&1; python3 tools/step_traffic.py gpurun_out/final/traffic 3 2 --json $O/step_traffic.json > $O/step_traffic.txt; grep "TOTAL per step, every" $O/step_traffic.txt
