@@ -686,6 +686,35 @@ def zero_stuff2x(x, hout, wout):
 # --------------------------------------------------------------------------- #
 # fused [GroupNorm (+SiLU)] -> conv (+bias, +residual)
 # --------------------------------------------------------------------------- #
+# Weight gradients on a SECOND stream (MAS_WGRAD_STREAM=1, round-6 experiment; default off).  The convolution kernels run into the package
+# power cap while the GroupNorm passes that follow each data gradient stay 13 % under it (profiles/r05_energy_budget.txt); a layer's weight
+# gradient depends on nothing the GroupNorm backward produces, so it can run BESIDE that pass instead of in front of the data gradient: launched
+# on the side stream right after the data gradient has been issued (ordered behind it), joined before the autograd node returns -- every
+# tensor crosses streams inside one node only, so the caching allocator needs no record_stream.  No CU masks (round 3's masked form lost).
+_WGRAD_STREAM = os.environ.get("MAS_WGRAD_STREAM", "0") == "1"
+_side_streams = {}
+
+
+def _side_stream():
+    dev = torch.cuda.current_device()
+    s = _side_streams.get(dev)
+    if s is None:
+        s = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
+def _on_side_stream(fn):
+    """fn()'s launches go to the side stream, ordered behind everything issued on the current stream so far"""
+    side = _side_stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        return fn()
+
+
+def _join_side_stream():
+    torch.cuda.current_stream().wait_stream(_side_stream())
+
+
 class _NormActConv(torch.autograd.Function):
     """y = conv(act(gn(x)), W) + b (+ residual).   act in {none, affine, affine+silu}.
 
@@ -758,11 +787,16 @@ class _NormActConv(torch.autograd.Function):
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         need_gn = act != ACT_NONE and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
         dx = dw = db = dgw = dgb = None
-        if need_w or need_b:
+
+        def wgrad():
             if a is not None:          # the forward left the activated input: prologue-free weight gradient
-                dw, db = conv_wgrad_raw(a, None, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ACT_NONE, ups, need_b)
-            else:
-                dw, db = conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, need_b)
+                return conv_wgrad_raw(a, None, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ACT_NONE, ups, need_b)
+            return conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, need_b)
+
+        # (MAS_WGRAD_STREAM: beside the GroupNorm backward, behind the data gradient -- see _on_side_stream)
+        defer = _WGRAD_STREAM and (need_w or need_b) and act != ACT_NONE and (need_x or need_gn) and dy.is_cuda
+        if (need_w or need_b) and not defer:
+            dw, db = wgrad()
             dw = dw.to(weight.dtype) if need_w else None
         if need_x or need_gn:
             wt = ConvWeight(weight, True, ctx.w_sources)
@@ -805,11 +839,16 @@ class _NormActConv(torch.autograd.Function):
                 da = conv_fwd_raw(d_in, None, wt, None, None, n, hd, wd, cout, hl, wl, cin, ks, 1, ks - 1 - pt, ks - 1 - pl, ACT_NONE, False, cd)
                 if ups:
                     da = sumpool2x(da)
+            if defer:
+                dw, db = _on_side_stream(wgrad)
             if act != ACT_NONE:
                 dx, dgw, dgb = gn_bwd(x, da, None, cfg["groups"], act, gn_w.detach().float(), mr, ss)
                 dgw, dgb = dgw.to(gn_w.dtype), dgb.to(gn_w.dtype)
             else:
                 dx = da
+            if defer:
+                _join_side_stream()
+                dw = dw.to(weight.dtype) if need_w else None
         dres = dy if ctx.has_res and ctx.needs_input_grad[5] else None
         return dx, dw, (db.to(weight.dtype) if db is not None else None), dgw, dgb, dres, None, None, None
 
@@ -908,10 +947,13 @@ class _ResBlock(torch.autograd.Function):
                 conv_wgrad_raw(x, ss1, dh_, *geo1, ACT_AFFINE_SILU, False, True)
 
         need_x = ng[0] or ng[1] or ng[2]
+        side = _WGRAD_STREAM and dy.is_cuda           # weight gradients beside the GroupNorm backward passes (see _on_side_stream)
         # conv2 / norm2
-        if ng[7] or ng[8]:       # (a2 / a1: the activated inputs the forward left behind -> prologue-free weight gradients)
+        if (ng[7] or ng[8]) and not side:       # (a2 / a1: the activated inputs the forward left behind -> prologue-free weight gradients)
             dw2, db2 = wgrad2()
         da2 = conv_fwd_raw(dy, None, ConvWeight(c2w, True), None, None, *geo2, ACT_NONE, False, cd)
+        if (ng[7] or ng[8]) and side:
+            dw2, db2 = _on_side_stream(wgrad2)
         dh, dg2w, dg2b = gn_bwd(hh, da2, None, groups, ACT_AFFINE_SILU, n2w.detach().float(), mr2, ss2)
         # the skip path's parameter gradients and its gradient with respect to x
         dskip = dy
@@ -921,11 +963,15 @@ class _ResBlock(torch.autograd.Function):
             if need_x:
                 dskip = conv_fwd_raw(dy, None, ConvWeight(sw, True), None, None, n, h, w, co, h, w, c, 1, 1, 0, 0, ACT_NONE, False, cd)
         # conv1 / norm1 (+ the skip connection's gradient, fused into the GroupNorm-backward apply pass)
-        if ng[3] or ng[4]:
-            dw1, db1 = wgrad1(dh)
+        if (ng[3] or ng[4]) and not (side and need_x):
+            dw1, db1 = wgrad1(dh) if not side else _on_side_stream(lambda: wgrad1(dh))
         if need_x:
             da1 = conv_fwd_raw(dh, None, ConvWeight(c1w, True), None, None, *geo1t, ACT_NONE, False, cd)
+            if (ng[3] or ng[4]) and side:
+                dw1, db1 = _on_side_stream(lambda: wgrad1(dh))
             dx, dg1w, dg1b = gn_bwd(x, da1, dskip, groups, ACT_AFFINE_SILU, n1w.detach().float(), mr1, ss1)
+        if side:
+            _join_side_stream()
         cast = lambda g, ref: g.to(ref.dtype) if g is not None else None
         return (dx, cast(dg1w, n1w), cast(dg1b, n1w), cast(dw1, c1w), cast(db1, c1w), cast(dg2w, n2w), cast(dg2b, n2w),
                 cast(dw2, c2w), cast(db2, c2w), cast(dsw, sw) if sw is not None else None, cast(dsb, sw) if sw is not None else None,
