@@ -16,7 +16,7 @@ def main():
     cols = [r[1] for r in cur.execute(f"pragma table_info({kd})")]
     q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
     rows = cur.execute(f"select d.start, d.end, s.kernel_name, d.{q} from {kd} d join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
-    adam = [i for i, r in enumerate(rows) if "FusedAdam" in r[2]]
+    adam = [i for i, r in enumerate(rows) if "FusedAdam" in r[2] or "adam_multi" in r[2]]
     ends = [adam[i] for i in range(len(adam)) if i + 1 == len(adam) or adam[i + 1] - adam[i] > 50]
     a, b = ends[-2] + 1, ends[-1] + 1
     win = rows[a:b]
