@@ -691,9 +691,7 @@ def zero_stuff2x(x, hout, wout):
 # gradient depends on nothing the GroupNorm backward produces, so it can run BESIDE that pass instead of in front of the data gradient: launched
 # on the side stream right after the data gradient has been issued (ordered behind it), joined before the autograd node returns -- every
 # tensor crosses streams inside one node only, so the caching allocator needs no record_stream.  No CU masks (round 3's masked form lost).
-_WGRAD_STREAM_MODE = int(os.environ.get("MAS_WGRAD_STREAM", "0"))      # 1: weight gradients on the side stream; 2: the GroupNorm backward on a HIGH-priority side stream
-_WGRAD_STREAM = _WGRAD_STREAM_MODE == 1
-_GN_STREAM = _WGRAD_STREAM_MODE == 2
+_WGRAD_STREAM = os.environ.get("MAS_WGRAD_STREAM", "0") == "1"
 _side_streams = {}
 
 
@@ -701,7 +699,7 @@ def _side_stream():
     dev = torch.cuda.current_device()
     s = _side_streams.get(dev)
     if s is None:
-        s = _side_streams[dev] = torch.cuda.Stream(device=dev, priority=-1 if _GN_STREAM else 0)
+        s = _side_streams[dev] = torch.cuda.Stream(device=dev)
     return s
 
 
@@ -951,21 +949,12 @@ class _ResBlock(torch.autograd.Function):
         need_x = ng[0] or ng[1] or ng[2]
         side = _WGRAD_STREAM and dy.is_cuda           # weight gradients beside the GroupNorm backward passes (see _on_side_stream)
         # conv2 / norm2
-        if (ng[7] or ng[8]) and not side and not (_GN_STREAM and dy.is_cuda):       # (a2 / a1: the activated inputs the forward left behind -> prologue-free weight gradients)
+        if (ng[7] or ng[8]) and not side:       # (a2 / a1: the activated inputs the forward left behind -> prologue-free weight gradients)
             dw2, db2 = wgrad2()
         da2 = conv_fwd_raw(dy, None, ConvWeight(c2w, True), None, None, *geo2, ACT_NONE, False, cd)
         if (ng[7] or ng[8]) and side:
             dw2, db2 = _on_side_stream(wgrad2)
-        if _GN_STREAM and dy.is_cuda and (ng[7] or ng[8]):
-            # mode 2: the data gradient is issued; the weight gradient follows it on THIS stream and the GroupNorm backward runs beside it
-            # on the high-priority stream (ordered behind the data gradient)
-            _side_stream().wait_stream(torch.cuda.current_stream())
-            dw2, db2 = wgrad2()
-            with torch.cuda.stream(_side_stream()):
-                dh, dg2w, dg2b = gn_bwd(hh, da2, None, groups, ACT_AFFINE_SILU, n2w.detach().float(), mr2, ss2)
-            _join_side_stream()
-        else:
-            dh, dg2w, dg2b = gn_bwd(hh, da2, None, groups, ACT_AFFINE_SILU, n2w.detach().float(), mr2, ss2)
+        dh, dg2w, dg2b = gn_bwd(hh, da2, None, groups, ACT_AFFINE_SILU, n2w.detach().float(), mr2, ss2)
         # the skip path's parameter gradients and its gradient with respect to x
         dskip = dy
         if ctx.has_sc:
@@ -974,21 +963,13 @@ class _ResBlock(torch.autograd.Function):
             if need_x:
                 dskip = conv_fwd_raw(dy, None, ConvWeight(sw, True), None, None, n, h, w, co, h, w, c, 1, 1, 0, 0, ACT_NONE, False, cd)
         # conv1 / norm1 (+ the skip connection's gradient, fused into the GroupNorm-backward apply pass)
-        gn2 = _GN_STREAM and dy.is_cuda and need_x and (ng[3] or ng[4])
-        if (ng[3] or ng[4]) and not (side and need_x) and not gn2:
+        if (ng[3] or ng[4]) and not (side and need_x):
             dw1, db1 = wgrad1(dh) if not side else _on_side_stream(lambda: wgrad1(dh))
         if need_x:
             da1 = conv_fwd_raw(dh, None, ConvWeight(c1w, True), None, None, *geo1t, ACT_NONE, False, cd)
             if (ng[3] or ng[4]) and side:
                 dw1, db1 = _on_side_stream(lambda: wgrad1(dh))
-            if gn2:
-                _side_stream().wait_stream(torch.cuda.current_stream())
-                dw1, db1 = wgrad1(dh)
-                with torch.cuda.stream(_side_stream()):
-                    dx, dg1w, dg1b = gn_bwd(x, da1, dskip, groups, ACT_AFFINE_SILU, n1w.detach().float(), mr1, ss1)
-                _join_side_stream()
-            else:
-                dx, dg1w, dg1b = gn_bwd(x, da1, dskip, groups, ACT_AFFINE_SILU, n1w.detach().float(), mr1, ss1)
+            dx, dg1w, dg1b = gn_bwd(x, da1, dskip, groups, ACT_AFFINE_SILU, n1w.detach().float(), mr1, ss1)
         if side:
             _join_side_stream()
         cast = lambda g, ref: g.to(ref.dtype) if g is not None else None
