@@ -527,6 +527,14 @@ int launch_dma(DmaWgradParams p, hipStream_t s) {
     return MAS_OK;
 }
 
+// MAS_WGRAD_CUS=n (experiment, with MAS_WGRAD_STREAM=1): size the persistent weight-gradient grid for n CUs instead of all of them, so that the
+// kernels running beside it on the other stream find free CUs (profiles/r06_wgrad_stream.txt)
+static int wgrad_cus() {
+    static const int n = mas_env_int("MAS_WGRAD_CUS", 0);
+    const int all = mas_num_cus();
+    return (n > 0 && n < all) ? n : all;
+}
+
 }  // namespace
 
 static bool dma_setup(const MasConvDesc* d, DmaWgradParams& p) {
@@ -548,7 +556,7 @@ static bool dma_setup(const MasConvDesc* d, DmaWgradParams& p) {
     // and a grid of exactly one work-group per CU runs the displaced ones as a second FULL round; MAS_WGRAD_OVERSUB=2 (bench.py sets
     // it for N > 1) halves the work-groups so the hardware rebalances at half-round granularity, for 2x the split-K partials.
     static const int oversub = mas_env_int("MAS_WGRAD_OVERSUB", 1);
-    int nsplit = mas_cdiv(mas_num_cus() * (oversub > 0 ? oversub : 1), out_tiles);
+    int nsplit = mas_cdiv(wgrad_cus() * (oversub > 0 ? oversub : 1), out_tiles);
     if (nsplit > p.n_pt) nsplit = p.n_pt;
     if (nsplit < 1) nsplit = 1;
     p.nsplit = nsplit;
@@ -645,7 +653,7 @@ static bool up2_wgrad_setup(const MasConvDesc* d, DmaWgradParams& p) {
     p.dy_ph_px = d->Cout * 2; p.dy_ph_row = d->Wo * d->Cout * 2; p.dy_px = 2 * p.dy_ph_px; p.dy_row = 2 * p.dy_ph_row;
     p.dy_img = (unsigned)((size_t)d->Ho * d->Wo * d->Cout * 2); p.dy_bytes = (unsigned)yb;
     static const int oversub = mas_env_int("MAS_WGRAD_OVERSUB", 1);
-    int nsplit = mas_cdiv(mas_num_cus() * (oversub > 0 ? oversub : 1), p.n_co_t * p.n_ci_t * 4);      // per phase: the four phases fill the chip together
+    int nsplit = mas_cdiv(wgrad_cus() * (oversub > 0 ? oversub : 1), p.n_co_t * p.n_ci_t * 4);      // per phase: the four phases fill the chip together
     if (nsplit > p.n_pt) nsplit = p.n_pt;
     if (nsplit < 1) nsplit = 1;
     p.nsplit = nsplit;
