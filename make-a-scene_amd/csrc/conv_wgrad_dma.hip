@@ -527,11 +527,16 @@ int launch_dma(DmaWgradParams p, hipStream_t s) {
     return MAS_OK;
 }
 
-// MAS_WGRAD_CUS=n (experiment, with MAS_WGRAD_STREAM=1): size the persistent weight-gradient grid for n CUs instead of all of them, so that the
-// kernels running beside it on the other stream find free CUs (profiles/r06_wgrad_stream.txt)
+// MAS_WGRAD_CUS: how many CUs the persistent 3x3 weight-gradient grid is sized for.  0 (the library's default): all of them.  n > 0: n.
+// -1: three quarters -- what mas_hip.ops sets when it runs the weight gradient on a second stream beside the GroupNorm backward passes
+// (MAS_WGRAD_STREAM=1, the default since late round 6): with one work-group on EVERY CU (138 KB of LDS each) the 6 us finalize launch between
+// the two GroupNorm passes is not placed until the weight gradient retires and the apply pass never overlaps; with a quarter of the CUs free it
+// starts at once and the passes run beside the weight gradient: step -1.35 ms at 192 of 256 CUs (208: -0.8, 176: -1.15, 160: -1.0, 128: 0;
+// profiles/r06_wgrad_stream.txt).  Alone, a 192-CU grid is 0.6 ms per step SLOWER: the two knobs go together.
 static int wgrad_cus() {
     static const int n = mas_env_int("MAS_WGRAD_CUS", 0);
     const int all = mas_num_cus();
+    if (n == -1) return all * 3 / 4 > 0 ? all * 3 / 4 : all;
     return (n > 0 && n < all) ? n : all;
 }
 
@@ -653,7 +658,7 @@ static bool up2_wgrad_setup(const MasConvDesc* d, DmaWgradParams& p) {
     p.dy_ph_px = d->Cout * 2; p.dy_ph_row = d->Wo * d->Cout * 2; p.dy_px = 2 * p.dy_ph_px; p.dy_row = 2 * p.dy_ph_row;
     p.dy_img = (unsigned)((size_t)d->Ho * d->Wo * d->Cout * 2); p.dy_bytes = (unsigned)yb;
     static const int oversub = mas_env_int("MAS_WGRAD_OVERSUB", 1);
-    int nsplit = mas_cdiv(wgrad_cus() * (oversub > 0 ? oversub : 1), p.n_co_t * p.n_ci_t * 4);      // per phase: the four phases fill the chip together
+    int nsplit = mas_cdiv(mas_num_cus() * (oversub > 0 ? oversub : 1), p.n_co_t * p.n_ci_t * 4);      // per phase: the four phases fill the chip together
     if (nsplit > p.n_pt) nsplit = p.n_pt;
     if (nsplit < 1) nsplit = 1;
     p.nsplit = nsplit;

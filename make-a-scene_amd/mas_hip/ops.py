@@ -686,12 +686,20 @@ def zero_stuff2x(x, hout, wout):
 # --------------------------------------------------------------------------- #
 # fused [GroupNorm (+SiLU)] -> conv (+bias, +residual)
 # --------------------------------------------------------------------------- #
-# Weight gradients on a SECOND stream (MAS_WGRAD_STREAM=1, round-6 experiment; default off).  The convolution kernels run into the package
-# power cap while the GroupNorm passes that follow each data gradient stay 13 % under it (profiles/r05_energy_budget.txt); a layer's weight
-# gradient depends on nothing the GroupNorm backward produces, so it can run BESIDE that pass instead of in front of the data gradient: launched
-# on the side stream right after the data gradient has been issued (ordered behind it), joined before the autograd node returns -- every
-# tensor crosses streams inside one node only, so the caching allocator needs no record_stream.  No CU masks (round 3's masked form lost).
-_WGRAD_STREAM = os.environ.get("MAS_WGRAD_STREAM", "0") == "1"
+# Weight gradients on a SECOND stream (MAS_WGRAD_STREAM, default 1 since late round 6; 0 = everything on one stream).  The convolution
+# kernels run into the package power cap while the GroupNorm passes that follow each data gradient stay 13 % under it
+# (profiles/r05_energy_budget.txt); a layer's weight gradient depends on nothing its GroupNorm backward produces, so it can run BESIDE those
+# passes instead of in front of the data gradient: launched on the side stream right after the data gradient has been issued (ordered behind
+# it), joined before the autograd node returns -- every tensor crosses streams inside one node only, so the caching allocator needs no
+# record_stream, and whoever consumes the node's outputs (autograd, DDP / GradReducer hooks, the optimizer) sees them ordered on the
+# current stream as before.  The weight-gradient grid is sized for three quarters of the CUs in this mode (MAS_WGRAD_CUS=-1, set below
+# unless the user set it): with a persistent work-group on every CU the tiny finalize launch between the two GroupNorm passes is not placed
+# until the weight gradient retires.  Same kernels, same arithmetic; the split-K count follows the grid, so gradients differ from the
+# one-stream form in summation order only (bitwise reproducible run to run either way).  Step 52.9 -> 51.55 ms on one box
+# (profiles/r06_wgrad_stream.txt).  No CU masks (round 3's masked form lost 20 %).
+_WGRAD_STREAM = os.environ.get("MAS_WGRAD_STREAM", "1") == "1"
+if _WGRAD_STREAM:
+    os.environ.setdefault("MAS_WGRAD_CUS", "-1")          # (read once by libmas_hip.so at its first weight-gradient call)
 _side_streams = {}
 
 
