@@ -30,6 +30,7 @@ Contract: ``finish()`` follows EVERY synchronising ``backward()``.  Gradient acc
 second synchronising backward before ``finish()`` would add into a flat buffer whose all-reduce is in flight, so it
 raises instead of producing racy, unreduced gradients."""
 import contextlib
+import os
 from typing import Iterable, List, Optional
 
 import torch
@@ -58,7 +59,7 @@ class _Bucket:
 
 
 class GradReducer:
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 128 << 20,
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = int(os.environ.get("MAS_DP_BUCKET_MB", "128")) << 20,
                  process_group: Optional[dist.ProcessGroup] = None, broadcast: bool = True,
                  first_bucket_bytes: int = 8 << 20, grad_dtype: Optional[torch.dtype] = None):
         """``grad_dtype`` (off by default; ``torch.bfloat16``): the gradients cross the links in that type -- one cast launch per bucket
