@@ -700,6 +700,10 @@ def zero_stuff2x(x, hout, wout):
 _WGRAD_STREAM = os.environ.get("MAS_WGRAD_STREAM", "1") == "1"
 if _WGRAD_STREAM:
     os.environ.setdefault("MAS_WGRAD_CUS", "-1")          # (read once by libmas_hip.so at its first weight-gradient call)
+# only where the passes are long enough to be worth two event round trips on the host: the 16 x 16 maps (25 of the 61 GroupNorm-fed layers,
+# 10-40 us kernels) are host-bound already, and with Python-side gradient hooks (mas_hip.dp.GradReducer) the extra host calls cost more
+# than the overlap bought (profiles/r06_wgrad_stream.txt)
+_WGRAD_STREAM_MIN_ELEMS = int(os.environ.get("MAS_WGRAD_STREAM_MIN_ELEMS", str(1 << 23)))
 _side_streams = {}
 
 
@@ -802,7 +806,7 @@ class _NormActConv(torch.autograd.Function):
             return conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, need_b)
 
         # (MAS_WGRAD_STREAM: beside the GroupNorm backward, behind the data gradient -- see _on_side_stream)
-        defer = _WGRAD_STREAM and (need_w or need_b) and act != ACT_NONE and (need_x or need_gn) and dy.is_cuda
+        defer = _WGRAD_STREAM and (need_w or need_b) and act != ACT_NONE and (need_x or need_gn) and dy.is_cuda and x.numel() >= _WGRAD_STREAM_MIN_ELEMS
         if (need_w or need_b) and not defer:
             dw, db = wgrad()
             dw = dw.to(weight.dtype) if need_w else None
@@ -955,7 +959,7 @@ class _ResBlock(torch.autograd.Function):
                 conv_wgrad_raw(x, ss1, dh_, *geo1, ACT_AFFINE_SILU, False, True)
 
         need_x = ng[0] or ng[1] or ng[2]
-        side = _WGRAD_STREAM and dy.is_cuda           # weight gradients beside the GroupNorm backward passes (see _on_side_stream)
+        side = _WGRAD_STREAM and dy.is_cuda and x.numel() >= _WGRAD_STREAM_MIN_ELEMS           # weight gradients beside the GroupNorm backward passes (see _on_side_stream)
         # conv2 / norm2
         if (ng[7] or ng[8]) and not side:       # (a2 / a1: the activated inputs the forward left behind -> prologue-free weight gradients)
             dw2, db2 = wgrad2()
