@@ -38,6 +38,9 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL / cross-process device memory needs on this driver
+# eight HIP hardware queues instead of four: RCCL's streams otherwise leave the weight-gradient side stream on the compute stream's queue
+# (mas_hip/__init__.py sets the same default; here it is set before anything can have touched the HIP runtime)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "make-a-scene_amd"), ROOT):

@@ -534,7 +534,7 @@ int launch_dma(DmaWgradParams p, hipStream_t s) {
 // starts at once and the passes run beside the weight gradient: step -1.35 ms at 192 of 256 CUs (208: -0.8, 176: -1.15, 160: -1.0, 128: 0;
 // profiles/r06_wgrad_stream.txt).  Alone, a 192-CU grid is 0.6 ms per step SLOWER: the two knobs go together.
 static int wgrad_cus() {
-    static const int n = mas_env_int("MAS_WGRAD_CUS", 0);
+    const int n = mas_env_int("MAS_WGRAD_CUS", 0);       // read per call (one getenv): the host side drops the 3/4 grid when its side stream is refused
     const int all = mas_num_cus();
     if (n == -1) return all * 3 / 4 > 0 ? all * 3 / 4 : all;
     return (n > 0 && n < all) ? n : all;

@@ -10,7 +10,14 @@ import ctypes as C
 import os
 import threading
 
-import torch  # noqa: F401  -- must come first: PyTorch-ROCm bundles its own libamdhip64; loading ours before it leaves torch without GPUs
+# HIP gives a process four hardware queues by default and hands them to streams in creation order; RCCL's own streams take the three beside
+# the default stream's, after which ops' side stream (weight gradients beside the GroupNorm backward) lands on the default stream's queue and
+# its kernels serialise behind barrier packets: +1.7 ms per step instead of -1.2 (profiles/r06_wgrad_stream.txt).  The runtime reads this at
+# its first HIP call -- after `import torch` is early enough, after torch.cuda.is_available() is not (ops probes the streams and refuses the
+# side stream when they do not overlap).  A value the user exported wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: F401,E402  -- must come first: PyTorch-ROCm bundles its own libamdhip64; loading ours before it leaves torch without GPUs
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MAS_HIP_LIB") or os.path.join(_HERE, "libmas_hip.so")   # env override: A/B kernel experiments

@@ -698,13 +698,63 @@ def zero_stuff2x(x, hout, wout):
 # one-stream form in summation order only (bitwise reproducible run to run either way).  Step 52.9 -> 51.55 ms on one box
 # (profiles/r06_wgrad_stream.txt).  No CU masks (round 3's masked form lost 20 %).
 _WGRAD_STREAM = os.environ.get("MAS_WGRAD_STREAM", "1") == "1"
-if _WGRAD_STREAM:
-    os.environ.setdefault("MAS_WGRAD_CUS", "-1")          # (read once by libmas_hip.so at its first weight-gradient call)
-# only where the passes are long enough to be worth two event round trips on the host: the 16 x 16 maps (25 of the 61 GroupNorm-fed layers,
-# 10-40 us kernels) are host-bound already, and with Python-side gradient hooks (mas_hip.dp.GradReducer) the extra host calls cost more
-# than the overlap bought (profiles/r06_wgrad_stream.txt)
-_WGRAD_STREAM_MIN_ELEMS = int(os.environ.get("MAS_WGRAD_STREAM_MIN_ELEMS", str(1 << 23)))
+_WGRAD_CUS_IS_OURS = _WGRAD_STREAM and "MAS_WGRAD_CUS" not in os.environ
+if _WGRAD_CUS_IS_OURS:
+    os.environ["MAS_WGRAD_CUS"] = "-1"                    # (libmas_hip.so reads it at every weight-gradient call)
+# layers below this many input elements keep their weight gradient on the current stream (0: every layer.  Measured at 0 / 2^23 / 2^25 /
+# 2^26: 50.36 / 50.66 / 51.05 / 51.23 ms -- the overlap pays even at the 16 x 16 maps; profiles/r06_wgrad_stream.txt)
+_WGRAD_STREAM_MIN_ELEMS = int(os.environ.get("MAS_WGRAD_STREAM_MIN_ELEMS", "0"))
 _side_streams = {}
+_side_ok = {}
+
+
+def _streams_overlap(main, side) -> bool:
+    """One-time probe (about 1 ms): do kernels on ``side`` run BESIDE kernels on ``main``?  Not when the two streams share a HIP hardware
+    queue (GPU_MAX_HW_QUEUES, default 4, handed out in creation order -- RCCL's streams usually hold the other three by the time the first
+    backward runs; see mas_hip/__init__.py).  Two spin kernels, one per stream: overlapped they take one kernel's time, serialised two."""
+    cycles = 1_000_000
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    torch.cuda._sleep(1000)                                  # (first launches: code object load, the side stream's queue is made at first use)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(1000)
+    main.wait_stream(side)
+    ev[0].record(main)
+    torch.cuda._sleep(cycles)
+    ev[1].record(main)                                       # alone: ev0 -> ev1
+    side.wait_stream(main)
+    ev[2].record(main)
+    torch.cuda._sleep(cycles)
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(cycles)
+        ev[3].record(side)
+    ev[4].record(main)
+    main.wait_stream(side)
+    ev[3].synchronize(), ev[4].synchronize()
+    alone = ev[0].elapsed_time(ev[1])
+    both = max(ev[2].elapsed_time(ev[3]), ev[2].elapsed_time(ev[4]))
+    _streams_overlap.last = (alone, both)
+    return both < 1.6 * alone
+
+
+def _side_stream_on() -> bool:
+    """MAS_WGRAD_STREAM=1 and the side stream really runs beside the current one (probed once per device, at the first backward)"""
+    if not _WGRAD_STREAM:
+        return False
+    dev = torch.cuda.current_device()
+    ok = _side_ok.get(dev)
+    if ok is None and torch.cuda.is_current_stream_capturing():
+        return False                                           # (no probe inside a graph capture; asked again at the next eager backward)
+    if ok is None:
+        ok = _side_ok[dev] = os.environ.get("MAS_WGRAD_STREAM_PROBE", "1") != "1" or _streams_overlap(torch.cuda.current_stream(), _side_stream())
+        if not ok:
+            import warnings
+            warnings.warn("mas_hip: the weight-gradient side stream shares a HIP hardware queue with the current stream (its kernels would "
+                          "serialise: one spin kernel %.3f ms, one per stream %.3f ms): weight gradients stay on the current stream.  Export GPU_MAX_HW_QUEUES=8 (or import mas_hip before "
+                          "the first torch.cuda call) to get the overlapped schedule." % _streams_overlap.last)
+            if _WGRAD_CUS_IS_OURS:
+                os.environ["MAS_WGRAD_CUS"] = "0"           # the 3/4 grid only pays beside the GroupNorm passes
+    return ok
 
 
 def _side_stream():
@@ -806,7 +856,7 @@ class _NormActConv(torch.autograd.Function):
             return conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, act, ups, need_b)
 
         # (MAS_WGRAD_STREAM: beside the GroupNorm backward, behind the data gradient -- see _on_side_stream)
-        defer = _WGRAD_STREAM and (need_w or need_b) and act != ACT_NONE and (need_x or need_gn) and dy.is_cuda and x.numel() >= _WGRAD_STREAM_MIN_ELEMS
+        defer = (need_w or need_b) and act != ACT_NONE and (need_x or need_gn) and dy.is_cuda and x.numel() >= _WGRAD_STREAM_MIN_ELEMS and _side_stream_on()
         if (need_w or need_b) and not defer:
             dw, db = wgrad()
             dw = dw.to(weight.dtype) if need_w else None
@@ -959,7 +1009,7 @@ class _ResBlock(torch.autograd.Function):
                 conv_wgrad_raw(x, ss1, dh_, *geo1, ACT_AFFINE_SILU, False, True)
 
         need_x = ng[0] or ng[1] or ng[2]
-        side = _WGRAD_STREAM and dy.is_cuda and x.numel() >= _WGRAD_STREAM_MIN_ELEMS           # weight gradients beside the GroupNorm backward passes (see _on_side_stream)
+        side = dy.is_cuda and x.numel() >= _WGRAD_STREAM_MIN_ELEMS and _side_stream_on()           # weight gradients beside the GroupNorm backward passes (see _on_side_stream)
         # conv2 / norm2
         if (ng[7] or ng[8]) and not side:       # (a2 / a1: the activated inputs the forward left behind -> prologue-free weight gradients)
             dw2, db2 = wgrad2()
