@@ -391,3 +391,38 @@ def test_odd_input_size_batch_and_attention_placement_vs_oracle(mode, tol):
         k = "decoder.model.%d.weight" % (len(m.decoder.model) - 1)
         e = float((params[k].grad.cpu() - sdr[k].grad).norm() / (sdr[k].grad.norm() + 1e-30))
         assert e < 2e-2, e
+
+
+def test_side_stream_weight_gradient_is_the_one_stream_gradient_bit_for_bit():
+    """ops issues each layer's weight gradient on a second stream beside its GroupNorm backward (MAS_WGRAD_STREAM).  Same
+    kernels, same split-K: every parameter gradient and the input gradient must be bitwise what the one-stream order produces -- a missing
+    cross-stream dependency would show here.  Also pins the probe's contract: a bool, cached per device, and a refusal is honoured."""
+    from mas_hip import ops
+    from oracle.vq_oracle import synth_image_batch
+    dev = _dev()
+    assert isinstance(ops._streams_overlap(torch.cuda.current_stream(), ops._side_stream()), bool)
+    alone, both = ops._streams_overlap.last
+    assert alone > 0 and both >= 0.9 * alone                  # two spin kernels never finish faster than one
+    if not ops._WGRAD_STREAM:
+        pytest.skip("MAS_WGRAD_STREAM=0")
+    m = _build(IMG, 3, torch.bfloat16)
+    x = synth_image_batch(2, 3, 128, seed=4).to(dev).requires_grad_(True)
+
+    def grads(on):
+        old = dict(ops._side_ok)
+        ops._side_ok[dev.index] = on
+        try:
+            m.zero_grad(set_to_none=True)
+            x.grad = None
+            rec, q = m(x)
+            ((x - rec).abs().mean() + q).backward()
+            torch.cuda.synchronize()
+            return [x.grad.clone()] + [p.grad.clone() for p in m.parameters() if p.grad is not None]
+        finally:
+            ops._side_ok.clear()
+            ops._side_ok.update(old)
+
+    one, two, again = grads(False), grads(True), grads(True)
+    assert len(one) == len(two) > 100
+    for a, b, c in zip(one, two, again):
+        assert torch.equal(a, b) and torch.equal(b, c)
