@@ -316,7 +316,14 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_fwd_kernel(ConvParams
                 // COUNTED wait finish the weight DMA (older) and leave the NPF patch loads issued after it in flight:
                 //   stage 0: everything (p_commit just consumed the registers);  stage s: N = slots issued in stage s-1.
                 if (stage == 0 || !PREFETCH) {
-                    __syncthreads();
+                    // EXPLICIT vmcnt(0): hipcc's own __syncthreads() here is `s_waitcnt lgkmcnt(0); s_barrier` -- it counts on the
+                    // vmcnt(0) that p_commit's last patch slot waits with, and that wait sits inside the slot's exec-masked region:
+                    // a wave none of whose lanes owns the last slot (wave 3 of the 8x16 tile: slots 184..191 of 180) skips it and reaches
+                    // the barrier with its newest weight DMA still in flight -- about one launch in 700 then read a stale weight stage
+                    // (found in round 6 as a run-to-run difference of the encoder's last convolution; profiles/r06_determinism.txt)
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
                 } else {
                     constexpr int lo = 0;
                     const int npf_prev = ((stage - 1) * PPT < NPU) ? (((stage) * PPT <= NPU) ? PPT : NPU - (stage - 1) * PPT) : lo;
@@ -326,8 +333,12 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void conv_fwd_kernel(ConvParams
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                 }
-#else
+#elif defined(MAS_CONV_W_REGSTAGE)
                 __syncthreads();               // weight stage (and, at stage 0, the patch) visible
+#else
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (see above: never leave the DMA to hipcc's barrier)
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
 #endif
                 TS(4 + ch * 28 + stage * 3);
                 {
