@@ -113,8 +113,6 @@ def _param_stamp(p: torch.Tensor):
 # debugging aid for writes the stamp cannot see (``w.data.copy_(...)`` without invalidate_weight_cache()): every cache hit compares a
 # checksum of the live parameter with the one taken when its image was packed (one device sync per conv call: never on by default)
 _CACHE_CHECK = os.environ.get("MAS_WEIGHT_CACHE_CHECK", "0") == "1"
-_PACK_SIDE = os.environ.get("MAS_PACK_SIDE", "1") == "1"                 # refresh of the late-used packed weights on the side stream
-_PACK_EARLY_BYTES = int(os.environ.get("MAS_PACK_EARLY_BYTES", str(2 << 20)))
 
 
 def _checksum(w: torch.Tensor) -> float:
@@ -131,21 +129,8 @@ class _PackCache:
         self.derived = {}                            # images of tensors DERIVED from several parameters (AttnBlock's q|k|v stack)
         self.sums = {}                               # MAS_WEIGHT_CACHE_CHECK=1 only
         self._tables = {}                            # device-resident item tables of the batched pack launches
-        self._late = None                            # (event, ids of entries packed on the side stream, streams that waited): _refresh_stale
-
-    def _wait_late(self, ent=None):
-        """orders the current stream behind the side-stream part of the last refresh (once per stream); ``ent``: only if it was part of it"""
-        late = self._late
-        if late is None or (ent is not None and id(ent) not in late[1]):
-            return
-        s = torch.cuda.current_stream()
-        if s.cuda_stream not in late[2]:
-            s.wait_event(late[0])
-            late[2].add(s.cuda_stream)
 
     def clear(self):
-        self._wait_late()
-        self._late = None
         self.store.clear()
         self.derived.clear()
         self._tables.clear()
@@ -153,7 +138,6 @@ class _PackCache:
     def drop(self, w: torch.Tensor):
         """forget every image made from parameter ``w`` (its module was switched train()/eval() or reloaded)"""
         k = id(w)
-        self._wait_late()                            # (a buffer freed here may still be written by the side-stream pack)
         for key in [key for key in self.store if key[0] == k]:
             self.store.pop(key, None)
         for key in [key for key in self.derived if k in key[0]]:
@@ -183,14 +167,11 @@ class _PackCache:
             if _CACHE_CHECK and self.sums.get(key) != _checksum(w):
                 raise RuntimeError("packed-weight cache: parameter of shape %s changed without a version bump / optimizer step (a write "
                                    "through .data?) -- call mas_hip.ops.invalidate_weight_cache() after such writes" % (tuple(w.shape),))
-            if self._late is not None:
-                self._wait_late(hit)
             return hit[2]
         if hit is None or hit[0]() is not w or hit[2].device != w.device:
             n = _packed_elems(w.shape[0], w.shape[1], w.shape[2], layout)
             self.store[key] = [weakref.ref(w, lambda _r, k=key: self.store.pop(k, None)), None, torch.empty(n, dtype=dtype, device=w.device)]
         self._refresh_stale(w.device)
-        self._wait_late(self.store[key])
         return self.store[key][2]
 
     def _refresh_stale(self, device):
@@ -199,8 +180,7 @@ class _PackCache:
         (``mas_pack_conv_weight_tiles``: one launch for the whole model); fp32 images (the parity mode) keep the gather kernel
         (``mas_pack_conv_weight_batch``, also one launch).  The packed buffers are refreshed in place (nothing saves them for backward:
         the backward asks the cache again)."""
-        self._wait_late()                                      # (a previous side-stream refresh nobody waited for)
-        groups, items, item_ents, first, fresh, keep = {}, [], [], 0, [], []
+        groups, items, first, fresh, keep = {}, [], 0, [], []
         for key, ent in list(self.store.items()):                                  # (a weakref callback may pop entries meanwhile)
             wid, transpose, dtype, layout = key
             w = ent[0]()
@@ -218,20 +198,17 @@ class _PackCache:
             g = groups.get(wid)
             if dtype == torch.bfloat16 and ks <= 4 and layout != WLAYOUT_UP2 and (g is None or len(g[2]) < 4):
                 if g is None:
-                    g = groups[wid] = (wf, (cout, cin, ks), [], [])
+                    g = groups[wid] = (wf, (cout, cin, ks), [])
                 g[2].append((ent[2].data_ptr(), int(transpose), int(layout)))
-                g[3].append(ent)
                 continue
             nb = lib().mas_pack_batch_blocks(cout, cin, ks, int(transpose), _DT[dtype], int(layout))
             if nb <= 0:
                 raise RuntimeError(f"pack_conv_weight: unsupported weight shape {tuple(w.shape)}")
             items.append(PackItem(wf.data_ptr(), ent[2].data_ptr(), cout, cin, ks, int(transpose), _DT[dtype], int(layout), first, nb))
-            item_ents.append(ent)
             first += nb
-
-        def launch_tiles(which, glist):
+        if groups:
             titems, tfirst, max_ks = [], 0, 1
-            for wf, (cout, cin, ks), imgs, _ in glist:
+            for wf, (cout, cin, ks), imgs in groups.values():
                 it = PackTileItem()
                 it.w_oihw, it.n_img, it.Cout, it.Cin, it.ks, it.first_block = wf.data_ptr(), len(imgs), cout, cin, ks, tfirst
                 for k, (ptr, tr, lay) in enumerate(imgs):
@@ -239,39 +216,11 @@ class _PackCache:
                 titems.append(it)
                 tfirst += lib().mas_pack_tile_blocks(cout, cin, ks)
                 max_ks = max(max_ks, ks)
-            table = self._upload(which, device, (PackTileItem * len(titems))(*titems))
+            table = self._upload("tiles", device, (PackTileItem * len(titems))(*titems))
             check(lib().mas_pack_conv_weight_tiles(_ptr(table), len(titems), tfirst, max_ks, _stream()), "pack_conv_weight_tiles")
-
-        def launch_items():
+        if items:
             table = self._upload("batch", device, (PackItem * len(items))(*items))
             check(lib().mas_pack_conv_weight_batch(_ptr(table), len(items), first, _stream()), "pack_conv_weight_batch")
-
-        # The refresh after an optimizer step is HBM-bound (0.45 ms per step of the benched model) and the forward that asked for it starts
-        # with power-capped convolutions: the images of the first-used parameters (the store keeps first-use order) are packed on the
-        # current stream, everything else on the side stream BESIDE the first convolutions; the first get() of a late image makes its
-        # stream wait for the side launch (MAS_PACK_SIDE=0: everything on the current stream, as before).
-        glist, early_n = list(groups.values()), 0
-        if _PACK_SIDE and len(glist) > 8 and not keep and device.type == "cuda" and not torch.cuda.is_current_stream_capturing() and _side_stream_on():
-            got = 0
-            while early_n < len(glist) and got < _PACK_EARLY_BYTES:
-                got += 4 * glist[early_n][0].numel()
-                early_n += 1
-        if 0 < early_n < len(glist):
-            launch_tiles("tiles", glist[:early_n])
-
-            def late():
-                launch_tiles("tiles_late", glist[early_n:])
-                if items:
-                    launch_items()
-            _on_side_stream(late)
-            ev = torch.cuda.Event()
-            ev.record(_side_stream())
-            self._late = (ev, {id(e) for g in glist[early_n:] for e in g[3]} | {id(e) for e in item_ents}, set())
-        else:
-            if glist:
-                launch_tiles("tiles", glist)
-            if items:
-                launch_items()
         for ent, stamp in fresh:                                 # (a failed launch raised above: the entries stay invalid)
             ent[1] = stamp
 
