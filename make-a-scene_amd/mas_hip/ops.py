@@ -746,9 +746,15 @@ def _side_stream_on() -> bool:
     if ok is None and torch.cuda.is_current_stream_capturing():
         return False                                           # (no probe inside a graph capture; asked again at the next eager backward)
     if ok is None:
-        ok = _side_ok[dev] = os.environ.get("MAS_WGRAD_STREAM_PROBE", "1") != "1" or _streams_overlap(torch.cuda.current_stream(), _side_stream())
+        import warnings
+        try:
+            ok = os.environ.get("MAS_WGRAD_STREAM_PROBE", "1") != "1" or _streams_overlap(torch.cuda.current_stream(), _side_stream())
+        except Exception as e:                                  # (torch.cuda._sleep is a private helper: without it, one stream)
+            warnings.warn(f"mas_hip: the side-stream probe could not run ({type(e).__name__}: {e}); weight gradients stay on the current stream")
+            _streams_overlap.last = (float("nan"), float("nan"))
+            ok = False
+        _side_ok[dev] = ok
         if not ok:
-            import warnings
             warnings.warn("mas_hip: the weight-gradient side stream shares a HIP hardware queue with the current stream (its kernels would "
                           "serialise: one spin kernel %.3f ms, one per stream %.3f ms): weight gradients stay on the current stream.  Export GPU_MAX_HW_QUEUES=8 (or import mas_hip before "
                           "the first torch.cuda call) to get the overlapped schedule." % _streams_overlap.last)
