@@ -9,7 +9,8 @@
 // activated tensor is never stored) and every tap reads a column-shifted fragment of it: an aligned
 // 5-dword read + v_alignbit for the odd shift, plain register renaming for the even one.
 // One work-group (8 waves) owns a 128(co) x 64(ci) x all-taps accumulator block in registers and
-// walks a strided subset of the pixel tiles (split-K); partial sums are committed with fp32 atomics.
+// walks a strided subset of the pixel tiles (split-K); each split STORES its partial sums into its own slab (WgradParams::slabs, round 6:
+// mas_conv_wgrad_partial + the fixed-order mas_wgrad_reduce -- bitwise reproducible) or, through mas_conv_wgrad, commits with fp32 atomics.
 #include "mas_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -22,6 +23,8 @@ struct WgradParams {
     int N, H, W, Cin, Ho, Wo, Cout;
     int Hl, Wl, pad_top, pad_left, act, upsample;
     int tiles_h, tiles_w, n_pt, n_co_t, n_ci_t, nsplit;
+    int slabs;             // 0: commit with fp32 atomics into dw / dbias (zeroed by the caller).  1 (round 6): split s STORES its partial
+                           // sums into dw + s * Cout*KS*KS*Cin and dbias + s * Cout -- mas_wgrad_reduce adds the slabs in a fixed order
 };
 
 #ifndef MAS_WGRAD_BCI
@@ -107,6 +110,27 @@ __device__ __forceinline__ void store_quad_bf16(bf16_t* base, int row_stride, in
         bf16_t* dst = base + (cu * 8 + 2 * k) * row_stride + (cu & 7) * 8 + col;    // rows skewed by (cu&7)*16 B
         *reinterpret_cast<u32x2*>(dst) = u32x2{lo01, lo23};
         *reinterpret_cast<u32x2*>(dst + row_stride) = u32x2{hi01, hi23};
+    }
+}
+
+// Bias gradient of one work-group: every thread holds the column sums (EPU channels of unit `cu` = tid % UPP) of the dY elements it staged.
+// Through LDS, added in THREAD ORDER (the first version used LDS float atomics: the order of the additions, and with it the last bits, changed
+// run to run); then one store into this split's slab, or one fp32 atomic per channel into the caller's zeroed vector.
+template <int NT, int EPU, int UPP>
+__device__ __forceinline__ void commit_bias(unsigned char* smem, int tid, int cu, const float (&bsum)[EPU], float* dst, int n_live, int slabs) {
+    static_assert(NT % UPP == 0, "threads of one channel unit are tid = cu, cu + UPP, ...");
+    __syncthreads();                                     // the staging buffers are dead: every wave is past its last fragment read
+    float* red = reinterpret_cast<float*>(smem);         // [NT / UPP][UPP * EPU]
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) red[(tid / UPP) * (UPP * EPU) + cu * EPU + e] = bsum[e];
+    __syncthreads();
+    for (int i = tid; i < UPP * EPU; i += NT) {
+        float v = 0.0f;
+        for (int k = 0; k < NT / UPP; ++k) v += red[k * (UPP * EPU) + i];
+        if (i < n_live) {
+            if (slabs) dst[i] = v;
+            else atomicAdd(dst + i, v);
+        }
     }
 }
 
@@ -464,8 +488,9 @@ __global__ __launch_bounds__(WSplit<KS>::NTW) void conv_wgrad_kernel(WgradParams
 #endif
     }
 
-    // ---- commit: fp32 atomics into dW[co][kh][kw][ci] --------------------------------
+    // ---- commit: dW[co][kh][kw][ci], fp32 atomics or this split's slab --------------------------------
     const int ci = ci0 + wci + l31;
+    float* dwp = p.dw + (p.slabs ? (size_t)split * p.Cout * NTAP * p.Cin : 0);
     auto commit = [&](auto HALF) {
         constexpr int LO = decltype(HALF)::value * TPH, HI = (LO + TPH < NTAP) ? LO + TPH : NTAP;
         if (ci < p.Cin) {
@@ -474,24 +499,17 @@ __global__ __launch_bounds__(WSplit<KS>::NTW) void conv_wgrad_kernel(WgradParams
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + wco + acc_row(lane, r);
-                    if (co < p.Cout) atomicAdd(p.dw + ((size_t)co * NTAP + t) * p.Cin + ci, acc[t - LO][r]);
+                    if (co < p.Cout) {
+                        float* dst = dwp + ((size_t)co * NTAP + t) * p.Cin + ci;
+                        if (p.slabs) *dst = acc[t - LO][r];
+                        else atomicAdd(dst, acc[t - LO][r]);
+                    }
                 }
         }
     };
     if (SPLIT == 1 || half == 0) commit(std::integral_constant<int, 0>{});
     else commit(std::integral_constant<int, SPLIT - 1>{});
-    if (do_bias) {
-        // reduce the per-thread column sums over threads that share a channel group (through LDS)
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);       // [BCO]
-        for (int i = tid; i < BCO; i += NTW) red[i] = 0.0f;
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < EPU; ++e) atomicAdd(&red[dy_cu * EPU + e], bsum[e]);
-        __syncthreads();
-        for (int i = tid; i < BCO; i += NTW)
-            if (co0 + i < p.Cout) atomicAdd(p.dbias + co0 + i, red[i]);
-    }
+    if (do_bias) commit_bias<NTW, EPU, DY_UPP>(smem, tid, dy_cu, bsum, p.dbias + (p.slabs ? (size_t)split * p.Cout : 0) + co0, p.Cout - co0, p.slabs);
 }
 
 
@@ -686,6 +704,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgradParams p) {
     }
 
     const int ci = ci0 + wci + l31;
+    float* dwp = p.dw + (p.slabs ? (size_t)split * p.Cout * NTAP * p.Cin : 0);
     auto commit = [&](auto HALF) {
         constexpr int LO = decltype(HALF)::value * TPH, HI = (LO + TPH < NTAP) ? LO + TPH : NTAP;
         if (ci < p.Cin) {
@@ -694,30 +713,24 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgradParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + wco + acc_row(lane, r);
-                    if (co < p.Cout) atomicAdd(p.dw + ((size_t)co * NTAP + t) * p.Cin + ci, acc[t - LO][r]);
+                    if (co < p.Cout) {
+                        float* dst = dwp + ((size_t)co * NTAP + t) * p.Cin + ci;
+                        if (p.slabs) *dst = acc[t - LO][r];
+                        else atomicAdd(dst, acc[t - LO][r]);
+                    }
                 }
         }
     };
     if (SPLIT == 1 || half == 0) commit(std::integral_constant<int, 0>{});
     else commit(std::integral_constant<int, SPLIT - 1>{});
-    if (do_bias) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);
-        for (int i = tid; i < BCO; i += NT) red[i] = 0.0f;
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(&red[dy_cu * 8 + e], bsum[e]);
-        __syncthreads();
-        for (int i = tid; i < BCO; i += NT)
-            if (co0 + i < p.Cout) atomicAdd(p.dbias + co0 + i, red[i]);
-    }
+    if (do_bias) commit_bias<NT, 8, 16>(smem, tid, dy_cu, bsum, p.dbias + (p.slabs ? (size_t)split * p.Cout : 0) + co0, p.Cout - co0, p.slabs);
 }
 
 #ifndef MAS_WGRAD_TR_BCI
 #define MAS_WGRAD_TR_BCI 64
 #endif
 template <int KS, int BCI_ = MAS_WGRAD_TR_BCI>
-int launch_tr(WgradParams p, hipStream_t s) {
+int launch_tr(WgradParams p, hipStream_t s, int* splits_only) {
     using G = TrGeo<KS, BCI_>;
     auto kern = conv_wgrad_tr_kernel<KS, BCI_>;
     static mas_devmask_t attr_mask{0};
@@ -735,13 +748,14 @@ int launch_tr(WgradParams p, hipStream_t s) {
     if (nsplit > p.n_pt) nsplit = p.n_pt;
     if (nsplit < 1) nsplit = 1;
     p.nsplit = nsplit;
+    if (splits_only) { *splits_only = nsplit; return MAS_OK; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(out_tiles * nsplit)), dim3(G::NT), G::LDS_BYTES, s, p);
     MAS_CHECK_LAUNCH("conv_wgrad_tr");
     return MAS_OK;
 }
 
 template <typename T, int KS, int STRIDE, int THW>
-int launch(WgradParams p, hipStream_t s) {
+int launch(WgradParams p, hipStream_t s, int* splits_only) {
     using G = WGeo<T, KS, STRIDE, THW>;
     auto kern = conv_wgrad_kernel<T, KS, STRIDE, THW>;
     static mas_devmask_t attr_mask{0};
@@ -759,31 +773,65 @@ int launch(WgradParams p, hipStream_t s) {
     if (nsplit > p.n_pt) nsplit = p.n_pt;
     if (nsplit < 1) nsplit = 1;
     p.nsplit = nsplit;
+    if (splits_only) { *splits_only = nsplit; return MAS_OK; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(out_tiles * nsplit)), dim3(WSplit<KS>::NTW), G::LDS_BYTES, s, p);
     MAS_CHECK_LAUNCH("conv_wgrad");
     return MAS_OK;
 }
 
 template <typename T>
-int launch_t(const WgradParams& p, int ks, int stride, hipStream_t s) {
+int launch_t(const WgradParams& p, int ks, int stride, hipStream_t s, int* splits_only = nullptr) {
     if constexpr (sizeof(T) == 2) {
         if (stride == 1 && (p.Cout % 8) == 0 && (p.Cin % 8) == 0) {
-            if (ks == 3) return launch_tr<3>(p, s);
-            if (ks == 1) return launch_tr<1>(p, s);
+            if (ks == 3) return launch_tr<3>(p, s, splits_only);
+            if (ks == 1) return launch_tr<1>(p, s, splits_only);
             // discriminator geometries (reference losses/discriminator.py:20-36): 4x4 stride 1 directly (32-channel input
             // slices: two waves share a 32x32 tile and split the 16 taps 8 / 8); 4x4 stride 2 as the 2x2 stride-1
             // convolution of the space-to-depth input (mas_space_to_depth2x; the host wrapper un-permutes dW)
-            if (ks == 4) return launch_tr<4, 32>(p, s);
-            if (ks == 2) return launch_tr<2, 64>(p, s);
+            if (ks == 4) return launch_tr<4, 32>(p, s, splits_only);
+            if (ks == 2) return launch_tr<2, 64>(p, s, splits_only);
         }
     }
-    if (ks == 1 && stride == 1) return launch<T, 1, 1, 8>(p, s);
-    if (ks == 3 && stride == 1) return launch<T, 3, 1, 8>(p, s);
-    if (ks == 3 && stride == 2) return launch<T, 3, 2, 4>(p, s);
+    if (ks == 1 && stride == 1) return launch<T, 1, 1, 8>(p, s, splits_only);
+    if (ks == 3 && stride == 1) return launch<T, 3, 1, 8>(p, s, splits_only);
+    if (ks == 3 && stride == 2) return launch<T, 3, 2, 4>(p, s, splits_only);
+    if (splits_only) { *splits_only = 0; return MAS_OK; }
     MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad: unsupported ks=%d stride=%d", ks, stride);
 }
 
+WgradParams general_params(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy, float* dw, float* dbias, int slabs) {
+    WgradParams p;
+    p.dbg = nullptr;
+    p.x = x; p.ss = scale_shift; p.dy = dy; p.dw = dw; p.dbias = dbias;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+    p.Hl = d->upsample ? 2 * d->H : d->H; p.Wl = d->upsample ? 2 * d->W : d->W;
+    p.pad_top = d->pad_top; p.pad_left = d->pad_left; p.act = d->act; p.upsample = d->upsample;
+    p.tiles_h = p.tiles_w = p.n_pt = p.n_co_t = p.n_ci_t = p.nsplit = 0;
+    p.slabs = slabs;
+    return p;
+}
+
 }  // namespace
+
+// The general kernels as split-K SLABS (round 6): every shape without a kernel of its own -- the 159-channel edge convolutions of VQ-SEG, the
+// discriminator's 4x4 convolutions, the exact-fp32 parity mode -- used to commit with fp32 atomics, the only order-dependent sums left in a
+// training step.  mas_conv_wgrad_splits / mas_conv_wgrad_partial (conv_wgrad_dma.hip) fall through to these two.
+int mas_conv_wgrad_general_splits(const MasConvDesc* d) {
+    if (!d || d->Cin % 4 != 0 || (d->upsample && d->stride != 1)) return 0;       // (mas_wgrad_reduce reads the slabs as float4 along Cin)
+    const WgradParams p = general_params(d, nullptr, nullptr, nullptr, nullptr, nullptr, 1);
+    int k = 0;
+    if (d->in_dtype == MAS_BF16) launch_t<bf16_t>(p, d->ks, d->stride, nullptr, &k);
+    else if (d->in_dtype == MAS_F32) launch_t<float>(p, d->ks, d->stride, nullptr, &k);
+    return k;
+}
+
+int mas_conv_wgrad_general_partial(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy, float* part, float* part_bias,
+                                   hipStream_t s) {
+    const WgradParams p = general_params(d, x, scale_shift, dy, part, part_bias, 1);
+    if (d->in_dtype == MAS_BF16) return launch_t<bf16_t>(p, d->ks, d->stride, s);
+    if (d->in_dtype == MAS_F32) return launch_t<float>(p, d->ks, d->stride, s);
+    MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad: unsupported dtype %d", d->in_dtype);
+}
 
 int mas_conv_wgrad_dma_try(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy, float* dw, float* dbias,
                            hipStream_t s);   // conv_wgrad_dma.hip
@@ -798,16 +846,10 @@ extern "C" int mas_conv_wgrad(const MasConvDesc* d, const void* x, const float* 
         const int rc = mas_conv_wgrad_dma_try(d, x, scale_shift, dy, dw, dbias, reinterpret_cast<hipStream_t>(stream));
         if (rc != 0) return rc < 0 ? rc : MAS_OK;
     }
-    WgradParams p;
-    p.dbg = nullptr;
+    WgradParams p = general_params(d, x, scale_shift, dy, dw, dbias, 0);
 #ifdef MAS_TIMELINE          // s_memtime timeline builds only (tools/build_variant.sh tl -DMAS_TIMELINE)
     if (const char* e = getenv("MAS_DBG_PTR")) p.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
 #endif
-    p.x = x; p.ss = scale_shift; p.dy = dy; p.dw = dw; p.dbias = dbias;
-    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
-    p.Hl = d->upsample ? 2 * d->H : d->H; p.Wl = d->upsample ? 2 * d->W : d->W;
-    p.pad_top = d->pad_top; p.pad_left = d->pad_left; p.act = d->act; p.upsample = d->upsample;
-    p.tiles_h = p.tiles_w = p.n_pt = p.n_co_t = p.n_ci_t = p.nsplit = 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d->in_dtype == MAS_BF16) return launch_t<bf16_t>(p, d->ks, d->stride, s);
     if (d->in_dtype == MAS_F32) return launch_t<float>(p, d->ks, d->stride, s);

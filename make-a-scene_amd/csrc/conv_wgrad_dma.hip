@@ -601,13 +601,23 @@ int mas_wgrad_s2_partial(const MasConvDesc* d, const void* x, const void* dy, fl
 int mas_wgrad_thin_splits(const MasConvDesc* d);                                  // conv_thin.hip
 int mas_wgrad_thin_partial(const MasConvDesc* d, const void* x, const void* dy, float* part, float* part_bias, hipStream_t s);
 
+int mas_conv_wgrad_general_splits(const MasConvDesc* d);                          // conv_wgrad.hip: the general kernels in slab mode
+int mas_conv_wgrad_general_partial(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy, float* part, float* part_bias,
+                                   hipStream_t s);
+
+// MAS_WGRAD_GENERAL_SLABS=0: shapes without a slab kernel of their own report 0 splits again and take mas_conv_wgrad's fp32 atomics
+static bool general_slabs() { static const int on = mas_env_int("MAS_WGRAD_GENERAL_SLABS", 1); return on != 0; }
+
 extern "C" int mas_conv_wgrad_splits(const MasConvDesc* d) {
     DmaWgradParams p;
     if (!d) return 0;
-    if (d->ks == 1) return mas_wgrad1x1_splits(d);
-    if (d->stride == 2) return mas_wgrad_s2_splits(d);
-    if (!dma_setup(d, p)) return mas_wgrad_thin_splits(d);
-    return p.nsplit;
+    int k;
+    if (d->ks == 1) k = mas_wgrad1x1_splits(d);
+    else if (d->stride == 2) k = mas_wgrad_s2_splits(d);
+    else if (!dma_setup(d, p)) k = mas_wgrad_thin_splits(d);
+    else k = p.nsplit;
+    if (k > 0 || !general_slabs()) return k;
+    return mas_conv_wgrad_general_splits(d);
 }
 
 // The weight gradient as split-K PARTIALS: part [nsplit][Cout][3][3][Cin] fp32 and (when non-NULL) part_bias [nsplit][Cout], every
@@ -620,11 +630,15 @@ extern "C" int mas_conv_wgrad_partial(const MasConvDesc* d, const void* x, const
     if (d->act != MAS_ACT_NONE && !scale_shift) MAS_FAIL(MAS_EINVAL, "conv_wgrad_partial: act prologue needs scale_shift");
     if (d->ks == 1) {                            // plain GEMM (conv1x1.hip)
         const int rc = mas_wgrad1x1_partial(d, x, dy, part, part_bias, reinterpret_cast<hipStream_t>(stream));
+        if (rc == 0 && general_slabs() && mas_conv_wgrad_general_splits(d) > 0)
+            return mas_conv_wgrad_general_partial(d, x, scale_shift, dy, part, part_bias, reinterpret_cast<hipStream_t>(stream));
         if (rc == 0) MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad_partial: this 1x1 convolution does not take the split-K partial path (mas_conv_wgrad_splits == 0)");
         return rc < 0 ? rc : MAS_OK;
     }
     if (d->stride == 2) {                        // Downsample: conv_s2.hip
         const int rc = mas_wgrad_s2_partial(d, x, dy, part, part_bias, reinterpret_cast<hipStream_t>(stream));
+        if (rc == 0 && general_slabs() && mas_conv_wgrad_general_splits(d) > 0)
+            return mas_conv_wgrad_general_partial(d, x, scale_shift, dy, part, part_bias, reinterpret_cast<hipStream_t>(stream));
         if (rc == 0) MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad_partial: this stride-2 convolution does not take the split-K partial path (mas_conv_wgrad_splits == 0)");
         return rc < 0 ? rc : MAS_OK;
     }
@@ -633,6 +647,8 @@ extern "C" int mas_conv_wgrad_partial(const MasConvDesc* d, const void* x, const
         const int rc = mas_wgrad_thin_partial(d, x, dy, part, part_bias, reinterpret_cast<hipStream_t>(stream));
         if (rc != 0) return rc < 0 ? rc : MAS_OK;
     }
+    if (!dma_setup(d, p) && general_slabs() && mas_conv_wgrad_general_splits(d) > 0)      // every other shape: the general kernels' slab mode
+        return mas_conv_wgrad_general_partial(d, x, scale_shift, dy, part, part_bias, reinterpret_cast<hipStream_t>(stream));
     if (!dma_setup(d, p)) MAS_FAIL(MAS_EUNSUPPORTED, "conv_wgrad_partial: this convolution does not take the split-K partial path (mas_conv_wgrad_splits == 0)");
     p.x = (const unsigned char*)x; p.ss = scale_shift; p.dy = (const unsigned char*)dy; p.dw = nullptr; p.dbias = nullptr;
     p.part = part; p.part_bias = part_bias;
