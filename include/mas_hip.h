@@ -206,7 +206,10 @@ int mas_conv_s2_dgrad(const MasConvDesc* d, const void* dy, const void* w_packed
 /* Deterministic split-K (ABI v3): for the convolutions that carry the FLOPs (mas_conv_wgrad_splits(d) = nsplit > 0: bf16, stride 1, no
  * prologue; 3x3 with Cin % 64 == 0, Cout % 128 == 0, or 1x1 with Cin % 128 == 0, Cout % 128 == 0: part is then [nsplit][Cout][ks][ks][Cin]) mas_conv_wgrad_partial writes the nsplit partial sums -- part [nsplit][Cout][3][3][Cin] fp32,
  * part_bias [nsplit][Cout] or NULL, every element exactly once, plain stores, no initialisation required -- and mas_wgrad_reduce adds
- * the slabs in a fixed order into dw_oihw [Cout][Cin][ks][ks] / dbias [Cout]: no atomics, bitwise reproducible run to run.          */
+ * the slabs in a fixed order into dw_oihw [Cout][Cin][ks][ks] / dbias [Cout]: no atomics, bitwise reproducible run to run.
+ * Round 6 (no ABI change): every other geometry mas_conv_wgrad accepts (ks 1..4, stride 1 / 2, bf16 / fp32, prologue or not, Cin % 4 == 0)
+ * reports nsplit > 0 too and runs the general kernels in slab mode; 0 is returned only for Cin % 4 != 0 (or MAS_WGRAD_GENERAL_SLABS=0),
+ * and only then is mas_conv_wgrad's atomic commit the route.                                                                         */
 int mas_conv_wgrad_splits(const MasConvDesc* d);
 int mas_conv_wgrad_partial(const MasConvDesc* d, const void* x, const float* scale_shift, const void* dy,
                            float* part, float* part_bias, void* stream);

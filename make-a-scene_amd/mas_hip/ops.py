@@ -625,7 +625,8 @@ def conv_wgrad_raw(x, ss, dy, n, h, w, cin, ho, wo, cout, ks, stride, pt, pl, ac
         check(lib().mas_wgrad_reduce(_ptr(ws), C.c_void_p(pb0) if want_bias else None, tot, _ptr(dwo), _ptr(db), cout, cin, ks, _stream()),
               "wgrad_reduce")
         return dwo, db
-    # The other split-K kernels ADD into a zero accumulator.  One persistent scratch per (device, stream), zeroed once, is handed to every
+    # (Round 6: mas_conv_wgrad_splits is > 0 for every geometry ops produces -- the general kernels have a slab mode --, so this route is
+    #  only reached with MAS_WGRAD_GENERAL_SLABS=0.)  The other split-K kernels ADD into a zero accumulator.  One persistent scratch per (device, stream), zeroed once, is handed to every
     # weight-gradient launch; ``mas_wgrad_commit`` moves the sums into a fresh OIHW gradient tensor (+ bias gradient) and zeroes the
     # scratch again while it reads it: no fill launch and no permute copy per convolution (round 2: 356 fills per VQ-IMG step).
     acc = _wgrad_scratch.get(key)
