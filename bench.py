@@ -8,7 +8,9 @@
 --workload vq (default, BASELINE.json's metric): one "step" = one pass of the hot path over one per-GPU batch of synthetic
 images: ``rec, q = VQBASE(x); (|x-rec|.mean() + q).backward(); Adam.step()`` on the model block of the reference's
 conf/img_config.yaml (BASELINE configs[1]: VQ-IMG 256x256, codebook 8192, per-GPU batch 32, bf16 activations, fp32 accumulate).
-Inputs are resident in HBM before the timed region.  N > 1: one process per GPU, the reference's own data-parallel scheme
+Inputs are resident in HBM before the timed region.  (Since round 6 each layer's weight gradient is issued on a second HIP stream beside its
+GroupNorm backward passes -- mas_hip.ops, MAS_WGRAD_STREAM -- and this file defaults GPU_MAX_HW_QUEUES=8 so that RCCL's streams leave it a
+hardware queue of its own; the timed region still ends with a device-wide synchronize.)  N > 1: one process per GPU, the reference's own data-parallel scheme
 (train.py:24,32: NCCL==RCCL process group + bucketed gradient all-reduce overlapped with backward; SyncBatchNorm's statistics
 all-gather), weak scaling (per-GPU batch fixed).
 
