@@ -81,5 +81,5 @@ for t in range(trials):
             if done:
                 break
         print(msg)
-print(f"MAS_WGRAD_STREAM={os.environ.get('MAS_WGRAD_STREAM', '1')} MAS_PACK_SIDE={os.environ.get('MAS_PACK_SIDE', '1')} CHECK={check}: "
+print(f"MAS_WGRAD_STREAM={os.environ.get('MAS_WGRAD_STREAM', '1')} CHECK={check}: "
       f"{trials} trials of {steps} steps, {nbad} differ from the first")
