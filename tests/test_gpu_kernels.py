@@ -272,3 +272,26 @@ def test_conv_full_size_properties():
     assert relerr(dw2, 2 * dw) < 1e-5 and relerr(db2, 2 * db) < 1e-5
     # column sums of dy == bias gradient (independent fp64 reduction on the GPU tensor)
     assert relerr(db, dy.double().sum((0, 2, 3)).float()) < 1e-4
+
+
+def test_general_conv_kernel_repeats_bitwise_beside_memory_traffic():
+    """Regression test for the barrier hole of conv_fwd.hip (round 6, profiles/r06_determinism.txt): the barrier that publishes weight stage 0
+    was not guarded by a vmcnt wait for a wave that owns no slot of the last patch row, and about one launch in 5 000 of the encoder's last
+    convolution (32 x 512 x 16 x 16 -> 256, bf16 in, fp32 out) read a stale 1 KiB weight piece -- but only with other traffic on the memory
+    system between launches.  20 000 launches with a streaming add every eighth one, an integer checksum of each output on the device: a
+    library built from the file before the fix fails this with 4 differing launches (gpurun r6_56), the fixed one with 0."""
+    from mas_hip import ops, ACT_NONE
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    n, cin, h, cout = 32, 512, 16, 256
+    x = torch.randn(n, cin, h, h, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter((torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(dev))
+    big = torch.zeros(64 << 20, dtype=torch.float32, device=dev)
+    sums = []
+    for r in range(20000):
+        if r % 8 == 0:
+            big.add_(1.0)
+        y = ops.conv_fwd_raw(x, None, ops.ConvWeight(w, False), None, None, n, h, h, cin, h, h, cout, 3, 1, 1, 1, ACT_NONE, False, torch.float32)
+        sums.append(y.view(torch.int32).sum())
+    t = torch.stack(sums).cpu()
+    assert int((t != t[0]).sum()) == 0
