@@ -36,6 +36,7 @@ from mas_hip import ops
 # 0 = torch's implementation everywhere.  MAS_SYNCBN_EXCHANGE_AT_WORLD_1=1 (tests): a one-rank group exchanges too.
 _MAS_SYNCBN = int(os.environ.get("MAS_SYNCBN", "2"))
 _EXCHANGE_AT_WORLD_1 = os.environ.get("MAS_SYNCBN_EXCHANGE_AT_WORLD_1", "0") == "1"
+_RESERVOIR_ASYNC = os.environ.get("MAS_RESERVOIR_ASYNC", "1") == "1"          # 0: the codebook's reservoir permutations reach the GPU by a blocking copy
 
 
 def nonlinearity(x):
@@ -329,12 +330,28 @@ class Codebook(nn.Module):
         self.reservoir_size = int(reservoir_size)
         self.reservoir = None
 
+    @staticmethod
+    def _randperm(n, device, keep=None):
+        """``torch.randperm(n)[:keep]`` as the reference draws it -- on the CPU, from the default generator (modules.py:479,481) -- delivered to
+        ``device`` WITHOUT a host synchronisation: through a pinned staging tensor and a non-blocking copy (the caching host allocator keeps
+        the block until the copy has run).  The reference indexes a CUDA tensor with the CPU permutation, ``torch.randperm(n, device="cuda")``
+        copies its small-n CPU result with a blocking copy: either way the host waits for the whole encoder forward it has queued, twice per
+        step, and the short kernels that follow (the decoder's 16 x 16 layers) run host-bound (profiles/r06_host_sync.txt)."""
+        p = torch.randperm(n)
+        if keep is not None:
+            p = p[:keep]
+        if device.type != "cuda" or not _RESERVOIR_ASYNC:
+            return p.to(device)
+        pinned = torch.empty(p.numel(), dtype=p.dtype, pin_memory=True)
+        pinned.copy_(p)
+        return pinned.to(device, non_blocking=True)
+
     def _collect(self, z_flat, batch_size):
         # reservoir sampling of 10 latents / image (reference modules.py:477-481)
         z_new = z_flat.detach().reshape(batch_size, -1, self.codebook_dim)
-        z_new = z_new[:, torch.randperm(z_new.size(1), device=z_new.device)][:, :10].reshape(-1, self.codebook_dim)
+        z_new = z_new[:, self._randperm(z_new.size(1), z_new.device)][:, :10].reshape(-1, self.codebook_dim)
         self.reservoir = z_new if self.reservoir is None else torch.cat([self.reservoir, z_new], dim=0)
-        keep = torch.randperm(self.reservoir.size(0), device=self.reservoir.device)[:self.reservoir_size]
+        keep = self._randperm(self.reservoir.size(0), self.reservoir.device, self.reservoir_size)
         self.reservoir = self.reservoir[keep].detach()
 
     def _reinit_from_reservoir(self):

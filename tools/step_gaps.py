@@ -1,41 +1,48 @@
 #!/usr/bin/env python3
-"""GPU busy fraction of one training step from a rocprofv3 --kernel-trace results.db: the window between the last two optimizer
-launches (multi_tensor_apply ... FusedAdam) -- wall time, sum of kernel durations, number of launches, idle gaps by size, and the
-kernels that precede the largest gaps.  Usage: step_gaps.py results.db"""
+"""Idle time inside one training step from a rocprofv3 --kernel-trace results.db: the window between the last two optimizer launches, the union
+of busy intervals over all queues, and the largest gaps with the kernels on either side.  Usage: step_gaps.py results.db [top_n]"""
 import sqlite3
 import sys
-from collections import Counter
 
 
 def main():
     con = sqlite3.connect(sys.argv[1])
+    top = int(sys.argv[2]) if len(sys.argv) > 2 else 25
     cur = con.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
     kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
     ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
     rows = cur.execute(f"select d.start, d.end, s.kernel_name from {kd} d join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
-    adam = [i for i, r in enumerate(rows) if "FusedAdam" in r[2] or "multi_tensor_apply" in r[2]]
-    # group consecutive optimizer launches into steps
-    ends = [adam[i] for i in range(len(adam)) if i + 1 == len(adam) or adam[i + 1] - adam[i] > 50]
-    if len(ends) < 2:
-        print("need two optimizer steps in the trace"); return
-    a, b = ends[-2] + 1, ends[-1] + 1
+    adam = [i for i, r in enumerate(rows) if "adam_multi" in r[2]]
+    a, b = adam[-2] + 1, adam[-1] + 1
     win = rows[a:b]
-    wall = win[-1][1] - win[0][0]
-    busy = sum(e - s for s, e, _ in win)
-    gaps = [(win[i + 1][0] - win[i][1], win[i][2], win[i + 1][2]) for i in range(len(win) - 1)]
-    pos = [g for g in gaps if g[0] > 0]
-    print(f"step window: {len(win)} launches, wall {wall / 1e6:.3f} ms, kernels {busy / 1e6:.3f} ms ({100 * busy / wall:.1f} % busy), "
-          f"idle {sum(g[0] for g in pos) / 1e6:.3f} ms in {len(pos)} gaps (overlap {-sum(g[0] for g in gaps if g[0] < 0) / 1e6:.3f} ms)")
-    for lo, hi in ((0, 2), (2, 5), (5, 10), (10, 20), (20, 50), (50, 1e9)):
-        sel = [g[0] for g in pos if lo * 1e3 <= g[0] < hi * 1e3]
-        print(f"  gaps {lo:>3}-{hi if hi < 1e9 else 'inf':>3} us: {len(sel):5d}  total {sum(sel) / 1e6:.3f} ms")
-    c = Counter()
-    for g, before, after in pos:
-        c[(before[:50], after[:50])] += g
-    print("largest idle by (kernel before -> kernel after):")
-    for (bk, ak), t in c.most_common(12):
-        print(f"  {t / 1e6:7.3f} ms  {bk}  ->  {ak}")
+    t0 = win[0][0]
+    t1 = max(r[1] for r in win)
+    cover_end, gaps, busy = win[0][0], [], 0
+    last_name = "(previous step's adam_multi)"
+    cur_start = win[0][0]
+    for s, e, name in win:
+        if s > cover_end:
+            gaps.append((s - cover_end, last_name, name, cover_end - t0))
+            busy += cover_end - cur_start
+            cur_start = s
+        if e > cover_end:
+            cover_end, last_name = e, name
+    busy += cover_end - cur_start
+    short = lambda n: n.replace("_ZN12_GLOBAL__N_1", "").replace("void ", "")[:44]
+    tot_gap = sum(g[0] for g in gaps)
+    print(f"step: {len(win)} launches, wall {(t1 - t0) / 1e6:.3f} ms, busy {busy / 1e6:.3f} ms, idle {tot_gap / 1e6:.3f} ms in {len(gaps)} gaps")
+    hist = [(1, 0, 0), (2, 0, 0), (5, 0, 0), (10, 0, 0), (50, 0, 0), (1e9, 0, 0)]
+    hist = [[h[0], 0, 0] for h in hist]
+    for g in gaps:
+        for h in hist:
+            if g[0] / 1e3 < h[0]:
+                h[1] += 1
+                h[2] += g[0]
+                break
+    print("gap length histogram (us: count, total us): " + ", ".join(f"<{h[0]:g}: {h[1]}, {h[2] / 1e3:.0f}" for h in hist))
+    for g in sorted(gaps, reverse=True)[:top]:
+        print(f"  {g[0] / 1e3:8.1f} us at {g[3] / 1e6:7.3f} ms   after {short(g[1])}   before {short(g[2])}")
 
 
 if __name__ == "__main__":
