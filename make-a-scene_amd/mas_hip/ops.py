@@ -755,12 +755,12 @@ def _side_stream_on() -> bool:
             _streams_overlap.last = (float("nan"), float("nan"))
             ok = False
         _side_ok[dev] = ok
-        if not ok:
+        if not ok and _WGRAD_CUS_IS_OURS:
+            os.environ["MAS_WGRAD_CUS"] = "0"               # the 3/4 grid only pays beside the GroupNorm passes
+        if not ok and _streams_overlap.last[0] == _streams_overlap.last[0]:        # (not after a probe that could not run: it has warned already)
             warnings.warn("mas_hip: the weight-gradient side stream shares a HIP hardware queue with the current stream (its kernels would "
                           "serialise: one spin kernel %.3f ms, one per stream %.3f ms): weight gradients stay on the current stream.  Export GPU_MAX_HW_QUEUES=8 (or import mas_hip before "
                           "the first torch.cuda call) to get the overlapped schedule." % _streams_overlap.last)
-            if _WGRAD_CUS_IS_OURS:
-                os.environ["MAS_WGRAD_CUS"] = "0"           # the 3/4 grid only pays beside the GroupNorm passes
     return ok
 
 
